@@ -1,0 +1,169 @@
+/* mscl_hip.h -- C ABI of libmscl_hip.so: the MI355X (gfx950) kernels of the MSCL training hot path.
+ *
+ * The reference has NO native layer on this path: every entry point below replaces
+ * a PyTorch op chain of the reference, cited per function as reference file:line (relative to the
+ * reference repo root).  Conventions:
+ *   - activations are NDHWC bf16 (uint16 storage), channel count a multiple of 8;
+ *   - parameters are fp32 masters with a bf16 shadow; conv kernels are laid out [Cout][kT][kH][kW][Cin]
+ *     (the memory order of a channels_last_3d torch tensor of logical shape (Cout,Cin,kT,kH,kW));
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     immediately: 0 = ok, <0 = argument error (MSCL_E_*), >0 = hipError_t of the launch;
+ *   - pointers are device pointers borrowed for the duration of the call; nothing is allocated.
+ */
+#ifndef MSCL_HIP_H
+#define MSCL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSCL_E_ARG      (-1)   /* null pointer / non-positive size */
+#define MSCL_E_SHAPE    (-2)   /* shape unsupported by the kernel family (e.g. C % 8 != 0) */
+#define MSCL_E_STRIDE   (-3)   /* stride other than 1 or 2 where the kernel needs a power of two */
+
+typedef struct {
+  int N, T, H, W, C;      /* conv input  x  (N,T,H,W,C)  */
+  int To, Ho, Wo, K;      /* conv output y  (N,To,Ho,Wo,K) */
+  int kT, kH, kW;
+  int sT, sH, sW;
+  int pT, pH, pW;
+} mscl_conv_desc;
+
+int mscl_abi_version(void);
+
+/* ---- Conv3d as implicit GEMM on MFMA (bf16 in, fp32 accumulate) --------------------------------
+ * replaces nn.Conv3d forward in r3d.py:16-34,176-184,285-288 / fastonly.py:61-80,185-193 /
+ * necks/fpn.py:131-149 / necks/sepc.py:74-104.
+ * y = conv(x, w) [+ bias] [+ addend] [relu];  optional per-channel sum / sum-of-squares of the
+ * fp32 result accumulated (atomically) into stat_sum/stat_sq (K floats each, caller zeroes them):
+ * the BatchNorm batch statistics of r3d.py:103-127 fused into the producer. */
+int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w_bf16, uint16_t* y,
+                    const float* bias, const uint16_t* addend, int relu,
+                    float* stat_sum, float* stat_sq, void* stream);
+
+/* dx = conv_transpose(dy, w) [+ addend]; wT_bf16 is the kernel re-laid out [Cin][kT][kH][kW][Cout]
+ * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient. */
+int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT_bf16, uint16_t* dx,
+                      const uint16_t* addend, void* stream);
+
+/* dw[Cout][taps][Cin] (fp32) += sum over positions of dy (x) x ; atomically accumulated, so the
+ * caller zeroes dw once per step and repeated traversals of a shared trunk simply add up
+ * (the flow encoder is traversed twice, recognizers/mscl.py:239-240).  dbias (K floats, optional)
+ * += sum over positions of dy.  Replaces autograd's conv3d weight/bias gradient. */
+int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
+                      float* dbias, void* stream);
+
+/* [Cout][taps][Cin] bf16 -> [Cin][taps][Cout] bf16 */
+int mscl_weight_transpose(const uint16_t* w, uint16_t* wT, int Cout, int taps, int Cin, void* stream);
+
+/* ---- BatchNorm3d (training mode) + ReLU + residual -------------------------------------------
+ * replaces nn.BatchNorm3d/ReLU/`out += residual` in r3d.py:95-127, fastonly.py:104-136.
+ * stats = {sum[C], sumsq[C]} from mscl_conv3d_fwd.  Computes mean/var over `rows` positions,
+ * out = relu?( (y-mean)*invstd*gamma+beta + residual ), writes mean/invstd (saved for backward)
+ * and updates running_mean/var (momentum, unbiased var) and num_batches_tracked (int64) in place.
+ * If res_sum != NULL the residual is itself a raw conv output normalised with its own statistics
+ * (the downsample branch r3d.py:285-288): its saved mean/invstd go to res_mean/res_invstd and its
+ * running buffers are updated too. */
+typedef struct {
+  const float* sum; const float* sumsq; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* save_mean; float* save_invstd;
+} mscl_bn_params;
+
+int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn,
+                    const uint16_t* residual, const mscl_bn_params* res_bn,
+                    uint16_t* out, int64_t rows, int C, float eps, float momentum, int relu, void* stream);
+
+/* backward of the above.  dz = dout * (out > 0 if relu).  Pass 1 reduces dgamma/dbeta (accumulated
+ * into the fp32 gradient buffers, caller-zeroed) and keeps the two sums in `scratch` (4*C floats,
+ * caller-zeroed); pass 2 writes dy (and dres: dz itself for an identity residual, the BN input
+ * gradient for a normalised residual). */
+int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y,
+                    const float* gamma, const float* save_mean, const float* save_invstd,
+                    float* dgamma, float* dbeta,
+                    const uint16_t* res_y, const float* res_gamma, const float* res_mean, const float* res_invstd,
+                    float* res_dgamma, float* res_dbeta,
+                    uint16_t* dy, uint16_t* dres, int want_identity_dres,
+                    float* scratch, int64_t rows, int C, int relu, void* stream);
+
+/* ---- layout / elementwise ---------------------------------------------------------------------
+ * frames [t_off, t_off+T) of (B,Cin<=3,T_total,H,W) fp32 NCTHW -> (B,T,H,W,8) bf16 NDHWC, channels Cin..7
+ * zero (the chunk(2, dim=2) of recognizers/mscl.py:230-235 without a copy); optional per-channel
+ * (x-mean)/std = the deterministic Normalize of common/ssl_aug_v2.py:66-68.  mean3/std3 are HOST
+ * arrays of 3 floats (or NULL). */
+int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
+                    const float* mean3, const float* std3, void* stream);
+/* out = relu?(a + b + c) elementwise bf16 (b, c optional) */
+int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, int relu, void* stream);
+/* din = dout * (out > 0) */
+int mscl_relu_bwd(const uint16_t* dout, const uint16_t* out, uint16_t* din, int64_t n, void* stream);
+/* nearest / trilinear (align_corners=False) resize-and-add of NDHWC maps:
+ * dst[n,t,h,w,:] (+)= interp(src); replaces F.interpolate in necks/fpn.py:188-203 (nearest) and
+ * necks/sepc.py:125-129 (trilinear).  accumulate=0 overwrites.  The *_bwd forms scatter-add the
+ * gradient back to the coarse map (gather form, deterministic). */
+int mscl_upsample_add(const uint16_t* src, uint16_t* dst, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
+                      int C, int trilinear, int accumulate, void* stream);
+int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
+                      int C, int trilinear, void* stream);
+
+/* mean over the middle axis: x (outer, inner, C) bf16 -> out (outer, C) fp32.
+ * AdaptiveAvgPool3d((1,1,1)) of necks/base.py:17-21 and ((None,1,1)) of heads/local_cl_head.py:23-24 */
+int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream);
+/* dx (outer, inner, C) bf16 = dout (outer, C) / inner, broadcast; accumulate into dx if accumulate */
+int mscl_pool_bwd(const float* dout, uint16_t* dx, int outer, int inner, int C, int accumulate, void* stream);
+
+/* ---- projection MLP: Linear(+ReLU) on a handful of rows (recognizers/moco.py:367-372) ---------- */
+int mscl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f, int relu, void* stream);
+/* dx = (dy*mask) W ; dw += dy^T x ; db += colsum(dy); mask = (y>0) if relu */
+int mscl_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
+                    int rows, int in_f, int out_f, int relu, void* stream);
+/* F.normalize(dim=1, eps=1e-12) and its backward (recognizers/moco.py:528-529) */
+int mscl_l2norm_fwd(const float* x, float* y, float* norms, int rows, int dim, void* stream);
+int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* dx, int rows, int dim, void* stream);
+
+/* ---- MoCo contrastive pass over the negative queue ---------------------------------------------
+ * replaces recognizers/moco.py:481-498 + heads/moco_head.py:38-77 + losses/cross_entropy_loss.py:134-138
+ * + core/evaluation/accuracy.py:130-149 (and heads/moco_head_v2.py:38-53 for the cross-modal rows).
+ * queue is the reference buffer (dim, K) fp32, count (K) int64.  For each of R query rows
+ * (q: R x dim fp32, pos_logit: R floats = q.k_pos, *not yet* divided by T) computes over the aged
+ * snapshot W = queue * 0.99999^count without materialising it:
+ *   part[blk][r] = {max, sum exp(l-max), #negatives with logit > pos logit}   (pass 1, one K chunk per block)
+ *   then mscl_nce_finish: lse, loss_r = lse - pos/T, rank_r, and probabilities' normaliser.
+ * Pass 2 (mscl_nce_bwd) re-streams the queue and accumulates dq[r] = (1/T) sum_k softmax_k * W[:,k]
+ * (the positive-key term is added by the caller's tiny kernel mscl_nce_pos_bwd). */
+int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit,
+                 float* part, int R, int dim, int K, float inv_T, void* stream);
+int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank,
+                    int R, int nblk, float inv_T, void* stream);
+int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse,
+                 const float* row_scale, float* dq, int R, int dim, int K, float inv_T, void* stream);
+
+/* queue bookkeeping, bit-exact int64: count += 1; queue[:, ptr:ptr+n] = keys^T; count[ptr:ptr+n] = 1;
+ * ptr = (ptr+n) % K.   recognizers/moco.py:423-440.  keys: (n, dim) fp32, ptr: int64[1] on device. */
+int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, const float* keys, int n, int dim, int K, void* stream);
+
+/* ---- LMCL (heads/local_cl_head.py:57-73,41-55) ------------------------------------------------
+ * rgb (B, t, C) and flow (B, 2t, C) are spatially pooled features (fp32).  Per clip: L2-normalise
+ * over C, sim = rgb . flow^T / T, CE against label j for row j, top-1/top-5 hit counts.
+ * Outputs: loss_sum (1 float, += sum of row losses), hits (2 int32: top1, top5 += hits),
+ * drgb / dflow = gradient of mean-over-(B*t) loss wrt the pooled features. */
+int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, int32_t* hits, float* drgb, float* dflow,
+              int B, int t, int C, float inv_T, void* stream);
+
+/* ---- parameter-sized elementwise passes --------------------------------------------------------
+ * key-encoder EMA (recognizers/moco.py:408-421): pk = m*pk + (1-m)*pq, and refresh pk's bf16 shadow */
+int mscl_ema_update(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, float m, void* stream);
+/* sum of squares of g into *out (fp32, caller-zeroed): first half of clip_grad_norm_ */
+int mscl_sumsq(const float* g, float* out, int64_t n, void* stream);
+/* second half + torch.optim.SGD (momentum, dampening 0, no nesterov), mmcv OptimizerHook wiring at
+ * mmaction/apis/train.py:111-119: coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)) (coef = 1 when max_norm <= 0);
+ * g = g*coef + wd*p; buf = first ? g : mom*buf + g; p -= lr*buf; p_bf16 = bf16(p).
+ * `first` selects the buffer initialisation of the very first step (buf = g). */
+int mscl_sgd_step(float* p, const float* g, float* buf, uint16_t* p_bf16, int64_t n, const float* sumsq,
+                  float max_norm, float lr, float momentum, float wd, int first, void* stream);
+int mscl_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,220 @@
+// BatchNorm3d (training) + ReLU + residual, forward and backward, on NDHWC bf16 maps (gfx950).
+// HBM-bound passes: 16-byte (8-channel) accesses, lanes run along the channel axis so every wave
+// touches whole contiguous rows; per-channel constants live in LDS.
+#include "common.h"
+
+struct BnDev {
+  const float* sum; const float* sumsq; const float* gamma; const float* beta;
+  float* rmean; float* rvar; int64_t* nbt; float* smean; float* sinv;
+};
+
+__device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* shift, int C, float inv_n,
+                                           float unbias, float eps, float momentum, bool writer) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float mean = b.sum[c] * inv_n;
+    const float var = fmaxf(b.sumsq[c] * inv_n - mean * mean, 0.f);
+    const float inv = rsqrtf(var + eps);
+    const float sc = b.gamma[c] * inv;
+    scale[c] = sc; shift[c] = b.beta[c] - mean * sc;
+    if (writer) {
+      b.smean[c] = mean; b.sinv[c] = inv;
+      b.rmean[c] = (1.f - momentum) * b.rmean[c] + momentum * mean;
+      b.rvar[c] = (1.f - momentum) * b.rvar[c] + momentum * var * unbias;
+    }
+  }
+  if (writer && threadIdx.x == 0 && b.nbt) *b.nbt += 1;
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, BnDev bn,
+                                                         const bf16_t* __restrict__ res, BnDev rbn, int res_is_bn,
+                                                         bf16_t* __restrict__ out, long rows, int C, float eps,
+                                                         float momentum, int relu) {
+  extern __shared__ float sm[];          // scale[C], shift[C], rscale[C], rshift[C]
+  float* scale = sm; float* shift = sm + C; float* rscale = sm + 2 * C; float* rshift = sm + 3 * C;
+  const float inv_n = 1.f / (float)rows;
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  const bool writer = blockIdx.x == 0;
+  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer);
+  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer);
+  __syncthreads();
+  const int G = C >> 3;
+  const long total = rows * G;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int gq = (int)(e % G);
+    const uint4 v = *reinterpret_cast<const uint4*>(y + e * 8);
+    float f[8]; unpack8(v, f);
+    const int c0 = gq * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = f[i] * scale[c0 + i] + shift[c0 + i];
+    if (res != nullptr) {
+      const uint4 rv = *reinterpret_cast<const uint4*>(res + e * 8);
+      float r[8]; unpack8(rv, r);
+      if (res_is_bn) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += r[i] * rscale[c0 + i] + rshift[c0 + i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += r[i];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = fmaxf(f[i], 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + e * 8) = pack8(f);
+  }
+}
+
+extern "C" int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn, const uint16_t* residual,
+                               const mscl_bn_params* res_bn, uint16_t* out, int64_t rows, int C, float eps,
+                               float momentum, int relu, void* stream) {
+  if (!y || !bn || !out || rows <= 0 || C <= 0) return MSCL_E_ARG;
+  if (C % 8 || C > 2048) return MSCL_E_SHAPE;
+  if (!bn->sum || !bn->sumsq || !bn->gamma || !bn->beta || !bn->running_mean || !bn->running_var ||
+      !bn->save_mean || !bn->save_invstd) return MSCL_E_ARG;
+  BnDev b{bn->sum, bn->sumsq, bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->num_batches_tracked,
+          bn->save_mean, bn->save_invstd};
+  BnDev rb{};
+  int res_is_bn = 0;
+  if (res_bn) {
+    if (!residual) return MSCL_E_ARG;
+    rb = BnDev{res_bn->sum, res_bn->sumsq, res_bn->gamma, res_bn->beta, res_bn->running_mean, res_bn->running_var,
+               res_bn->num_batches_tracked, res_bn->save_mean, res_bn->save_invstd};
+    res_is_bn = 1;
+  }
+  const long total = rows * (C / 8);
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C * sizeof(float),
+                     (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward pass 1: per-channel sum(dz), sum(dz*xhat) [and the same against the residual's xhat] ----
+// scratch layout: [0:C) sum dz, [C:2C) sum dz*xhat, [2C:3C) sum dz*xhat_res
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ inv, const bf16_t* __restrict__ ry,
+    const float* __restrict__ rmean, const float* __restrict__ rinv, float* __restrict__ scratch, long rows, int C,
+    int relu) {
+  extern __shared__ float sm[];     // red[3*C]
+  const int G = C >> 3;             // threads per row; 256 % G == 0 required (C/8 power of two)
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  const int c0 = tg * 8;
+  float mu[8], iv[8], rmu[8], riv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    mu[i] = mean[c0 + i]; iv[i] = inv[c0 + i];
+    rmu[i] = ry ? rmean[c0 + i] : 0.f; riv[i] = ry ? rinv[c0 + i] : 0.f;
+  }
+  float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long r = (long)blockIdx.x * RP + tr; r < rows; r += (long)gridDim.x * RP) {
+    const long o = r * C + c0;
+    float d[8], a[8], yy[8];
+    unpack8(*reinterpret_cast<const uint4*>(dout + o), d);
+    unpack8(*reinterpret_cast<const uint4*>(y + o), yy);
+    if (relu) {
+      unpack8(*reinterpret_cast<const uint4*>(out + o), a);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0[i] += d[i]; s1[i] += d[i] * (yy[i] - mu[i]) * iv[i]; }
+    if (ry) {
+      float rr[8]; unpack8(*reinterpret_cast<const uint4*>(ry + o), rr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2[i] += d[i] * (rr[i] - rmu[i]) * riv[i];
+    }
+  }
+  for (int i = threadIdx.x; i < 3 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    atomicAdd(&sm[c0 + i], s0[i]); atomicAdd(&sm[C + c0 + i], s1[i]);
+    if (ry) atomicAdd(&sm[2 * C + c0 + i], s2[i]);
+  }
+  __syncthreads();
+  const int lim = ry ? 3 * C : 2 * C;
+  for (int i = threadIdx.x; i < lim; i += 256) atomicAdd(&scratch[i], sm[i]);
+}
+
+// ---- backward pass 2: dy = gamma*inv*(dz - sum_dz/n - xhat*sum_dzxhat/n); residual gradient ----
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ inv,
+    const bf16_t* __restrict__ ry, const float* __restrict__ rgamma, const float* __restrict__ rmean,
+    const float* __restrict__ rinv, const float* __restrict__ scratch, bf16_t* __restrict__ dy,
+    bf16_t* __restrict__ dres, int identity_dres, long rows, int C, int relu,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rdgamma, float* __restrict__ rdbeta) {
+  extern __shared__ float sm[];   // k0[C] (gamma*inv), k1[C] (mean), k2[C] (inv), a[C], b[C]; then res: 5*C more
+  float* gi = sm; float* mu = sm + C; float* iv = sm + 2 * C; float* ca = sm + 3 * C; float* cb = sm + 4 * C;
+  float* rgi = sm + 5 * C; float* rmu = sm + 6 * C; float* riv = sm + 7 * C; float* rcb = sm + 8 * C;
+  const float inv_n = 1.f / (float)rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    gi[c] = gamma[c] * inv[c]; mu[c] = mean[c]; iv[c] = inv[c];
+    ca[c] = scratch[c] * inv_n; cb[c] = scratch[C + c] * inv_n;
+    if (ry) { rgi[c] = rgamma[c] * rinv[c]; rmu[c] = rmean[c]; riv[c] = rinv[c]; rcb[c] = scratch[2 * C + c] * inv_n; }
+    if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step)
+      atomicAdd(&dgamma[c], scratch[C + c]); atomicAdd(&dbeta[c], scratch[c]);
+      if (ry) { atomicAdd(&rdgamma[c], scratch[2 * C + c]); atomicAdd(&rdbeta[c], scratch[c]); }
+    }
+  }
+  __syncthreads();
+  const int G = C >> 3;
+  const long total = rows * G;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(e % G) * 8;
+    float d[8], yy[8], o8[8];
+    unpack8(*reinterpret_cast<const uint4*>(dout + e * 8), d);
+    unpack8(*reinterpret_cast<const uint4*>(y + e * 8), yy);
+    if (relu) {
+      float a[8]; unpack8(*reinterpret_cast<const uint4*>(out + e * 8), a);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      o8[i] = gi[c] * (d[i] - ca[c] - (yy[i] - mu[c]) * iv[c] * cb[c]);
+    }
+    *reinterpret_cast<uint4*>(dy + e * 8) = pack8(o8);
+    if (ry) {
+      float rr[8]; unpack8(*reinterpret_cast<const uint4*>(ry + e * 8), rr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i;
+        o8[i] = rgi[c] * (d[i] - ca[c] - (rr[i] - rmu[c]) * riv[c] * rcb[c]);
+      }
+      *reinterpret_cast<uint4*>(dres + e * 8) = pack8(o8);
+    } else if (identity_dres) {
+      *reinterpret_cast<uint4*>(dres + e * 8) = pack8(d);
+    }
+  }
+}
+
+extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y, const float* gamma,
+                               const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                               const uint16_t* res_y, const float* res_gamma, const float* res_mean,
+                               const float* res_invstd, float* res_dgamma, float* res_dbeta, uint16_t* dy,
+                               uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
+                               void* stream) {
+  if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
+  if (relu && !out) return MSCL_E_ARG;
+  if (rows <= 0 || C <= 0) return MSCL_E_ARG;
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 2048) return MSCL_E_SHAPE;
+  if (res_y && (!res_gamma || !res_mean || !res_invstd || !res_dgamma || !res_dbeta || !dres)) return MSCL_E_ARG;
+  if (want_identity_dres && !dres) return MSCL_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int RP = 256 / (C / 8);
+  long blocks = (rows + RP * 8 - 1) / (RP * 8); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)3 * C * sizeof(float), st, dout,
+                     out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu);
+  MSCL_LAUNCH_CHECK();
+  const long total = rows * (C / 8);
+  long b2 = (total + 255) / 256; if (b2 > 2048) b2 = 2048;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)9 * C * sizeof(float), st, dout, out, y,
+                     gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
+                     want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}

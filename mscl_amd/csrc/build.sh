@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libmscl_hip.so (gfx950) in-tree.  One translation unit per kernel family, compiled in parallel.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in conv_igemm conv_wgrad bn_act elementwise contrast optim; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/mscl_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmscl_hip.so build/*.o
+echo "built $(pwd)/libmscl_hip.so"

@@ -1,0 +1,278 @@
+// MoCo InfoNCE against the aged negative queue (streaming, never materialises the R x 65537 logits),
+// bit-exact queue bookkeeping, and the frame-level LMCL loss (gfx950).
+// Roofline: HBM.  One forward pass reads the queue once (dim*K*4 B, 33.5 MB at K=65536) for ALL query
+// rows that share the snapshot; lanes run along K so every wave reads whole contiguous rows of the
+// (dim, K) buffer; query rows are wave-uniform and come through the scalar cache.
+#include "common.h"
+
+#define NCE_COLS 128          // queue columns per block (threads per block)
+
+template <int RT>
+__device__ __forceinline__ void nce_logits(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                           const float* __restrict__ q, int k, int R, int dim, int K, float inv_T,
+                                           float* lg, float& decay) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r) lg[r] = 0.f;
+  for (int c = 0; c < dim; ++c) {
+    const float w = queue[(long)c * K + k];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) lg[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, lg[r]);
+  }
+  decay = powf(0.99999f, (float)count[k]);      // recognizers/moco.py:484: 0.99999 ** (1.0 * count)
+#pragma unroll
+  for (int r = 0; r < RT; ++r) lg[r] = lg[r] * decay * inv_T;
+}
+
+// part[(blk*R + r)*3 + {0: max, 1: sum exp(l - max), 2: #(l > pos)}]
+template <int RT>
+__global__ __launch_bounds__(NCE_COLS) void nce_fwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                           const float* __restrict__ q, const float* __restrict__ pos,
+                                                           float* __restrict__ part, int R, int dim, int K, float inv_T) {
+  __shared__ float red[2][RT * 3];
+  const int k = blockIdx.x * NCE_COLS + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float lg[RT], decay;
+  nce_logits<RT>(queue, count, q, k < K ? k : K - 1, R, dim, K, inv_T, lg, decay);
+  const bool live = k < K;
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const float l = live ? lg[r] : -INFINITY;
+    const float m = wave_max(l);
+    const float s = wave_sum(live ? __expf(l - m) : 0.f);
+    const float c = wave_sum((live && r < R && l > pos[r < R ? r : 0] * inv_T) ? 1.f : 0.f);
+    if (lane == 0) { red[wave][r * 3] = m; red[wave][r * 3 + 1] = s; red[wave][r * 3 + 2] = c; }
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += NCE_COLS) {
+    const float m0 = red[0][r * 3], m1 = red[1][r * 3];
+    const float m = fmaxf(m0, m1);
+    const float s = red[0][r * 3 + 1] * __expf(m0 - m) + red[1][r * 3 + 1] * __expf(m1 - m);
+    float* o = part + ((long)blockIdx.x * R + r) * 3;
+    o[0] = m; o[1] = s; o[2] = red[0][r * 3 + 2] + red[1][r * 3 + 2];
+  }
+}
+
+__global__ void nce_finish_kernel(const float* __restrict__ part, const float* __restrict__ pos, float* __restrict__ lse,
+                                  float* __restrict__ loss_rows, int32_t* __restrict__ rank, int R, int nblk, float inv_T) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float p = pos[r] * inv_T;
+  float m = p;
+  for (int b = 0; b < nblk; ++b) m = fmaxf(m, part[((long)b * R + r) * 3]);
+  float s = expf(p - m), c = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    const float* o = part + ((long)b * R + r) * 3;
+    s += o[1] * expf(o[0] - m); c += o[2];
+  }
+  const float l = m + logf(s);
+  lse[r] = l; loss_rows[r] = l - p; rank[r] = (int32_t)c;
+}
+
+// dq[r][c] += inv_T * row_scale[r] * sum_k softmax_k * decay_k * queue[c][k]
+template <int RT>
+__global__ __launch_bounds__(NCE_COLS) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                           const float* __restrict__ q, const float* __restrict__ lse,
+                                                           const float* __restrict__ row_scale, float* __restrict__ dq,
+                                                           int R, int dim, int K, float inv_T) {
+  extern __shared__ float sm[];                 // Wt[dim][NCE_COLS+1], gcoef[RT][NCE_COLS]
+  float* Wt = sm; float* gc = sm + dim * (NCE_COLS + 1);
+  const int k = blockIdx.x * NCE_COLS + threadIdx.x;
+  const bool live = k < K;
+  const int kk = live ? k : K - 1;
+  float lg[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) lg[r] = 0.f;
+  for (int c = 0; c < dim; ++c) {
+    const float w = queue[(long)c * K + kk];
+    Wt[c * (NCE_COLS + 1) + threadIdx.x] = live ? w : 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) lg[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, lg[r]);
+  }
+  const float decay = powf(0.99999f, (float)count[kk]);
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const float l = lg[r] * decay * inv_T;
+    const float coef = (live && r < R) ? __expf(l - lse[r < R ? r : 0]) * decay * inv_T * row_scale[r < R ? r : 0] : 0.f;
+    gc[r * NCE_COLS + threadIdx.x] = coef;
+  }
+  __syncthreads();
+  // phase 2: thread = channel c (dim <= NCE_COLS)
+  const int c = threadIdx.x;
+  if (c < dim) {
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    for (int j = 0; j < NCE_COLS; ++j) {
+      const float w = Wt[c * (NCE_COLS + 1) + j];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = fmaf(gc[r * NCE_COLS + j], w, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) if (r < R) atomicAdd(&dq[r * dim + c], acc[r]);
+  }
+}
+
+#define NCE_DISPATCH(RV, CALL8, CALL16, CALL24, CALL32) \
+  if ((RV) <= 8) { CALL8; } else if ((RV) <= 16) { CALL16; } else if ((RV) <= 24) { CALL24; } else { CALL32; }
+
+extern "C" int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
+                            int R, int dim, int K, float inv_T, void* stream) {
+  if (!queue || !count || !q || !pos_logit || !part || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+  if (R > 32 || dim > NCE_COLS) return MSCL_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
+  NCE_DISPATCH(R,
+    hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T))
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank, int R,
+                               int nblk, float inv_T, void* stream) {
+  if (!part || !pos_logit || !lse || !loss_rows || !rank || R <= 0 || nblk <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(nce_finish_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, pos_logit, lse, loss_rows, rank, R, nblk, inv_T);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
+                            float* dq, int R, int dim, int K, float inv_T, void* stream) {
+  if (!queue || !count || !q || !lse || !row_scale || !dq || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+  if (R > 32 || dim > NCE_COLS) return MSCL_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
+  const int rt = R <= 8 ? 8 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32));
+  const size_t lds = ((size_t)dim * (NCE_COLS + 1) + (size_t)rt * NCE_COLS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  NCE_DISPATCH(R,
+    hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T))
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- queue bookkeeping (int64, bit-exact)
+__global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue, int64_t* __restrict__ count,
+                                                      const int64_t* __restrict__ ptr, const float* __restrict__ keys, int n,
+                                                      int dim, int K) {
+  const int64_t p = *ptr;
+  const long total = (long)K + (long)n * dim;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (e < K) {
+      count[e] = (e >= p && e < p + n) ? (int64_t)1 : count[e] + 1;
+    } else {
+      const long i = e - K; const int c = (int)(i / n), j = (int)(i % n);
+      queue[(long)c * K + p + j] = keys[(long)j * dim + c];
+    }
+  }
+}
+__global__ void enqueue_advance_kernel(int64_t* ptr, int n, int K) { *ptr = (*ptr + n) % K; }
+extern "C" int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, const float* keys, int n, int dim, int K, void* stream) {
+  if (!queue || !count || !ptr || !keys || n <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+  if (K % n) return MSCL_E_SHAPE;                 // recognizers/moco.py:432 `assert self.K % batch_size == 0`
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)K + (long)n * dim;
+  hipLaunchKernelGGL(enqueue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, queue, count, ptr, keys, n, dim, K);
+  MSCL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(enqueue_advance_kernel, dim3(1), dim3(1), 0, st, ptr, n, K);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- LMCL: one block per clip
+#define LMCL_MAX_T 32
+__global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb, const float* __restrict__ flow,
+                                                   float* __restrict__ loss_sum, int32_t* __restrict__ hits,
+                                                   float* __restrict__ drgb, float* __restrict__ dflow, int B, int t, int C,
+                                                   float inv_T) {
+  extern __shared__ float sm[];
+  const int t2 = 2 * t;
+  float* xr = sm;                    // [t][C] normalised
+  float* xf = xr + t * C;            // [2t][C] normalised
+  float* nr = xf + t2 * C;           // [t]
+  float* nf = nr + t;                // [2t]
+  float* sim = nf + t2;              // [t][2t] -> dlogits
+  float* gr = sim + t * t2;          // [t][C]  grad wrt normalised rgb
+  float* gf = gr + t * C;            // [2t][C]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* rb = rgb + (long)b * t * C; const float* fb = flow + (long)b * t2 * C;
+  for (int row = wave; row < t + t2; row += 4) {
+    const float* src = row < t ? rb + row * C : fb + (row - t) * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += src[c] * src[c];
+    s = wave_sum(s);
+    const float nrm = fmaxf(sqrtf(s), 1e-12f);
+    float* dst = row < t ? xr + row * C : xf + (row - t) * C;
+    for (int c = lane; c < C; c += 64) dst[c] = src[c] / nrm;
+    if (lane == 0) { if (row < t) nr[row] = nrm; else nf[row - t] = nrm; }
+  }
+  __syncthreads();
+  for (int e = wave; e < t * t2; e += 4) {
+    const int i = e / t2, j = e % t2;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[i * C + c] * xf[j * C + c];
+    s = wave_sum(s);
+    if (lane == 0) sim[e] = s * inv_T;
+  }
+  __syncthreads();
+  const float scale = 1.f / (float)(B * t);
+  if (tid < t) {
+    const int i = tid;
+    float m = -INFINITY;
+    for (int j = 0; j < t2; ++j) m = fmaxf(m, sim[i * t2 + j]);
+    float s = 0.f;
+    for (int j = 0; j < t2; ++j) s += expf(sim[i * t2 + j] - m);
+    const float lse = m + logf(s), pos = sim[i * t2 + i];
+    int rank = 0;
+    for (int j = 0; j < t2; ++j) rank += (sim[i * t2 + j] > pos) ? 1 : 0;
+    atomicAdd(loss_sum, lse - pos);
+    if (rank == 0) atomicAdd(&hits[0], 1);
+    if (rank < 5) atomicAdd(&hits[1], 1);
+    for (int j = 0; j < t2; ++j) sim[i * t2 + j] = (expf(sim[i * t2 + j] - lse) - (j == i ? 1.f : 0.f)) * scale * inv_T;
+  }
+  __syncthreads();
+  for (int e = tid; e < t * C; e += 256) {
+    const int i = e / C, c = e % C;
+    float s = 0.f;
+    for (int j = 0; j < t2; ++j) s += sim[i * t2 + j] * xf[j * C + c];
+    gr[e] = s;
+  }
+  for (int e = tid; e < t2 * C; e += 256) {
+    const int j = e / C, c = e % C;
+    float s = 0.f;
+    for (int i = 0; i < t; ++i) s += sim[i * t2 + j] * xr[i * C + c];
+    gf[e] = s;
+  }
+  __syncthreads();
+  for (int row = wave; row < t + t2; row += 4) {
+    const bool isr = row < t;
+    const float* n8 = isr ? xr + row * C : xf + (row - t) * C;
+    const float* g8 = isr ? gr + row * C : gf + (row - t) * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += n8[c] * g8[c];
+    s = wave_sum(s);
+    const float inv = 1.f / (isr ? nr[row] : nf[row - t]);
+    float* dst = isr ? drgb + ((long)b * t + row) * C : dflow + ((long)b * t2 + (row - t)) * C;
+    for (int c = lane; c < C; c += 64) dst[c] = (g8[c] - n8[c] * s) * inv;
+  }
+}
+extern "C" int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, int32_t* hits, float* drgb, float* dflow, int B,
+                         int t, int C, float inv_T, void* stream) {
+  if (!rgb || !flow || !loss_sum || !hits || !drgb || !dflow || B <= 0 || t <= 0 || C <= 0) return MSCL_E_ARG;
+  if (t > LMCL_MAX_T) return MSCL_E_SHAPE;
+  const size_t lds = ((size_t)6 * t * C + 3 * t + 2 * t * t) * sizeof(float);
+  if (lds > 150 * 1024) return MSCL_E_SHAPE;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lmcl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,363 @@
+// Layout conversion, pooling, resize-add, small dense layers (gfx950).  All HBM- or launch-bound:
+// 16-byte accesses along the channel axis, one wave per output where a reduction is needed.
+#include "common.h"
+
+// ---------------------------------------------------------------- input packing NCTHW fp32 -> NDHWC8 bf16
+// frames [t_off, t_off+T) of a clip holding T_total frames (the base / rotated halves of the flow clip,
+// recognizers/mscl.py:230-235, are packed straight from the concatenated tensor)
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B,
+                                                         int Cin, long THW, long THW_total, long off, float m0, float m1,
+                                                         float m2, float i0, float i1, float i2) {
+  const long total = (long)B * THW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / THW, p = e - b * THW;
+    const float* xb = x + b * Cin * THW_total + off + p;
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f[0] = (xb[0] - m0) * i0;
+    if (Cin > 1) f[1] = (xb[THW_total] - m1) * i1;
+    if (Cin > 2) f[2] = (xb[2 * THW_total] - m2) * i2;
+    *reinterpret_cast<uint4*>(out + e * 8) = pack8(f);
+  }
+}
+
+extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
+                               const float* mean3, const float* std3, void* stream) {
+  if (!x || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t_off < 0 || t_off + T > T_total) return MSCL_E_ARG;
+  if (Cin < 1 || Cin > 3) return MSCL_E_SHAPE;
+  float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
+  if (mean3 && std3) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; iv[i] = 1.f / std3[i]; }   // host arrays
+  const long THW = (long)T * H * W, total = (long)B * THW;
+  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, B, Cin, THW,
+                     (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- add / relu
+__global__ __launch_bounds__(256) void add_relu_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       const bf16_t* __restrict__ c, bf16_t* __restrict__ out, long n8,
+                                                       int relu) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (long)gridDim.x * blockDim.x) {
+    float f[8]; unpack8(*reinterpret_cast<const uint4*>(a + e * 8), f);
+    if (b) { float g[8]; unpack8(*reinterpret_cast<const uint4*>(b + e * 8), g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += g[i]; }
+    if (c) { float g[8]; unpack8(*reinterpret_cast<const uint4*>(c + e * 8), g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += g[i]; }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = fmaxf(f[i], 0.f); }
+    *reinterpret_cast<uint4*>(out + e * 8) = pack8(f);
+  }
+}
+extern "C" int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, int relu,
+                             void* stream) {
+  if (!a || !out || n <= 0) return MSCL_E_ARG;
+  if (n % 8) return MSCL_E_SHAPE;
+  long blocks = (n / 8 + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, (long)(n / 8), relu);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                       bf16_t* __restrict__ din, long n8) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (long)gridDim.x * blockDim.x) {
+    float d[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(dout + e * 8), d);
+    unpack8(*reinterpret_cast<const uint4*>(out + e * 8), o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = o[i] > 0.f ? d[i] : 0.f;
+    *reinterpret_cast<uint4*>(din + e * 8) = pack8(d);
+  }
+}
+extern "C" int mscl_relu_bwd(const uint16_t* dout, const uint16_t* out, uint16_t* din, int64_t n, void* stream) {
+  if (!dout || !out || !din || n <= 0) return MSCL_E_ARG;
+  if (n % 8) return MSCL_E_SHAPE;
+  long blocks = (n / 8 + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, out, din, (long)(n / 8));
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- nearest / trilinear resize (+add)
+// PyTorch semantics: nearest: src = floor(dst * in/out); trilinear align_corners=False:
+// s = max(0, (dst+0.5)*in/out - 0.5), i0 = floor(s), i1 = min(i0+1, in-1), w1 = s - i0.
+__device__ __forceinline__ void lin_coord(int d, int in, int outn, int& i0, int& i1, float& w1) {
+  const float sc = (float)in / (float)outn;
+  float s = ((float)d + 0.5f) * sc - 0.5f; s = s < 0.f ? 0.f : s;
+  i0 = (int)s; if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 > in - 1 ? in - 1 : i0 + 1; w1 = s - (float)i0;
+}
+__global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N,
+                                                           int Ts, int Hs, int Ws, int Td, int Hd, int Wd, int C,
+                                                           int trilinear, int accumulate) {
+  const int G = C >> 3;
+  const long total = (long)N * Td * Hd * Wd * G;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int gq = (int)(e % G); long r = e / G;
+    const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd;
+    const int t = (int)(r % Td); const int n = (int)(r / Td);
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!trilinear) {
+      const int ts = (int)((long)t * Ts / Td), hs = (int)((long)h * Hs / Hd), ws = (int)((long)w * Ws / Wd);
+      unpack8(*reinterpret_cast<const uint4*>(src + ((((long)n * Ts + ts) * Hs + hs) * Ws + ws) * C + gq * 8), f);
+    } else {
+      int t0, t1, h0, h1, w0, w1; float a, b, c;
+      lin_coord(t, Ts, Td, t0, t1, a); lin_coord(h, Hs, Hd, h0, h1, b); lin_coord(w, Ws, Wd, w0, w1, c);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int tt = (k & 4) ? t1 : t0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
+        const float wt = ((k & 4) ? a : 1.f - a) * ((k & 2) ? b : 1.f - b) * ((k & 1) ? c : 1.f - c);
+        float g8[8];
+        unpack8(*reinterpret_cast<const uint4*>(src + ((((long)n * Ts + tt) * Hs + hh) * Ws + ww) * C + gq * 8), g8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += wt * g8[i];
+      }
+    }
+    if (accumulate) {
+      float d8[8]; unpack8(*reinterpret_cast<const uint4*>(dst + e * 8), d8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += d8[i];
+    }
+    *reinterpret_cast<uint4*>(dst + e * 8) = pack8(f);
+  }
+}
+extern "C" int mscl_upsample_add(const uint16_t* src, uint16_t* dst, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
+                                 int C, int trilinear, int accumulate, void* stream) {
+  if (!src || !dst || N <= 0 || Ts <= 0 || Hs <= 0 || Ws <= 0 || Td <= 0 || Hd <= 0 || Wd <= 0) return MSCL_E_ARG;
+  if (C % 8) return MSCL_E_SHAPE;
+  const long total = (long)N * Td * Hd * Wd * (C / 8);
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, Ts, Hs, Ws,
+                     Td, Hd, Wd, C, trilinear, accumulate);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward: gather form.  For each coarse cell, sum the fine cells that read it (with their weights).
+// Per axis a coarse index i receives from fine d in a window; we scan the (small) fine extent per axis.
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restrict__ dd, bf16_t* __restrict__ ds, int N,
+                                                           int Ts, int Hs, int Ws, int Td, int Hd, int Wd, int C,
+                                                           int trilinear) {
+  const int G = C >> 3;
+  const long total = (long)N * Ts * Hs * Ws * G;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int gq = (int)(e % G); long r = e / G;
+    const int ws = (int)(r % Ws); r /= Ws; const int hs = (int)(r % Hs); r /= Hs;
+    const int ts = (int)(r % Ts); const int n = (int)(r / Ts);
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // candidate fine ranges: a coarse index influences fine indices within +-ceil(out/in)+1 of its centre
+    const int rt = Td / Ts + 2, rh = Hd / Hs + 2, rw = Wd / Ws + 2;
+    const int ct = (int)(((long)ts * Td) / Ts), ch = (int)(((long)hs * Hd) / Hs), cw = (int)(((long)ws * Wd) / Ws);
+    for (int t = max(0, ct - rt); t <= min(Td - 1, ct + rt); ++t) {
+      float wt_t;
+      if (!trilinear) { wt_t = ((int)((long)t * Ts / Td) == ts) ? 1.f : 0.f; }
+      else { int i0, i1; float a; lin_coord(t, Ts, Td, i0, i1, a); wt_t = (i0 == ts ? 1.f - a : 0.f) + (i1 == ts ? a : 0.f); }
+      if (wt_t == 0.f) continue;
+      for (int h = max(0, ch - rh); h <= min(Hd - 1, ch + rh); ++h) {
+        float wt_h;
+        if (!trilinear) { wt_h = ((int)((long)h * Hs / Hd) == hs) ? 1.f : 0.f; }
+        else { int i0, i1; float a; lin_coord(h, Hs, Hd, i0, i1, a); wt_h = (i0 == hs ? 1.f - a : 0.f) + (i1 == hs ? a : 0.f); }
+        if (wt_h == 0.f) continue;
+        for (int w = max(0, cw - rw); w <= min(Wd - 1, cw + rw); ++w) {
+          float wt_w;
+          if (!trilinear) { wt_w = ((int)((long)w * Ws / Wd) == ws) ? 1.f : 0.f; }
+          else { int i0, i1; float a; lin_coord(w, Ws, Wd, i0, i1, a); wt_w = (i0 == ws ? 1.f - a : 0.f) + (i1 == ws ? a : 0.f); }
+          if (wt_w == 0.f) continue;
+          float g8[8];
+          unpack8(*reinterpret_cast<const uint4*>(dd + ((((long)n * Td + t) * Hd + h) * Wd + w) * C + gq * 8), g8);
+          const float wt = wt_t * wt_h * wt_w;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] += wt * g8[i];
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(ds + e * 8) = pack8(f);
+  }
+}
+extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
+                                 int C, int trilinear, void* stream) {
+  if (!ddst || !dsrc || N <= 0 || Ts <= 0 || Hs <= 0 || Ws <= 0 || Td <= 0 || Hd <= 0 || Wd <= 0) return MSCL_E_ARG;
+  if (C % 8) return MSCL_E_SHAPE;
+  const long total = (long)N * Ts * Hs * Ws * (C / 8);
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, N, Ts, Hs, Ws,
+                     Td, Hd, Wd, C, trilinear);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- mean over the middle axis
+// x (outer, inner, C) bf16 -> out (outer, C) fp32.  One block per (outer, 64-channel group... ) :
+// block = 256 threads = G channel-granules x (256/G) row lanes; LDS reduce.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C) {
+  __shared__ float red[2048];
+  const int G = C >> 3;
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  const long base = (long)blockIdx.x * inner * C;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = tr; r < inner; r += RP) {
+    float f[8]; unpack8(*reinterpret_cast<const uint4*>(x + base + (long)r * C + tg * 8), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] += f[i];
+  }
+  for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) atomicAdd(&red[tg * 8 + i], s[i]);
+  __syncthreads();
+  const float inv = 1.f / (float)inner;
+  for (int i = threadIdx.x; i < C; i += 256) out[(long)blockIdx.x * C + i] = red[i] * inv;
+}
+extern "C" int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream) {
+  if (!x || !out || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 2048) return MSCL_E_SHAPE;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer), dim3(256), 0, (hipStream_t)stream, x, out, inner, C);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, bf16_t* __restrict__ dx, long inner,
+                                                       int C, long total, int accumulate) {
+  const int G = C >> 3;
+  const float inv = 1.f / (float)inner;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int gq = (int)(e % G); const long o = (e / G) / inner;
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = dout[o * C + gq * 8 + i] * inv;
+    if (accumulate) { float d8[8]; unpack8(*reinterpret_cast<const uint4*>(dx + e * 8), d8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += d8[i]; }
+    *reinterpret_cast<uint4*>(dx + e * 8) = pack8(f);
+  }
+}
+extern "C" int mscl_pool_bwd(const float* dout, uint16_t* dx, int outer, int inner, int C, int accumulate, void* stream) {
+  if (!dout || !dx || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
+  if (C % 8) return MSCL_E_SHAPE;
+  const long total = (long)outer * inner * (C / 8);
+  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, dx, (long)inner, C, total, accumulate);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- Linear on a few rows (fp32)
+// y[r][o] = relu?( sum_i x[r][i] w[o][i] + b[o] ).  One wave per output feature, all rows at once.
+#define LIN_MAX_ROWS 32
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                         int in_f, int out_f, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= out_f) return;
+  float acc[LIN_MAX_ROWS];
+#pragma unroll
+  for (int r = 0; r < LIN_MAX_ROWS; ++r) acc[r] = 0.f;
+  for (int i = lane; i < in_f; i += 64) {
+    const float wv = w[(long)o * in_f + i];
+#pragma unroll
+    for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) acc[r] += wv * x[(long)r * in_f + i];
+  }
+#pragma unroll
+  for (int r = 0; r < LIN_MAX_ROWS; ++r) {
+    if (r < rows) {
+      float v = wave_sum(acc[r]) + (b ? b[o] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      if (lane == 0) y[(long)r * out_f + o] = v;
+    }
+  }
+}
+extern "C" int mscl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
+                               int relu, void* stream) {
+  if (!x || !w || !y || rows <= 0 || in_f <= 0 || out_f <= 0) return MSCL_E_ARG;
+  if (rows > LIN_MAX_ROWS) return MSCL_E_SHAPE;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((out_f + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, y, rows, in_f, out_f, relu);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+// backward: g = dy * (y>0 if relu);  dx[r][i] = sum_o g[r][o] w[o][i];  dw[o][i] += sum_r g[r][o] x[r][i];  db[o] += sum_r g[r][o]
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, float* __restrict__ dx, int rows,
+                                                            int in_f, int out_f, int relu) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= in_f) return;
+  float acc[LIN_MAX_ROWS];
+#pragma unroll
+  for (int r = 0; r < LIN_MAX_ROWS; ++r) acc[r] = 0.f;
+  for (int o = 0; o < out_f; ++o) {
+    const float wv = w[(long)o * in_f + i];
+#pragma unroll
+    for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) {
+      float g = dy[(long)r * out_f + o];
+      if (relu && !(y[(long)r * out_f + o] > 0.f)) g = 0.f;
+      acc[r] += g * wv;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) dx[(long)r * in_f + i] = acc[r];
+}
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, float* __restrict__ dw,
+                                                            float* __restrict__ db, int rows, int in_f, int out_f, int relu) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)out_f * in_f) return;
+  const int o = (int)(e / in_f), i = (int)(e % in_f);
+  float s = 0.f, sb = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    float g = dy[(long)r * out_f + o];
+    if (relu && !(y[(long)r * out_f + o] > 0.f)) g = 0.f;
+    s += g * x[(long)r * in_f + i]; sb += g;
+  }
+  dw[e] += s;
+  if (i == 0 && db) db[o] += sb;
+}
+extern "C" int mscl_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                               float* db, int rows, int in_f, int out_f, int relu, void* stream) {
+  if (!x || !w || !y || !dy || !dw || rows <= 0 || in_f <= 0 || out_f <= 0) return MSCL_E_ARG;
+  if (rows > LIN_MAX_ROWS) return MSCL_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((in_f + 255) / 256), dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
+    MSCL_LAUNCH_CHECK();
+  }
+  const long tot = (long)out_f * in_f;
+  hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, y, dy, dw, db, rows, in_f, out_f, relu);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- F.normalize(dim=1, eps=1e-12)
+__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        float* __restrict__ norms, int dim) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int i = lane; i < dim; i += 64) { const float v = x[(long)r * dim + i]; s += v * v; }
+  s = wave_sum(s);
+  const float nrm = fmaxf(sqrtf(s), 1e-12f);
+  for (int i = lane; i < dim; i += 64) y[(long)r * dim + i] = x[(long)r * dim + i] / nrm;
+  if (lane == 0 && norms) norms[r] = nrm;
+}
+extern "C" int mscl_l2norm_fwd(const float* x, float* y, float* norms, int rows, int dim, void* stream) {
+  if (!x || !y || rows <= 0 || dim <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, x, y, norms, dim);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+__global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norms,
+                                                        const float* __restrict__ dy, float* __restrict__ dx, int dim) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int i = lane; i < dim; i += 64) s += y[(long)r * dim + i] * dy[(long)r * dim + i];
+  s = wave_sum(s);
+  const float inv = 1.f / norms[r];
+  for (int i = lane; i < dim; i += 64) dx[(long)r * dim + i] = (dy[(long)r * dim + i] - y[(long)r * dim + i] * s) * inv;
+}
+extern "C" int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* dx, int rows, int dim, void* stream) {
+  if (!y || !norms || !dy || !dx || rows <= 0 || dim <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, y, norms, dy, dx, dim);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}

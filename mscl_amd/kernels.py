@@ -1,0 +1,223 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw device pointers.
+
+Activations: torch.bfloat16, shape (N, T, H, W, C) contiguous (NDHWC).  Conv kernels: bf16
+[Cout][kT][kH][kW][Cin] (forward) and [Cin][kT][kH][kW][Cout] (input gradient).  No torch compute ops
+are used on the data path; torch only owns the memory and the stream.
+"""
+import ctypes
+
+import torch
+
+from . import lib
+from .lib import BnParams, ConvDesc, call, ptr, stream_ptr
+
+
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+def conv_desc(x_shape, K, kernel, stride, pad):
+    N, T, H, W, C = x_shape
+    k, s, p = _triple(kernel), _triple(stride), _triple(pad)
+    To = (T + 2 * p[0] - k[0]) // s[0] + 1
+    Ho = (H + 2 * p[1] - k[1]) // s[1] + 1
+    Wo = (W + 2 * p[2] - k[2]) // s[2] + 1
+    return ConvDesc(N, T, H, W, C, To, Ho, Wo, K, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+
+
+def out_shape(d):
+    return (d.N, d.To, d.Ho, d.Wo, d.K)
+
+
+def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
+    """y = conv(x, w) (+bias) (+addend) (relu).  stats = (sum, sumsq) fp32 K-vectors, pre-zeroed."""
+    y = torch.empty(out_shape(d), dtype=torch.bfloat16, device=x.device)
+    s0, s1 = stats if stats is not None else (None, None)
+    call('mscl_conv3d_fwd', ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(addend), int(relu),
+         ptr(s0), ptr(s1), stream_ptr())
+    return y
+
+
+def conv3d_dgrad(dy, wT, d, addend=None):
+    dx = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
+    call('mscl_conv3d_dgrad', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dx), ptr(addend), stream_ptr())
+    return dx
+
+
+def conv3d_wgrad(x, dy, d, dw, dbias=None):
+    """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated)."""
+    call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream_ptr())
+
+
+def weight_transpose(w, wT, Cout, taps, Cin):
+    call('mscl_weight_transpose', ptr(w), ptr(wT), Cout, taps, Cin, stream_ptr())
+
+
+def _bnp(stats, gamma, beta, rm, rv, nbt, smean, sinv):
+    return BnParams(ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt), ptr(smean), ptr(sinv))
+
+
+def bn_act_fwd(y, bn, residual=None, res_bn=None, relu=True, eps=1e-5, momentum=0.1):
+    """bn / res_bn: BnParams.  Returns out (bf16, same shape as y)."""
+    out = torch.empty_like(y)
+    C = y.shape[-1]
+    rows = y.numel() // C
+    call('mscl_bn_act_fwd', ptr(y), ctypes.byref(bn), ptr(residual),
+         ctypes.byref(res_bn) if res_bn is not None else None, ptr(out), rows, C, eps, momentum, int(relu), stream_ptr())
+    return out
+
+
+def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, res=None, want_identity_dres=False):
+    """res = None | dict(y=, gamma=, mean=, invstd=, dgamma=, dbeta=).  Returns (dy, dres|None)."""
+    C = y.shape[-1]
+    rows = y.numel() // C
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if (res is not None or want_identity_dres) else None
+    r = res or {}
+    call('mscl_bn_act_bwd', ptr(dout), ptr(out), ptr(y), ptr(gamma), ptr(smean), ptr(sinv), ptr(dgamma), ptr(dbeta),
+         ptr(r.get('y')), ptr(r.get('gamma')), ptr(r.get('mean')), ptr(r.get('invstd')), ptr(r.get('dgamma')),
+         ptr(r.get('dbeta')), ptr(dy), ptr(dres), int(want_identity_dres and res is None), ptr(scratch), rows, C,
+         int(relu), stream_ptr())
+    return dy, dres
+
+
+def pack_input(x, mean=None, std=None, t_off=0, T=None):
+    """frames [t_off, t_off+T) of (B,C<=3,Ttot,H,W) fp32 -> (B,T,H,W,8) bf16, optional (x-mean)/std."""
+    B, C, Ttot, H, W = x.shape
+    T = Ttot - t_off if T is None else T
+    if not x.is_contiguous():
+        raise lib.MsclError('pack_input needs a contiguous NCTHW tensor')
+    out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    call('mscl_pack_input', ptr(x), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, stream_ptr())
+    return out
+
+
+def add_relu(a, b=None, c=None, relu=False):
+    out = torch.empty_like(a)
+    call('mscl_add_relu', ptr(a), ptr(b), ptr(c), ptr(out), a.numel(), int(relu), stream_ptr())
+    return out
+
+
+def relu_bwd(dout, out):
+    din = torch.empty_like(dout)
+    call('mscl_relu_bwd', ptr(dout), ptr(out), ptr(din), dout.numel(), stream_ptr())
+    return din
+
+
+def upsample_add(src, dst, trilinear, accumulate):
+    N, Ts, Hs, Ws, C = src.shape
+    _, Td, Hd, Wd, _ = dst.shape
+    call('mscl_upsample_add', ptr(src), ptr(dst), N, Ts, Hs, Ws, Td, Hd, Wd, C, int(trilinear), int(accumulate), stream_ptr())
+    return dst
+
+
+def upsample_bwd(ddst, src_shape, trilinear):
+    N, Ts, Hs, Ws, C = src_shape
+    _, Td, Hd, Wd, _ = ddst.shape
+    dsrc = torch.empty(src_shape, dtype=torch.bfloat16, device=ddst.device)
+    call('mscl_upsample_bwd', ptr(ddst), ptr(dsrc), N, Ts, Hs, Ws, Td, Hd, Wd, C, int(trilinear), stream_ptr())
+    return dsrc
+
+
+def pool_fwd(x, outer, inner):
+    C = x.shape[-1]
+    out = torch.empty((outer, C), dtype=torch.float32, device=x.device)
+    call('mscl_pool_fwd', ptr(x), ptr(out), outer, inner, C, stream_ptr())
+    return out
+
+
+def pool_bwd(dout, shape, outer, inner, into=None):
+    C = shape[-1]
+    dx = into if into is not None else torch.empty(shape, dtype=torch.bfloat16, device=dout.device)
+    call('mscl_pool_bwd', ptr(dout), ptr(dx), outer, inner, C, int(into is not None), stream_ptr())
+    return dx
+
+
+def linear_fwd(x, w, b, relu):
+    rows, in_f = x.shape
+    out_f = w.shape[0]
+    y = torch.empty((rows, out_f), dtype=torch.float32, device=x.device)
+    call('mscl_linear_fwd', ptr(x), ptr(w), ptr(b), ptr(y), rows, in_f, out_f, int(relu), stream_ptr())
+    return y
+
+
+def linear_bwd(x, w, y, dy, dw, db, relu, need_dx=True):
+    rows, in_f = x.shape
+    out_f = w.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    call('mscl_linear_bwd', ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), rows, in_f, out_f, int(relu), stream_ptr())
+    return dx
+
+
+def l2norm_fwd(x):
+    y = torch.empty_like(x)
+    norms = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    call('mscl_l2norm_fwd', ptr(x), ptr(y), ptr(norms), x.shape[0], x.shape[1], stream_ptr())
+    return y, norms
+
+
+def l2norm_bwd(y, norms, dy):
+    dx = torch.empty_like(y)
+    call('mscl_l2norm_bwd', ptr(y), ptr(norms), ptr(dy), ptr(dx), y.shape[0], y.shape[1], stream_ptr())
+    return dx
+
+
+NCE_COLS = 128
+
+
+def nce_forward(queue, count, q, pos, inv_T):
+    """Returns (lse, loss_rows, rank) for R query rows against the aged queue snapshot."""
+    R, dim = q.shape
+    K = queue.shape[1]
+    nblk = (K + NCE_COLS - 1) // NCE_COLS
+    dev = q.device
+    part = torch.empty((nblk, R, 3), dtype=torch.float32, device=dev)
+    lse = torch.empty((R,), dtype=torch.float32, device=dev)
+    loss = torch.empty((R,), dtype=torch.float32, device=dev)
+    rank = torch.empty((R,), dtype=torch.int32, device=dev)
+    call('mscl_nce_fwd', ptr(queue), ptr(count), ptr(q), ptr(pos), ptr(part), R, dim, K, inv_T, stream_ptr())
+    call('mscl_nce_finish', ptr(part), ptr(pos), ptr(lse), ptr(loss), ptr(rank), R, nblk, inv_T, stream_ptr())
+    return lse, loss, rank
+
+
+def nce_backward(queue, count, q, lse, row_scale, inv_T):
+    """dq (R, dim) = inv_T * row_scale[r] * sum_k softmax_k * W[:, k] (negatives only)."""
+    R, dim = q.shape
+    dq = torch.zeros((R, dim), dtype=torch.float32, device=q.device)
+    call('mscl_nce_bwd', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), R, dim, queue.shape[1], inv_T, stream_ptr())
+    return dq
+
+
+def queue_enqueue(queue, count, qptr, keys):
+    n, dim = keys.shape
+    call('mscl_queue_enqueue', ptr(queue), ptr(count), ptr(qptr), ptr(keys), n, dim, queue.shape[1], stream_ptr())
+
+
+def lmcl(rgb, flow, inv_T):
+    """rgb (B,t,C), flow (B,2t,C) fp32 pooled features -> loss_sum[1], hits[2], drgb, dflow."""
+    B, t, C = rgb.shape
+    dev = rgb.device
+    loss_sum = torch.zeros((1,), dtype=torch.float32, device=dev)
+    hits = torch.zeros((2,), dtype=torch.int32, device=dev)
+    drgb, dflow = torch.empty_like(rgb), torch.empty_like(flow)
+    call('mscl_lmcl', ptr(rgb), ptr(flow), ptr(loss_sum), ptr(hits), ptr(drgb), ptr(dflow), B, t, C, inv_T, stream_ptr())
+    return loss_sum, hits, drgb, dflow
+
+
+def ema_update(pk, pq, pk_bf16, m):
+    call('mscl_ema_update', ptr(pk), ptr(pq), ptr(pk_bf16), pk.numel(), float(m), stream_ptr())
+
+
+def sumsq(g, out):
+    call('mscl_sumsq', ptr(g), ptr(out), g.numel(), stream_ptr())
+
+
+def sgd_step(p, g, buf, p_bf16, sumsq_t, max_norm, lr, momentum, wd, first):
+    call('mscl_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(p_bf16), p.numel(), ptr(sumsq_t), float(max_norm), float(lr),
+         float(momentum), float(wd), int(first), stream_ptr())
+
+
+def cast_bf16(src, dst):
+    call('mscl_cast_bf16', ptr(src), ptr(dst), src.numel(), stream_ptr())

@@ -1,0 +1,103 @@
+"""ctypes binding of libmscl_hip.so (the C ABI declared in include/mscl_hip.h).
+
+The library is built in-tree by mscl_amd/csrc/build.sh (see __graft_entry__.build).  There is no CPU
+fallback: if the library is missing, or a kernel is asked to run on a non-GPU tensor, this module
+raises -- the product path never silently degrades to PyTorch ops.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmscl_hip.so')
+
+
+class MsclError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in ('N', 'T', 'H', 'W', 'C', 'To', 'Ho', 'Wo', 'K', 'kT', 'kH', 'kW',
+                                     'sT', 'sH', 'sW', 'pT', 'pH', 'pW')]
+
+
+class BnParams(Structure):
+    _fields_ = [(n, c_void_p) for n in ('sum', 'sumsq', 'gamma', 'beta', 'running_mean', 'running_var',
+                                        'num_batches_tracked', 'save_mean', 'save_invstd')]
+
+
+P = c_void_p
+_SIGS = {
+    'mscl_abi_version': [],
+    'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P],
+    'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P],
+    'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P],
+    'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],
+    'mscl_bn_act_fwd': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, P],
+    'mscl_bn_act_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P],
+    'mscl_pack_input': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P],
+    'mscl_add_relu': [P, P, P, P, c_int64, c_int, P],
+    'mscl_relu_bwd': [P, P, P, c_int64, P],
+    'mscl_upsample_add': [P, P] + [c_int] * 10 + [P],
+    'mscl_upsample_bwd': [P, P] + [c_int] * 9 + [P],
+    'mscl_pool_fwd': [P, P, c_int, c_int, c_int, P],
+    'mscl_pool_bwd': [P, P, c_int, c_int, c_int, c_int, P],
+    'mscl_linear_fwd': [P, P, P, P, c_int, c_int, c_int, c_int, P],
+    'mscl_linear_bwd': [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    'mscl_l2norm_fwd': [P, P, P, c_int, c_int, P],
+    'mscl_l2norm_bwd': [P, P, P, P, c_int, c_int, P],
+    'mscl_nce_fwd': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
+    'mscl_nce_finish': [P, P, P, P, P, c_int, c_int, c_float, P],
+    'mscl_nce_bwd': [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
+    'mscl_queue_enqueue': [P, P, P, P, c_int, c_int, c_int, P],
+    'mscl_lmcl': [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
+    'mscl_ema_update': [P, P, P, c_int64, c_float, P],
+    'mscl_sumsq': [P, P, c_int64, P],
+    'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
+    'mscl_cast_bf16': [P, P, c_int64, P],
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the CDLL; raises MsclError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsclError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        f'or mscl_amd/csrc/build.sh (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL); refuses non-GPU tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MsclError('mscl_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback')
+    return c_void_p(t.data_ptr())
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: 'bad argument', -2: 'unsupported shape', -3: 'unsupported stride'}.get(code, f'hipError {code}')
+        raise MsclError(f'{what} failed: {kind}')
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,312 @@
+"""Per-kernel parity: every HIP kernel (through the C ABI) against plain PyTorch fp32 on the CPU.
+
+The CPU side computes in fp32 from the SAME bf16-rounded inputs, so the only differences are the
+accumulation order (fp32) and the final rounding of bf16 outputs: tolerance = 2^-7 relative to the
+tensor's max magnitude for bf16 outputs, 2e-4 relative for fp32 outputs (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 2.0 ** -7
+F32_TOL = 3e-4
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close(got, want, tol, what=''):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f'{what}: max err {err:.4g} vs scale {scale:.4g} (rel {err/scale:.3g} > {tol:.3g})'
+
+
+CONV_CASES = [
+    # name, N,T,H,W, C, K, kernel, stride, pad
+    ('r3d_64_64_s1', 2, 4, 12, 12, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('r3d_64_128_s2', 2, 4, 12, 12, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ('r3d_128_128_s1', 1, 3, 9, 10, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('r3d_256_256_s1', 1, 2, 7, 7, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('ds_64_128', 2, 4, 12, 12, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    ('flow_16_16', 2, 3, 14, 14, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('flow_16_32_s2', 2, 3, 14, 14, 16, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ('flow_32_64_s2', 2, 3, 14, 14, 32, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ('flow_ds_16_32', 2, 3, 14, 14, 16, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ('fpn_133', 1, 4, 10, 10, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('lat_512_128', 1, 2, 7, 7, 512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('stem_rgb', 1, 4, 20, 20, 8, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
+    ('stem_flow', 1, 4, 20, 20, 8, 16, (1, 7, 7), (2, 2, 2), (0, 3, 3)),
+    ('big_m_tail', 3, 5, 13, 11, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+]
+
+
+def _conv_ref(x, w, stride, pad, bias=None):
+    """x (N,T,H,W,C) float, w (K,kT,kH,kW,C) float -> (N,To,Ho,Wo,K) float"""
+    y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(0, 4, 1, 2, 3), bias=bias, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, dev):
+    from mscl_amd import kernels as K_
+    name, N, T, H, W, C, K, kern, stride, pad = case
+    x = bf(rnd((N, T, H, W, C), 1)); w = bf(rnd((K, *kern, C), 2, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
+    if name.startswith('stem'):
+        x[..., 3:] = 0
+    d = K_.conv_desc(x.shape, K, kern, stride, pad)
+    xg, wg = x.to(dev), w.to(dev)
+    # forward + BN statistics
+    ssum = torch.zeros(K, device=dev); ssq = torch.zeros(K, device=dev)
+    y = K_.conv3d_fwd(xg, wg, d, stats=(ssum, ssq))
+    xr = x.float().requires_grad_(True); wr = w.float().requires_grad_(True)
+    yr = _conv_ref(xr, wr, stride, pad)
+    close(y, yr, BF16_TOL, 'conv fwd')
+    close(ssum, yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'bn sum')
+    close(ssq, (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'bn sumsq')
+    # forward with bias + addend + relu
+    b = rnd((K,), 3); a = bf(rnd(tuple(yr.shape), 4))
+    y2 = K_.conv3d_fwd(xg, wg, d, bias=b.to(dev), addend=a.to(dev), relu=True)
+    close(y2, F.relu(yr.detach() + b + a.float()), BF16_TOL, 'conv fwd epilogue')
+    # backward
+    dy = bf(rnd(tuple(yr.shape), 5))
+    yr.backward(dy.float())
+    taps = int(np.prod(kern))
+    if not name.startswith('stem'):
+        wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+        K_.weight_transpose(wg, wT, K, taps, C)
+        assert torch.equal(wT.cpu(), w.permute(4, 1, 2, 3, 0).contiguous())
+        dx = K_.conv3d_dgrad(dy.to(dev), wT, d)
+        close(dx, xr.grad, BF16_TOL, 'conv dgrad')
+        add = bf(rnd(tuple(x.shape), 6))
+        dx2 = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
+        close(dx2, xr.grad + add.float(), BF16_TOL, 'conv dgrad+addend')
+    dw = torch.zeros((K, *kern, C), dtype=torch.float32, device=dev)
+    db = torch.zeros((K,), dtype=torch.float32, device=dev)
+    K_.conv3d_wgrad(xg, dy.to(dev), d, dw, db)
+    close(dw, wr.grad, F32_TOL, 'conv wgrad')
+    close(db, dy.float().sum(dim=(0, 1, 2, 3)), F32_TOL, 'conv dbias')
+    K_.conv3d_wgrad(xg, dy.to(dev), d, dw, None)           # accumulates
+    close(dw, 2 * wr.grad, F32_TOL, 'conv wgrad accumulate')
+
+
+@pytest.mark.parametrize('C,relu,resmode', [(64, True, 'none'), (64, True, 'identity'), (128, True, 'bn'),
+                                            (16, False, 'none'), (32, True, 'identity'), (512, True, 'bn')])
+def test_bn_act_fwd_bwd(C, relu, resmode, dev):
+    from mscl_amd import kernels as K_
+    from mscl_amd.kernels import _bnp
+    shape = (2, 3, 5, 7, C)
+    rows = 2 * 3 * 5 * 7
+    y = bf(rnd(shape, 1) * 1.5 + 0.3)
+    gamma = 1 + 0.1 * rnd((C,), 2); beta = 0.1 * rnd((C,), 3)
+    res = bf(rnd(shape, 4)) if resmode != 'none' else None
+    rgamma = 1 + 0.1 * rnd((C,), 5); rbeta = 0.1 * rnd((C,), 6)
+    # reference: torch BatchNorm in training mode on NCTHW fp32
+    def bn_ref(inp, g, b_):
+        m = torch.nn.BatchNorm3d(C)
+        m.weight.data.copy_(g); m.bias.data.copy_(b_)
+        m.train()
+        return m, m(inp.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+    yr = y.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    m1, z = bn_ref(yr, gamma, beta)
+    rr = None
+    if resmode == 'identity':
+        rr = res.float().requires_grad_(True); z = z + rr
+    elif resmode == 'bn':
+        rr = res.float().requires_grad_(True); m2, z2 = bn_ref(rr, rgamma, rbeta); z = z + z2
+    out_ref = F.relu(z) if relu else z
+    # device
+    def stats_of(t):
+        f = t.float().to(dev).reshape(-1, C)
+        return f.sum(0).contiguous(), (f * f).sum(0).contiguous()
+    mk = lambda: dict(rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev),
+                      nbt=torch.zeros((), dtype=torch.long, device=dev), sm=torch.empty(C, device=dev), si=torch.empty(C, device=dev))
+    s1 = mk(); g1, b1 = gamma.to(dev), beta.to(dev)
+    st1 = stats_of(y)                      # keep alive: BnParams only holds raw pointers
+    bn = _bnp(st1, g1, b1, s1['rm'], s1['rv'], s1['nbt'], s1['sm'], s1['si'])
+    rbn = None
+    if resmode == 'bn':
+        s2 = mk(); g2, b2 = rgamma.to(dev), rbeta.to(dev)
+        st2 = stats_of(res)
+        rbn = _bnp(st2, g2, b2, s2['rm'], s2['rv'], s2['nbt'], s2['sm'], s2['si'])
+    out = K_.bn_act_fwd(y.to(dev), bn, residual=res.to(dev) if res is not None else None, res_bn=rbn, relu=relu)
+    close(out, out_ref, BF16_TOL, 'bn fwd')
+    close(s1['rm'], m1.running_mean, 1e-4, 'running_mean'); close(s1['rv'], m1.running_var, 1e-4, 'running_var')
+    assert int(s1['nbt']) == 1
+    if resmode == 'bn':
+        close(s2['rm'], m2.running_mean, 1e-4, 'res running_mean'); close(s2['rv'], m2.running_var, 1e-4, 'res running_var')
+    # backward: use the device's own bf16 `out` for the relu mask on both sides
+    dout = bf(rnd(shape, 7))
+    mask = (out.float().cpu() > 0).float() if relu else torch.ones(shape)
+    z.backward(dout.float() * mask)
+    dgamma = torch.zeros(C, device=dev); dbeta = torch.zeros(C, device=dev)
+    scratch = torch.zeros(4 * C, device=dev)
+    resd = None
+    if resmode == 'bn':
+        rdg = torch.zeros(C, device=dev); rdb = torch.zeros(C, device=dev)
+        resd = dict(y=res.to(dev), gamma=g2, mean=s2['sm'], invstd=s2['si'], dgamma=rdg, dbeta=rdb)
+    dy, dres = K_.bn_act_bwd(dout.to(dev), out, y.to(dev), g1, s1['sm'], s1['si'], dgamma, dbeta, relu, scratch,
+                             res=resd, want_identity_dres=(resmode == 'identity'))
+    close(dy, yr.grad, 2 * BF16_TOL, 'bn dy')
+    close(dgamma, m1.weight.grad, 2e-3, 'dgamma'); close(dbeta, m1.bias.grad, 2e-3, 'dbeta')
+    if resmode == 'identity':
+        close(dres, rr.grad, BF16_TOL, 'identity dres')
+    if resmode == 'bn':
+        close(dres, rr.grad, 2 * BF16_TOL, 'bn dres')
+        close(rdg, m2.weight.grad, 2e-3, 'res dgamma'); close(rdb, m2.bias.grad, 2e-3, 'res dbeta')
+
+
+def test_pack_add_relu_pool(dev):
+    from mscl_amd import kernels as K_
+    x = torch.rand(2, 3, 4, 6, 5, generator=torch.Generator().manual_seed(0))
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = K_.pack_input(x.to(dev), mean, std)
+    ref = torch.zeros(2, 4, 6, 5, 8)
+    ref[..., :3] = ((x - torch.tensor(mean).view(1, 3, 1, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1, 1)).permute(0, 2, 3, 4, 1)
+    close(out, ref, BF16_TOL, 'pack_input')
+    assert torch.equal(out[..., 3:].cpu().float(), torch.zeros(2, 4, 6, 5, 5))
+    out2 = K_.pack_input(x.to(dev))
+    close(out2[..., :3], x.permute(0, 2, 3, 4, 1), BF16_TOL, 'pack_input raw')
+    out3 = K_.pack_input(x.to(dev), t_off=2, T=2)            # second half of the frames, no copy
+    close(out3[..., :3], x[:, :, 2:].permute(0, 2, 3, 4, 1), BF16_TOL, 'pack_input window')
+    a, b, c = (bf(rnd((2, 3, 4, 5, 16), s)) for s in (1, 2, 3))
+    close(K_.add_relu(a.to(dev), b.to(dev), c.to(dev), relu=True), F.relu(a.float() + b.float() + c.float()), BF16_TOL, 'add3 relu')
+    close(K_.add_relu(a.to(dev), b.to(dev)), a.float() + b.float(), BF16_TOL, 'add2')
+    close(K_.relu_bwd(a.to(dev), b.to(dev)), a.float() * (b.float() > 0), BF16_TOL, 'relu bwd')
+    xm = bf(rnd((4, 37, 128), 4))
+    p = K_.pool_fwd(xm.to(dev), 4, 37)
+    close(p, xm.float().mean(1), 1e-5, 'pool fwd')
+    dp = rnd((4, 128), 5)
+    dx = K_.pool_bwd(dp.to(dev), (4, 37, 128), 4, 37)
+    close(dx, (dp / 37).unsqueeze(1).expand(4, 37, 128), BF16_TOL, 'pool bwd')
+    base = bf(rnd((4, 37, 128), 6)).to(dev)
+    dx2 = K_.pool_bwd(dp.to(dev), (4, 37, 128), 4, 37, into=base.clone())
+    close(dx2, base.float().cpu() + (dp / 37).unsqueeze(1), BF16_TOL, 'pool bwd accumulate')
+
+
+@pytest.mark.parametrize('tri', [False, True])
+def test_upsample(tri, dev):
+    from mscl_amd import kernels as K_
+    mode = 'trilinear' if tri else 'nearest'
+    for (ss, ds) in (((2, 7, 7), (4, 14, 14)), ((4, 14, 14), (8, 28, 28)), ((2, 3, 5), (3, 7, 9))):
+        src = bf(rnd((2, *ss, 16), 1)); dst = bf(rnd((2, *ds, 16), 2))
+        sr = src.float().requires_grad_(True)
+        up = F.interpolate(sr.permute(0, 4, 1, 2, 3), size=ds, mode=mode).permute(0, 2, 3, 4, 1)
+        got = K_.upsample_add(src.to(dev), dst.to(dev).clone(), tri, accumulate=True)
+        close(got, up + dst.float(), BF16_TOL, f'upsample add {mode} {ss}->{ds}')
+        got = K_.upsample_add(src.to(dev), torch.empty_like(dst, device=dev), tri, accumulate=False)
+        close(got, up, BF16_TOL, f'upsample {mode}')
+        dd = bf(rnd((2, *ds, 16), 3))
+        up.backward(dd.float())
+        close(K_.upsample_bwd(dd.to(dev), tuple(src.shape), tri), sr.grad, BF16_TOL, f'upsample bwd {mode}')
+
+
+def test_linear_l2norm(dev):
+    from mscl_amd import kernels as K_
+    for rows, i, o, relu in ((8, 512, 512, True), (8, 512, 128, False), (2, 128, 128, True), (16, 128, 128, False)):
+        x = rnd((rows, i), 1).requires_grad_(True); w = (rnd((o, i), 2) / i ** 0.5).requires_grad_(True); b = rnd((o,), 3).requires_grad_(True)
+        y = F.linear(x, w, b); y = F.relu(y) if relu else y
+        yd = K_.linear_fwd(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev), relu)
+        close(yd, y, F32_TOL, 'linear fwd')
+        dy = rnd((rows, o), 4); y.backward(dy)
+        dw = torch.zeros(o, i, device=dev); db = torch.zeros(o, device=dev)
+        dx = K_.linear_bwd(x.detach().to(dev), w.detach().to(dev), yd, dy.to(dev), dw, db, relu)
+        close(dx, x.grad, F32_TOL, 'linear dx'); close(dw, w.grad, F32_TOL, 'linear dw'); close(db, b.grad, F32_TOL, 'linear db')
+    x = rnd((8, 128), 5).requires_grad_(True)
+    y = F.normalize(x, dim=1); dy = rnd((8, 128), 6); y.backward(dy)
+    yd, nr = K_.l2norm_fwd(x.detach().to(dev))
+    close(yd, y, 1e-6, 'l2norm fwd')
+    close(K_.l2norm_bwd(yd, nr, dy.to(dev)), x.grad, 1e-5, 'l2norm bwd')
+
+
+@pytest.mark.parametrize('R,K', [(8, 1024), (24, 65536), (16, 4096), (3, 640), (32, 2048)])
+def test_nce(R, K, dev):
+    from mscl_amd import kernels as K_
+    dim, T = 128, 0.07
+    queue = F.normalize(rnd((dim, K), 1), dim=0)
+    count = torch.randint(0, 9000, (K,), generator=torch.Generator().manual_seed(2))
+    q = F.normalize(rnd((R, dim), 3), dim=1).requires_grad_(True)
+    kpos = F.normalize(rnd((R, dim), 4), dim=1)
+    pos = (q * kpos).sum(1)
+    w = queue * (0.99999 ** (1.0 * count))
+    logits = torch.cat([pos[:, None], q @ w], 1) / T
+    loss_rows = F.cross_entropy(logits, torch.zeros(R, dtype=torch.long), reduction='none')
+    rank = (logits[:, 1:] > logits[:, :1]).sum(1)
+    lse, lr, rk = K_.nce_forward(queue.to(dev), count.to(dev), q.detach().to(dev), pos.detach().to(dev), 1.0 / T)
+    close(lse, torch.logsumexp(logits, 1), 1e-5, 'lse')
+    close(lr, loss_rows, 2e-5, 'nce loss rows')
+    assert torch.equal(rk.cpu().long(), rank), (rk.cpu(), rank)
+    scale = rnd((R,), 5).abs() + 0.1
+    # gradient of sum_r scale_r * loss_r wrt q through the NEGATIVE logits only
+    neg_only = (torch.logsumexp(torch.cat([pos.detach()[:, None], q @ w], 1) / T, 1) * scale).sum()
+    gq, = torch.autograd.grad(neg_only, q)
+    dq = K_.nce_backward(queue.to(dev), count.to(dev), q.detach().to(dev), lse, scale.to(dev), 1.0 / T)
+    close(dq, gq, 1e-4, 'nce dq')
+
+
+def test_enqueue_bit_exact(dev):
+    from mscl_amd import kernels as K_
+    dim, K, n = 128, 64, 8
+    queue = rnd((dim, K), 1); count = torch.zeros(K, dtype=torch.long); ptr = torch.zeros(1, dtype=torch.long)
+    qd, cd, pd = queue.to(dev), count.to(dev), ptr.to(dev)
+    for step in range(11):                       # wraps around K=64 after 8 steps
+        keys = rnd((n, dim), 10 + step)
+        K_.queue_enqueue(qd, cd, pd, keys.to(dev))
+        count += 1; p = int(ptr); queue[:, p:p + n] = keys.T; count[p:p + n] = 1; ptr[0] = (p + n) % K
+        assert torch.equal(cd.cpu(), count) and torch.equal(pd.cpu(), ptr) and torch.equal(qd.cpu(), queue)
+    with pytest.raises(Exception):
+        K_.queue_enqueue(qd, cd, pd, rnd((7, dim), 0).to(dev))      # K % n != 0 (moco.py:432 assert)
+
+
+@pytest.mark.parametrize('B,t', [(2, 4), (8, 8), (3, 2)])
+def test_lmcl(B, t, dev):
+    from mscl_amd import kernels as K_
+    C, T = 128, 0.07
+    rgb = rnd((B, t, C), 1).requires_grad_(True); flow = rnd((B, 2 * t, C), 2).requires_grad_(True)
+    xr = F.normalize(rgb.transpose(1, 2), dim=1); xf = F.normalize(flow.transpose(1, 2), dim=1)
+    sim = torch.bmm(xr.transpose(1, 2), xf).flatten(0, 1) / T
+    labels = torch.arange(t).repeat(B)
+    loss = F.cross_entropy(sim, labels)
+    loss.backward()
+    pos = sim[torch.arange(B * t), labels]
+    rank = (sim > pos[:, None]).sum(1)
+    ls, hits, drgb, dflow = K_.lmcl(rgb.detach().to(dev), flow.detach().to(dev), 1.0 / T)
+    close(ls / (B * t), loss.reshape(1), 1e-5, 'lmcl loss')
+    assert hits.cpu().tolist() == [int((rank == 0).sum()), int((rank < 5).sum())]
+    close(drgb, rgb.grad, 1e-4, 'lmcl drgb'); close(dflow, flow.grad, 1e-4, 'lmcl dflow')
+
+
+def test_ema_sgd(dev):
+    from mscl_amd import kernels as K_
+    n = 100003
+    pk, pq = rnd((n + 1,), 1)[:n].clone(), rnd((n + 1,), 2)[:n].clone()
+    m = 0.9953
+    pkd = pk.to(dev); pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    K_.ema_update(pkd, pq.to(dev), pb, m)
+    ref = pk * m + pq * (1.0 - m)
+    close(pkd, ref, 1e-6, 'ema'); assert torch.equal(pb.cpu(), pkd.cpu().to(torch.bfloat16))
+    # clip + SGD, two steps, against torch.optim.SGD + clip_grad_norm_
+    p = torch.nn.Parameter(rnd((n,), 3)); opt = torch.optim.SGD([p], lr=0.02, momentum=0.9, weight_decay=1e-4)
+    pd = p.detach().clone().to(dev); buf = torch.zeros(n, device=dev); pbf = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    for step in range(2):
+        g = rnd((n,), 10 + step) * (3.0 if step == 0 else 0.01)     # step 0 clips (norm > 40), step 1 does not
+        p.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([p], 40.0, 2.0)
+        opt.step()
+        ss = torch.zeros(1, device=dev)
+        K_.sumsq(g.to(dev), ss)
+        close(ss.sqrt(), tn.reshape(1), 1e-5, 'grad norm')
+        K_.sgd_step(pd, g.to(dev), buf, pbf, ss, 40.0, 0.02, 0.9, 1e-4, first=(step == 0))
+        close(pd, p.detach(), 2e-6, f'sgd step {step}')
+    assert torch.equal(pbf.cpu(), pd.cpu().to(torch.bfloat16))
