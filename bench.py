@@ -1,0 +1,150 @@
+"""MSCL hot-path benchmark: clip-pairs / second / node for the full MSCLWithAug training step
+(dual-stream R3D-18 + r2d_18, MoCo queues, cross-modal InfoNCE, LMCL, backward, grad-clip + SGD).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch of 8 clip-pairs per GPU (16 frames, 112x112,
+RGB q/k + visualised flow q/k as base||rotated), inputs resident in HBM, weights from the closed-form
+fill.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      dominant kernel = the layer-1 3x3x3 64->64 implicit-GEMM conv (MFMA-bound), timed with
+                events on the launch stream during the timed steps
+  cpu_baseline  the oracle/ restatement ("port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+T_FRAMES, SIDE, BATCH = 16, 112, 8
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-batch', type=int, default=4)
+    return p.parse_args()
+
+
+def cpu_baseline(cpu_batch):
+    """oracle/ (pure-PyTorch fp32 restatement of the reference step) on the host cores: 1 untimed + 1 timed step."""
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    threads = torch.get_num_threads()
+    orc = om.MSCLWithAug(num_frames=T_FRAMES)
+    ofill.fill_module(orc)
+    orc.train()
+    opt = om.SGDClip(orc.parameters())
+    times = []
+    for s in range(2):
+        batch = synthetic_batch(cpu_batch, T_FRAMES, SIDE, SIDE, 0, s)
+        t0 = time.perf_counter()
+        out = orc.train_step(batch)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    return dict(value=cpu_batch / times[-1], unit='clip-pairs/s', cores=threads, kind='port',
+                sample=f'oracle MSCLWithAug step (fwd+bwd+clip+SGD), fp32, B={cpu_batch}, T={T_FRAMES}, {SIDE}x{SIDE}, '
+                       f'1 warm-up + 1 timed step ({times[-1]:.1f} s)')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from mscl_amd import ClipSGD, Config, build_model, kernels
+    from mscl_amd.fill import fill_module
+    from mscl_amd.synthetic import synthetic_batch
+
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    cfg.model.sup_head.t = T_FRAMES // 2            # the config derives it from num_frames (16 here, 8 as shipped)
+    model = build_model(cfg.model)
+    fill_module(model)
+    model.materialize(dev).train()
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    nbatch = 4
+    batches = [synthetic_batch(BATCH, T_FRAMES, SIDE, SIDE, rank, s, device=dev) for s in range(nbatch)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        out = model.train_step(batches[i % nbatch], sync_logs=False)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    kernels.PROFILE_CONV = dict(sig=(BATCH, T_FRAMES, SIDE // 2, SIDE // 2, 64, 64, 3), events=[])
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = kernels.PROFILE_CONV
+    kernels.PROFILE_CONV = None
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss = float(out['loss'])
+    if not (loss == loss):
+        raise SystemExit('loss is NaN')
+
+    if rank == 0:
+        ms = [a.elapsed_time(b) for a, b in prof['events']]
+        avg_ms = sum(ms) / max(1, len(ms))
+        flops = 2.0 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 27 * 64       # 88.8 GFLOP per launch
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if ms else 0.0
+        line = {
+            'metric': 'clip-pairs/sec/node (R3D-18, 16x112^2, bs8/gpu)',
+            'value': world * BATCH * args.steps / dt, 'unit': 'clip-pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'full MSCLWithAug step (dual-stream R3D-18 + r2d_18, MoCo queues K=65536, '
+                                   'cross-modal InfoNCE, LMCL, backward, clip+SGD), mscl_r18 config with T=16',
+                       'clip': f'{T_FRAMES}x{SIDE}x{SIDE}', 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
+                       'parallelism': f'dp{world}', 'weights': 'closed-form fill, fp32 masters + bf16 shadows'},
+            'final_loss': loss,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<256,64,64> fwd, 3x3x3 64->64 on (8,16,56,56,64)',
+                         'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
+                         'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

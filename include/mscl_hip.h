@@ -138,6 +138,12 @@ int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float
 int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse,
                  const float* row_scale, float* dq, int R, int dim, int K, float inv_T, void* stream);
 
+/* pos[r] = <a[r], b[r]> (l_pos, recognizers/moco.py:481) and the positive-key term of the query gradient:
+ * dq[r] += row_scale[r] * inv_T * (softmax_pos[r] - 1) * kpos[r] */
+int mscl_rowdot(const float* a, const float* b, float* out, int rows, int dim, void* stream);
+int mscl_nce_pos_bwd(const float* kpos, const float* pos, const float* lse, const float* row_scale, float* dq,
+                     int R, int dim, float inv_T, void* stream);
+
 /* queue bookkeeping, bit-exact int64: count += 1; queue[:, ptr:ptr+n] = keys^T; count[ptr:ptr+n] = 1;
  * ptr = (ptr+n) % K.   recognizers/moco.py:423-440.  keys: (n, dim) fp32, ptr: int64[1] on device. */
 int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, const float* keys, int n, int dim, int K, void* stream);

@@ -276,3 +276,35 @@ extern "C" int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, i
   MSCL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- positive-pair pieces of InfoNCE
+// pos[r] = <a[r], b[r]>   (l_pos = einsum('nc,nc->n'), recognizers/moco.py:481)
+__global__ __launch_bounds__(64) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ out, int dim) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int i = lane; i < dim; i += 64) s += a[(long)r * dim + i] * b[(long)r * dim + i];
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s;
+}
+extern "C" int mscl_rowdot(const float* a, const float* b, float* out, int rows, int dim, void* stream) {
+  if (!a || !b || !out || rows <= 0 || dim <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, a, b, out, dim);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+// dq[r][:] += row_scale[r] * inv_T * (softmax_pos[r] - 1) * kpos[r][:]
+__global__ __launch_bounds__(64) void nce_pos_bwd_kernel(const float* __restrict__ kpos, const float* __restrict__ pos,
+                                                         const float* __restrict__ lse, const float* __restrict__ row_scale,
+                                                         float* __restrict__ dq, int dim, float inv_T) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float coef = row_scale[r] * inv_T * (__expf(pos[r] * inv_T - lse[r]) - 1.f);
+  for (int i = lane; i < dim; i += 64) dq[(long)r * dim + i] += coef * kpos[(long)r * dim + i];
+}
+extern "C" int mscl_nce_pos_bwd(const float* kpos, const float* pos, const float* lse, const float* row_scale, float* dq,
+                                int R, int dim, float inv_T, void* stream) {
+  if (!kpos || !pos || !lse || !row_scale || !dq || R <= 0 || dim <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(nce_pos_bwd_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, kpos, pos, lse, row_scale, dq, dim, inv_T);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}

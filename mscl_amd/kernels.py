@@ -29,12 +29,23 @@ def out_shape(d):
     return (d.N, d.To, d.Ho, d.Wo, d.K)
 
 
+PROFILE_CONV = None      # bench.py: dict(sig=(N,T,H,W,C,K,kT), events=[]) -> event pairs around matching launches
+
+
 def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats = (sum, sumsq) fp32 K-vectors, pre-zeroed."""
     y = torch.empty(out_shape(d), dtype=torch.bfloat16, device=x.device)
     s0, s1 = stats if stats is not None else (None, None)
+    prof = PROFILE_CONV
+    timed = prof is not None and prof['sig'] == (d.N, d.T, d.H, d.W, d.C, d.K, d.kT)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call('mscl_conv3d_fwd', ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(addend), int(relu),
          ptr(s0), ptr(s1), stream_ptr())
+    if timed:
+        e1.record()
+        prof['events'].append((e0, e1))
     return y
 
 
@@ -188,6 +199,16 @@ def nce_backward(queue, count, q, lse, row_scale, inv_T):
     dq = torch.zeros((R, dim), dtype=torch.float32, device=q.device)
     call('mscl_nce_bwd', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), R, dim, queue.shape[1], inv_T, stream_ptr())
     return dq
+
+
+def rowdot(a, b):
+    out = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    call('mscl_rowdot', ptr(a), ptr(b), ptr(out), a.shape[0], a.shape[1], stream_ptr())
+    return out
+
+
+def nce_pos_bwd(kpos, pos, lse, row_scale, dq, inv_T):
+    call('mscl_nce_pos_bwd', ptr(kpos), ptr(pos), ptr(lse), ptr(row_scale), ptr(dq), dq.shape[0], dq.shape[1], inv_T, stream_ptr())
 
 
 def queue_enqueue(queue, count, qptr, keys):

@@ -1,0 +1,145 @@
+"""Necks of the MSCL recognizers on HIP kernels (registry names and constructor kwargs of the reference).
+
+ref: mmaction/models/necks/base.py:9-24 (BaseMoCo), :136-175 (TPNMoCo); necks/fpn_video.py:43-136 (TPNSingle);
+necks/fpn.py:130-152,188-203 (FPN); necks/sepc.py:16-54,57-135 (SEPC / PConv3D).
+"""
+import torch
+import torch.nn as nn
+
+from .nn import Conv3dHip, conv_bias, pool, upsample
+from .registry import NECKS
+
+
+def global_pool(x):
+    """AdaptiveAvgPool3d((1,1,1)) + Flatten on an NDHWC map -> (N, C) fp32 (necks/base.py:17-21)."""
+    n, t, h, w, c = x.shape
+    return pool(x, n, t * h * w)
+
+
+@NECKS.register_module()
+class BaseMoCo(nn.Module):
+    def forward(self, feats):
+        return (global_pool(feats[-1]), feats), dict()
+
+    def init_weights(self):
+        pass
+
+
+class _ConvModule(nn.Module):
+    """mmcv ConvModule with norm_cfg=None, act_cfg=None == conv + bias under `.conv` (fpn.py:131-149)."""
+
+    def __init__(self, cin, cout, kernel, pad):
+        super().__init__()
+        self.conv = Conv3dHip(cin, cout, kernel, 1, pad, bias=True)
+
+
+class FPNHip(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel=(1, 3, 3)):
+        super().__init__()
+        pad = tuple((k - 1) // 2 for k in kernel)
+        self.lateral_convs = nn.ModuleList(_ConvModule(c, out_channels, 1, 0) for c in in_channels)
+        self.fpn_convs = nn.ModuleList(_ConvModule(out_channels, out_channels, kernel, pad) for _ in in_channels)
+
+    def forward(self, feats):
+        """top-down: lat[i-1] += nearest_up(lat[i]) (fpn.py:193-203); the add rides the lateral conv's
+        epilogue instead of a separate pass."""
+        n = len(feats)
+        lat = [None] * n
+        lat[n - 1] = conv_bias(self.lateral_convs[n - 1].conv, feats[n - 1])
+        for i in range(n - 2, -1, -1):
+            up = upsample(lat[i + 1], feats[i].shape[1:4], trilinear=False)
+            lat[i] = conv_bias(self.lateral_convs[i].conv, feats[i], addend=up)
+        return [conv_bias(self.fpn_convs[i].conv, lat[i]) for i in range(n)]
+
+
+class PConv3DHip(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.Pconv = nn.ModuleList([
+            Conv3dHip(cin, cout, 3, 1, 1, bias=True),
+            Conv3dHip(cin, cout, 3, 1, 1, bias=True),
+            Conv3dHip(cin, cout, 3, stride, 1, bias=True),
+        ])
+
+    def forward(self, xs, levels=None):
+        """y_l = relu(P1(x_l) [+ P2(x_{l-1})] [+ trilinear_up(P0(x_{l+1}))])  (sepc.py:118-135).
+        Sums and the ReLU ride conv epilogues.  `levels`: output levels to compute (None = all)."""
+        L = len(xs)
+        out = []
+        for l in range(L):
+            if levels is not None and l not in levels:
+                out.append(None)
+                continue
+            acc = None
+            if l < L - 1:
+                acc = upsample(conv_bias(self.Pconv[0], xs[l + 1]), xs[l].shape[1:4], trilinear=True)
+            if l > 0:
+                acc = conv_bias(self.Pconv[1], xs[l], addend=acc)
+                y = conv_bias(self.Pconv[2], xs[l - 1], addend=acc, relu=True)
+            else:
+                y = conv_bias(self.Pconv[1], xs[l], addend=acc, relu=True)
+            out.append(y)
+        return out
+
+
+class SEPCHip(nn.Module):
+    def __init__(self, in_channels=[256] * 3, out_channels=256, stride=(2, 1, 1), iBN=False, Pconv_num=2):
+        super().__init__()
+        if iBN:
+            raise NotImplementedError('iBN=True is not used by the MSCL configs (mscl_r18_cosm_lr2e-2.py:23)')
+        self.in_channels = in_channels
+        self.Pconvs = nn.ModuleList(PConv3DHip(in_channels[i], out_channels, stride) for i in range(Pconv_num))
+
+    def forward(self, xs):
+        assert len(xs) == len(self.in_channels)
+        for p in self.Pconvs:
+            xs = p(xs)
+        return xs
+
+
+class TPNSingleHip(nn.Module):
+    def __init__(self, in_channels, out_channels, fpn_cfg, temporal_modulation_cfg, sepc_cfg, reverse_st=False):
+        super().__init__()
+        assert isinstance(in_channels, list) and isinstance(out_channels, int)
+        if temporal_modulation_cfg is not None or reverse_st:
+            raise NotImplementedError('temporal modulation / reverse_st are not used by the MSCL configs')
+        self.num_tpn_stages = len(in_channels)
+        self.fpn = FPNHip(in_channels, out_channels, kernel=tuple(fpn_cfg.get('fpn_kerne_size', (1, 3, 3))))
+        self.sepc = SEPCHip(**sepc_cfg) if sepc_cfg is not None else None
+        self.init_weights()
+
+    def init_weights(self):
+        """every Conv3d under the neck ends up xavier-uniform with zero bias: TPNSingle.init_weights
+        (fpn_video.py:97-108) runs after, and overwrites, PConv3D's normal(0, 0.01)."""
+        for m in self.modules():
+            if isinstance(m, Conv3dHip):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, feats):
+        outs = self.fpn(list(feats[-self.num_tpn_stages:]))
+        return self.sepc(outs) if self.sepc is not None else outs
+
+
+@NECKS.register_module()
+class TPNMoCo(nn.Module):
+    def __init__(self, in_channels, out_channels,
+                 fpn_cfg=dict(fpn_kerne_size=(1, 3, 3), conv_cfg=dict(type='Conv3d')),
+                 temporal_modulation_cfg=None, sepc_cfg=None, reverse_st=False, emb_from_bkb=True):
+        super().__init__()
+        self.tpn = TPNSingleHip(list(in_channels), out_channels, fpn_cfg, temporal_modulation_cfg,
+                                dict(sepc_cfg) if sepc_cfg is not None else None, reverse_st=reverse_st)
+        self.emb_from_bkb = emb_from_bkb
+
+    def init_weights(self):
+        self.tpn.init_weights()
+
+    def forward(self, feats, target=None):
+        if self.emb_from_bkb:
+            emb = global_pool(feats[-1])
+            outs = self.tpn(feats)
+        else:
+            outs = self.tpn(feats)
+            emb = global_pool(outs[-1])
+        return (emb, outs), {}

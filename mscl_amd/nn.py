@@ -1,0 +1,339 @@
+"""HIP-backed building blocks: parameter-holding nn.Modules with the reference's state-dict names, and
+torch.autograd.Functions that call the gfx950 kernels through the C ABI.
+
+PyTorch's role here is plumbing only: it owns device memory, the stream and the autograd *graph*; all
+arithmetic on activations, parameters and gradients is done by libmscl_hip.so.  Parameter gradients
+never travel through autograd: kernels accumulate them straight into the flat gradient arena
+(mscl_amd/arena.py), so a fused block is one graph node.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .lib import MsclError
+
+
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(int(i) for i in v)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise MsclError('mscl_amd modules compute on the GPU only: move the model with .materialize("cuda") '
+                        'and feed CUDA tensors (there is no CPU fallback; the CPU restatement lives in oracle/ for tests)')
+
+
+class Conv3dHip(nn.Module):
+    """Parameter holder + kernel front-end for nn.Conv3d (state-dict: `weight` (Cout,Cin,kT,kH,kW), `bias`)."""
+
+    def __init__(self, cin, cout, kernel, stride=1, padding=0, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.kernel_size, self.stride, self.padding = _triple(kernel), _triple(stride), _triple(padding)
+        self.weight = nn.Parameter(torch.empty(cout, cin, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.cin_eff = cin if cin % 8 == 0 else 8
+        self.taps = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        self._rt = None           # runtime views, set by materialize()
+        self._descs = {}
+
+    def extra_repr(self):
+        return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}, bias={self.bias is not None}'
+
+    def desc(self, x_shape):
+        d = self._descs.get(tuple(x_shape))
+        if d is None:
+            d = K.conv_desc(tuple(x_shape), self.out_channels, self.kernel_size, self.stride, self.padding)
+            self._descs[tuple(x_shape)] = d
+        return d
+
+    def fwd(self, x, addend=None, relu=False, stats=None):
+        rt = self._rt
+        if rt is None:
+            raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
+        return K.conv3d_fwd(x, rt['w'], self.desc(x.shape), bias=rt['bias'], addend=addend, relu=relu, stats=stats)
+
+    def dgrad(self, dy, x_shape, addend=None):
+        return K.conv3d_dgrad(dy, self._rt['wT'], self.desc(x_shape), addend=addend)
+
+    def wgrad(self, x, dy):
+        rt = self._rt
+        K.conv3d_wgrad(x, dy, self.desc(x.shape), rt['dw'], rt['dbias'])
+        rt['slot_w'].touched = True
+        if rt['slot_b'] is not None:
+            rt['slot_b'].touched = True
+
+
+class BatchNorm3dHip(nn.Module):
+    """Parameter/buffer holder for nn.BatchNorm3d (training-mode batch statistics only)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._rt = None
+
+    def extra_repr(self):
+        return f'{self.num_features}, eps={self.eps}, momentum={self.momentum}'
+
+
+def cba_fwd(conv, bn, x, residual, relu):
+    """conv -> BN(batch stats fused into the conv epilogue) -> (+residual) -> (ReLU).
+    Returns (y raw conv output, out, save[2,C] = mean/invstd)."""
+    if not bn.training:
+        raise MsclError('BatchNorm3dHip implements training-mode statistics only (both MoCo encoders run in train(), SURVEY App. E-6)')
+    C = conv.out_channels
+    stats = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+    y = conv.fwd(x, stats=(stats[0], stats[1]))
+    save = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    rt = bn._rt
+    bnp = K._bnp((stats[0], stats[1]), rt['gamma'], rt['beta'], bn.running_mean, bn.running_var,
+                 bn.num_batches_tracked, save[0], save[1])
+    out = K.bn_act_fwd(y, bnp, residual=residual, relu=relu, eps=bn.eps, momentum=bn.momentum)
+    return y, out, save
+
+
+def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_addend=None):
+    """backward of cba_fwd: BN(+ReLU) input gradient, conv weight gradient (into the arena), conv input
+    gradient (optionally fused with `dx_addend`).  Returns (dx|None, dres|None)."""
+    rt = bn._rt
+    C = conv.out_channels
+    scratch = torch.zeros((4 * C,), dtype=torch.float32, device=dout.device)
+    dy, dres = K.bn_act_bwd(dout, out, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], relu, scratch,
+                            want_identity_dres=want_dres)
+    rt['slot_g'].touched = True
+    rt['slot_b'].touched = True
+    conv.wgrad(x, dy)
+    dx = conv.dgrad(dy, x.shape, addend=dx_addend) if need_dx else None
+    return dx, dres
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, stem):
+        conv, bn = stem[0], stem[1]
+        y, out, save = cba_fwd(conv, bn, x, None, True)
+        ctx.stem = stem
+        ctx.save_for_backward(x, y, out, save)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, out, save = ctx.saved_tensors
+        conv, bn = ctx.stem[0], ctx.stem[1]
+        cba_bwd(conv, bn, dout.contiguous(), out, y, save, x, True, need_dx=False)
+        return None, None, None
+
+
+class _BlockFn(torch.autograd.Function):
+    """One BasicBlock as a single graph node (ref: r3d.py:95-127 / fastonly.py:104-136):
+    out = relu(bn2(conv2(relu(bn1(conv1 x)))) + shortcut(x))."""
+
+    @staticmethod
+    def forward(ctx, x, block):
+        c1, b1 = block.conv1[0], block.conv1[1]
+        c2, b2 = block.conv2[0], block.conv2[1]
+        y1, a1, s1 = cba_fwd(c1, b1, x, None, True)
+        if block.downsample is not None:
+            yd, ad, sd = cba_fwd(block.downsample[0], block.downsample[1], x, None, False)
+            res = ad
+        else:
+            yd = sd = None
+            res = x
+        y2, out, s2 = cba_fwd(c2, b2, a1, res, True)
+        ctx.block = block
+        ctx.has_ds = yd is not None
+        if ctx.has_ds:
+            ctx.save_for_backward(x, y1, a1, s1, y2, out, s2, yd, sd)
+        else:
+            ctx.save_for_backward(x, y1, a1, s1, y2, out, s2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        block = ctx.block
+        if ctx.has_ds:
+            x, y1, a1, s1, y2, out, s2, yd, sd = ctx.saved_tensors
+        else:
+            x, y1, a1, s1, y2, out, s2 = ctx.saved_tensors
+        c1, b1 = block.conv1[0], block.conv1[1]
+        c2, b2 = block.conv2[0], block.conv2[1]
+        da1, dz = cba_bwd(c2, b2, dout.contiguous(), out, y2, s2, a1, True, need_dx=True, want_dres=True)
+        if ctx.has_ds:
+            dxd, _ = cba_bwd(block.downsample[0], block.downsample[1], dz, None, yd, sd, x, False, need_dx=True)
+            shortcut_grad = dxd
+        else:
+            shortcut_grad = dz
+        dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
+        return dx, None
+
+
+class BasicBlockHip(nn.Module):
+    def __init__(self, cin, cout, kernel, stride, pad, shortcut_stride=None):
+        super().__init__()
+        self.conv1 = nn.Sequential(Conv3dHip(cin, cout, kernel, stride, pad), BatchNorm3dHip(cout), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(Conv3dHip(cout, cout, kernel, 1, pad), BatchNorm3dHip(cout))
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if shortcut_stride is not None:
+            self.downsample = nn.Sequential(Conv3dHip(cin, cout, 1, shortcut_stride, 0), BatchNorm3dHip(cout))
+
+    def forward(self, x):
+        return _BlockFn.apply(x, self)
+
+
+class VideoResNetHip(nn.Module):
+    """R3D-18 ('rgb') / r2d_18 ('flow') trunks on HIP kernels, returning the four stage maps (NDHWC bf16).
+    ref: torchvision r3d_18 == mmaction/models/backbones/r3d.py:176-184,216-296;
+         flow: mmaction/models/backbones/fastonly.py:185-193,238-326,399-408;
+         multi-level forward: mmaction/models/recognizers/moco.py:12-24.
+    Input: packed clip (N,T,H,W,8) bf16 from kernels.pack_input."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+        if kind == 'rgb':
+            base, kernel, pad = 64, (3, 3, 3), (1, 1, 1)
+            self.stem = nn.Sequential(Conv3dHip(3, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)), BatchNorm3dHip(64), nn.ReLU(inplace=True))
+            st = lambda s: (s, s, s)
+        elif kind == 'flow':
+            base, kernel, pad = 16, (1, 3, 3), (0, 1, 1)
+            self.stem = nn.Sequential(Conv3dHip(3, 16, (1, 7, 7), (2, 2, 2), (0, 3, 3)), BatchNorm3dHip(16), nn.ReLU(inplace=True))
+            st = lambda s: (1, s, s)
+        else:
+            raise ValueError(kind)
+        cin = base
+        for li, mult in enumerate((1, 2, 4, 8), start=1):
+            cout, s = base * mult, (1 if li == 1 else 2)
+            first = BasicBlockHip(cin, cout, kernel, st(s), pad, shortcut_stride=st(s) if (s != 1 or cin != cout) else None)
+            setattr(self, f'layer{li}', nn.Sequential(first, BasicBlockHip(cout, cout, kernel, 1, pad)))
+            cin = cout
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.fc = nn.Identity()           # base_moco.py:90-91,100-101 disables the classifier
+        self._anchor = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """ref: r3d.py:298-310 / fastonly.py:312-326: kaiming_normal(fan_out, relu) convs, BN 1/0."""
+        for m in self.modules():
+            if isinstance(m, Conv3dHip):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, BatchNorm3dHip):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        _need_gpu(x)
+        if self._anchor is None or self._anchor.device != x.device:
+            self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+        x = _StemFn.apply(x, self._anchor, self.stem)
+        outs = []
+        for li in range(1, 5):
+            for blk in getattr(self, f'layer{li}'):
+                x = blk(x)
+            outs.append(x)
+        return outs
+
+
+# ------------------------------------------------------------------------------------------ neck pieces
+class _ConvBiasFn(torch.autograd.Function):
+    """out = relu?(conv(x) + bias + addend)"""
+
+    @staticmethod
+    def forward(ctx, x, addend, conv, relu):
+        out = conv.fwd(x, addend=addend, relu=relu)
+        ctx.conv, ctx.relu, ctx.has_add = conv, relu, addend is not None
+        ctx.save_for_backward(x, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out = ctx.saved_tensors
+        dz = K.relu_bwd(dout.contiguous(), out) if ctx.relu else dout.contiguous()
+        ctx.conv.wgrad(x, dz)
+        dx = ctx.conv.dgrad(dz, x.shape) if ctx.needs_input_grad[0] else None
+        return dx, (dz if ctx.has_add else None), None, None
+
+
+def conv_bias(conv, x, addend=None, relu=False):
+    return _ConvBiasFn.apply(x, addend, conv, relu)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, size, trilinear):
+        dst = torch.empty((src.shape[0], *size, src.shape[-1]), dtype=torch.bfloat16, device=src.device)
+        K.upsample_add(src, dst, trilinear, accumulate=False)
+        ctx.src_shape, ctx.trilinear = tuple(src.shape), trilinear
+        return dst
+
+    @staticmethod
+    def backward(ctx, ddst):
+        return K.upsample_bwd(ddst.contiguous(), ctx.src_shape, ctx.trilinear), None, None
+
+
+def upsample(src, size, trilinear):
+    return _UpsampleFn.apply(src, tuple(size), trilinear)
+
+
+class _PoolFn(torch.autograd.Function):
+    """mean over the middle axis of (outer, inner, C) bf16 -> (outer, C) fp32"""
+
+    @staticmethod
+    def forward(ctx, x, outer, inner):
+        ctx.shape, ctx.outer, ctx.inner = tuple(x.shape), outer, inner
+        return K.pool_fwd(x, outer, inner)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return K.pool_bwd(dout.contiguous(), ctx.shape, ctx.outer, ctx.inner), None, None
+
+
+def pool(x, outer, inner):
+    return _PoolFn.apply(x, outer, inner)
+
+
+class _MlpHeadFn(torch.autograd.Function):
+    """q = normalize(Linear(ReLU(Linear(emb)))).  ref: recognizers/moco.py:367-372,528-529."""
+
+    @staticmethod
+    def forward(ctx, emb, mlp):
+        l1, l2 = mlp[0], mlp[2]
+        h = K.linear_fwd(emb, l1._rt['w'], l1._rt['b'], True)
+        z = K.linear_fwd(h, l2._rt['w'], l2._rt['b'], False)
+        q, norms = K.l2norm_fwd(z)
+        ctx.mlp = mlp
+        ctx.save_for_backward(emb, h, z, q, norms)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        emb, h, z, q, norms = ctx.saved_tensors
+        l1, l2 = ctx.mlp[0], ctx.mlp[2]
+        dz = K.l2norm_bwd(q, norms, dq.contiguous())
+        dh = K.linear_bwd(h, l2._rt['w'], z, dz, l2._rt['dw'], l2._rt['db'], False)
+        demb = K.linear_bwd(emb, l1._rt['w'], h, dh, l1._rt['dw'], l1._rt['db'], True)
+        for l in (l1, l2):
+            l._rt['slot_w'].touched = True
+            l._rt['slot_b'].touched = True
+        return demb, None
+
+
+def mlp_head(mlp, emb):
+    return _MlpHeadFn.apply(emb, mlp)
+
+
+class LinearHip(nn.Module):
+    """Parameter holder for nn.Linear (state-dict `weight` (out,in), `bias`)."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        self.in_features, self.out_features = in_f, out_f
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        self.bias = nn.Parameter(torch.empty(out_f))
+        nn.Linear.reset_parameters(self)
+        self._rt = None

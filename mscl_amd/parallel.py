@@ -1,0 +1,97 @@
+"""Data-parallel pieces: one process per GPU, torch.distributed (backend 'nccl' = RCCL over xGMI on ROCm;
+'gloo' in the CPU tests).  The path shards by samples; the exchange steps are
+  * shuffle-BN of key clips (recognizers/moco.py:146-191): all ranks derive the SAME permutation from a
+    counter-based seed (no rank-0 randperm + broadcast), gather the key clips and keep their slice;
+  * the negative-key all-gather before the queue write (moco.py:426), so every replica's queue stays
+    bit-identical;
+  * the gradient all-reduce of the flat fp32 arena, in a few large buckets sized for the 7-link xGMI mesh.
+All helpers are device-agnostic and are exercised on CPU tensors with 2-rank gloo in tests/.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+@torch.no_grad()
+def all_gather_cat(t):
+    """ref: recognizers/moco.py:558-568 (concat_all_gather); identity for a single replica."""
+    if world_size() == 1:
+        return t
+    t = t.contiguous()
+    out = torch.empty((world_size() * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t) if t.is_cuda else dist.all_gather(list(out.chunk(world_size())), t)
+    return out
+
+
+def shuffle_perm(n, step, slot, seed=20221):
+    """permutation of range(n) shared by all ranks: CPU generator seeded from (seed, step, slot)."""
+    g = torch.Generator().manual_seed(seed + 7919 * step + 104729 * slot)
+    return torch.randperm(n, generator=g)
+
+
+@torch.no_grad()
+def shuffle_select(x, step, slot):
+    """rows of the all-gathered batch this rank encodes with the key encoder (moco.py:146-172)."""
+    W = world_size()
+    if W == 1:
+        return x          # a within-batch permutation does not change per-GPU BN statistics
+    b = x.shape[0]
+    perm = shuffle_perm(W * b, step, slot)
+    idx = perm.view(W, b)[rank()].to(x.device)
+    return all_gather_cat(x).index_select(0, idx)
+
+
+@torch.no_grad()
+def unshuffle_select(k, step, slot):
+    """undo shuffle_select on the encoded keys (moco.py:174-191)."""
+    W = world_size()
+    if W == 1:
+        return k
+    b = k.shape[0]
+    inv = torch.argsort(shuffle_perm(W * b, step, slot))
+    idx = inv.view(W, b)[rank()].to(k.device)
+    return all_gather_cat(k).index_select(0, idx)
+
+
+def bucket_plan(total, bucket_elems):
+    """[(start, end)] covering [0, total) in buckets of at most bucket_elems (last one short)."""
+    out, a = [], 0
+    while a < total:
+        b = min(total, a + bucket_elems)
+        out.append((a, b))
+        a = b
+    return out
+
+
+@torch.no_grad()
+def allreduce_mean_(flat, bucket_elems=8 << 20):
+    """average a flat gradient buffer over the replicas, bucket by bucket (async, waited at the end).
+    149.8 MB of fp32 gradients -> 5 buckets of 32 MiB: large enough to run every xGMI link at rate,
+    small enough that the first bucket's reduction overlaps the rest being issued."""
+    W = world_size()
+    if W == 1:
+        return flat
+    works = []
+    for a, b in bucket_plan(flat.numel(), bucket_elems):
+        seg = flat[a:b]
+        if flat.is_cuda:
+            works.append(dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True))
+        else:
+            works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), seg))
+    for w in works:
+        if isinstance(w, tuple):
+            w[0].wait(); w[1].div_(W)
+        else:
+            w.wait()
+    return flat

@@ -1,0 +1,431 @@
+"""MoCoV2 and MSCLWithAug on the MI355X kernels, behind the reference's registry surface.
+
+ref: mmaction/models/recognizers/moco.py:324-547 (MoCoV2), recognizers/mscl.py:158-277 (MSCLWithAug),
+recognizers/base.py:274-308 (_parse_losses), recognizers/base_moco.py:77-106 (backbone dispatch).
+
+Step schedule (one data-parallel replica; equivalent to the reference's, re-ordered so that every
+queue snapshot is streamed exactly once forward and once backward -- SURVEY.md Appendix E-2/3):
+  1. pack clips NCTHW fp32 -> NDHWC bf16 (RGB normalised in the same pass)
+  2. RGB:  EMA(key enc) ; q = f_q(im_q) ; k = f_k(im_k)                     [no_grad for k]
+  3. flow base, then flow rotated: EMA ; q ; k   (EMA twice, separate BN statistics, App. E-5)
+  4. loss phase (one autograd node, gradients w.r.t. q / pooled maps computed eagerly):
+        pass A  queue_rgb (pre-enqueue):  rows q_rgb | q_flow_base | q_flow_rot  vs k_rgb
+        pass B  queue_flow (pre-enqueue): rows q_flow_base                      vs k_flow_base
+        enqueue flow keys (all-gathered), pass C queue_flow (post): q_flow_rot vs k_flow_rot,
+        q_rgb vs k_flow_base, q_rgb vs k_flow_rot ; enqueue rgb keys ; LMCL
+  5. backward through necks / trunks (fused block nodes), gradients accumulate in the flat arena.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels as K
+from . import parallel
+from .arena import ParamArena
+from .lib import MsclError
+from .nn import BatchNorm3dHip, Conv3dHip, LinearHip, VideoResNetHip, mlp_head, pool
+from .registry import RECOGNIZERS, build_head, build_neck, build_ssl_aug
+
+LOG_KEYS = ('top1_acc', 'top5_acc', 'loss_cls', 'top1_acc_flow', 'top5_acc_flow', 'loss_cls_flow', 'loss_cls_flow_aug',
+            'top1_acc_mx', 'top5_acc_mx', 'loss_cls_mx', 'top1_acc_mx_r', 'top5_acc_mx_r', 'loss_cls_mx_r',
+            'top1_acc_mx_aug', 'top5_acc_mx_aug', 'loss_cls_mx_aug', 'top1_acc_mx_r_aug', 'top5_acc_mx_r_aug',
+            'loss_cls_mx_r_aug', 'loss_pos', 'top1_acc_pos', 'top5_acc_pos', 'loss')
+
+
+def momentum_at(iters, max_iters, m_base):
+    """ref: moco.py:413-415."""
+    factor = min(iters / max_iters, 1)
+    return 1 - 0.5 * (1 - m_base) * (math.cos(math.pi * factor) + 1)
+
+
+def build_backbone_by_name(cfg):
+    """ref: base_moco.py:77-106: 'torchvision.<name>' and 'resnet_flow.<name>' bypass the registry."""
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    if typ == 'torchvision.r3d_18':
+        return VideoResNetHip('rgb', **cfg)
+    if typ == 'resnet_flow.r2d_18':
+        return VideoResNetHip('flow', **cfg)
+    raise NotImplementedError(f'backbone {typ} is outside the mscl_r18 hot path')
+
+
+@RECOGNIZERS.register_module()
+class MoCoV2(nn.Module):
+    def __init__(self, backbone, neck, moco_head, im_key='imgs', dim_in=512, dim=128, K=65536, m_base=0.994,
+                 t_decay=0.99999, max_iters=1, T=0.07, mlp=False, aux_info=[], aug=dict(type='IdentityAug'),
+                 train_cfg=None, test_cfg=None):
+        super().__init__()
+        if not mlp:
+            raise NotImplementedError('mlp=False projection is not used by the MSCL configs')
+        if abs(t_decay - 0.99999) > 0:
+            raise NotImplementedError('the reference hard-codes the queue age decay 0.99999 (moco.py:484)')
+        self.K, self.m_base, self.m, self.T = K, m_base, m_base, T
+        self.iters, self.max_iters, self.batch_size = 0, max_iters, 0
+        self.im_key, self.t_decay, self.aux_info = im_key, t_decay, aux_info
+        self.backbone_from = 'torchvision'
+        self.encoder_q = build_backbone_by_name(backbone)
+        self.encoder_k = build_backbone_by_name(backbone)
+        self.neck_q, self.neck_k = build_neck(neck), build_neck(neck)
+        self.moco_head = build_head(moco_head)
+        self.mlp_q = nn.Sequential(LinearHip(dim_in, dim_in), nn.ReLU(), LinearHip(dim_in, dim))
+        self.mlp_k = nn.Sequential(LinearHip(dim_in, dim_in), nn.ReLU(), LinearHip(dim_in, dim))
+        for pq, pk in self.qk_pairs():
+            pk.data.copy_(pq.data)
+            pk.requires_grad = False
+        self.register_buffer('queue', F.normalize(torch.randn(dim, K), dim=0))
+        self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long))
+        self.register_buffer('count', torch.zeros(K, dtype=torch.long))
+        self._weight = None
+        self.aug_gpu = build_ssl_aug(aug)
+        self._arena, self._range = None, None
+
+    def q_modules(self):
+        return (self.encoder_q, self.neck_q, self.mlp_q)
+
+    def k_modules(self):
+        return (self.encoder_k, self.neck_k, self.mlp_k)
+
+    def qk_pairs(self):
+        for mq, mk in zip(self.q_modules(), self.k_modules()):
+            yield from zip(mq.parameters(), mk.parameters())
+
+    @property
+    def weight(self):
+        raise MsclError('the aged queue snapshot is never materialised on the HIP path (it is streamed by the '
+                        'contrastive kernels); use queue / count')
+
+    @torch.no_grad()
+    def momentum_update(self, iters=None):
+        """ref: moco.py:408-421 -- one kernel over this recognizer's contiguous arena range."""
+        self.m = momentum_at(self.iters if iters is None else iters, self.max_iters, self.m_base)
+        a, b = self._range
+        ar = self._arena
+        K.ema_update(ar.KX[a:b], ar.Q[a:b], ar.Kb[a:b], self.m)
+        for fn in self._k_refresh:
+            fn()
+
+    def encode_q(self, x):
+        emb_maps, _ = self.neck_q(self.encoder_q(x))
+        emb, maps = emb_maps
+        return mlp_head(self.mlp_q, emb), maps
+
+    @torch.no_grad()
+    def encode_k(self, x):
+        emb_maps, _ = self.neck_k(self.encoder_k(x))
+        emb, maps = emb_maps
+        return mlp_head(self.mlp_k, emb), maps
+
+    @torch.no_grad()
+    def dequeue_and_enqueue(self, keys):
+        """ref: moco.py:423-440 (keys are all-gathered first; bookkeeping is bit-exact int64 on device)."""
+        keys = parallel.all_gather_cat(keys)
+        self.batch_size = keys.shape[0]
+        if self.K % self.batch_size != 0:
+            raise AssertionError('K % batch_size == 0 (moco.py:432)')
+        K.queue_enqueue(self.queue, self.count, self.queue_ptr, keys.contiguous())
+
+
+class _MSCLLossFn(torch.autograd.Function):
+    """Loss phase as ONE graph node: the 7 InfoNCE terms over 3 queue snapshots + LMCL."""
+
+    @staticmethod
+    def forward(ctx, q_rgb, q_fb, q_fa, p_rgb, p_fb, p_fa, k_rgb, k_fb, k_fa, model):
+        rec, recf = model.recognizer, model.recognizer_flow
+        B, dim = q_rgb.shape
+        inv_T, inv_Tx = 1.0 / rec.T, 1.0 / model.moco_mx_head.T
+        if abs(inv_T - inv_Tx) > 1e-12 or abs(inv_T - 1.0 / recf.T) > 1e-12:
+            raise NotImplementedError('all contrastive temperatures are equal in the MSCL configs (0.07)')
+        w_intra, w_inter = model.weight_aug_flow
+        use_aug_mx = w_inter > 0
+        if not model.same_kn:
+            raise NotImplementedError('same_kn=False is not used by the MSCL configs')
+        dev = q_rgb.device
+        ones = torch.full((B,), 1.0 / B, device=dev)
+
+        def run(queue_owner, Q, Kp, scale):
+            pos = K.rowdot(Q, Kp)
+            lse, loss_rows, rank = K.nce_forward(queue_owner.queue, queue_owner.count, Q, pos, inv_T)
+            dq = K.nce_backward(queue_owner.queue, queue_owner.count, Q, lse, scale, inv_T)
+            K.nce_pos_bwd(Kp, pos, lse, scale, dq, inv_T)
+            return loss_rows, rank, dq
+
+        # pass A: RGB queue before this step's enqueue (moco.py:484-488 snapshot; fr logits moco_head_v2.py:44,47)
+        rowsA = [q_rgb, q_fb] + ([q_fa] if use_aug_mx else [])
+        QA = torch.cat(rowsA, 0)
+        lossA, rankA, dA = run(rec, QA, k_rgb.repeat(len(rowsA), 1), ones.repeat(len(rowsA)))
+        # pass B: flow queue before enqueue -> loss_cls_flow
+        lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
+        recf.dequeue_and_enqueue(k_fb)                                   # base pass: update_queue=True (mscl.py:239)
+        # pass C: flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug
+        rowsC = [q_fa, q_rgb] + ([q_rgb] if use_aug_mx else [])
+        keysC = [k_fa, k_fb] + ([k_fa] if use_aug_mx else [])
+        scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
+        lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC)
+        if model.update_aug_flow:
+            recf.dequeue_and_enqueue(k_fa)
+        rec.dequeue_and_enqueue(k_rgb)
+        # LMCL (local_cl_head.py:57-73): RGB frame-slot features vs [base flow | rotated flow] frames
+        t = p_rgb.shape[0] // B
+        C = p_rgb.shape[1]
+        flow = torch.cat([p_fb.view(B, t, C), p_fa.view(B, t, C)], dim=1).contiguous()
+        lsum, hits, dpr, dpf = K.lmcl(p_rgb.view(B, t, C), flow, 1.0 / model.sup_head.T)
+
+        def grp(v, i):
+            return v[i * B:(i + 1) * B]
+        mean = lambda v: v.mean()
+        acc = lambda r, k: (r < k).float().mean()
+        e = OrderedDict()
+        e['top1_acc'], e['top5_acc'], e['loss_cls'] = acc(grp(rankA, 0), 1), acc(grp(rankA, 0), 5), mean(grp(lossA, 0))
+        e['top1_acc_flow'], e['top5_acc_flow'], e['loss_cls_flow'] = acc(rankB, 1), acc(rankB, 5), mean(lossB)
+        e['loss_cls_flow_aug'] = mean(grp(lossC, 0)) * w_intra
+        e['top1_acc_mx'], e['top5_acc_mx'], e['loss_cls_mx'] = acc(grp(rankC, 1), 1), acc(grp(rankC, 1), 5), mean(grp(lossC, 1))
+        e['top1_acc_mx_r'], e['top5_acc_mx_r'], e['loss_cls_mx_r'] = acc(grp(rankA, 1), 1), acc(grp(rankA, 1), 5), mean(grp(lossA, 1))
+        if use_aug_mx:
+            e['top1_acc_mx_aug'], e['top5_acc_mx_aug'], e['loss_cls_mx_aug'] = acc(grp(rankC, 2), 1), acc(grp(rankC, 2), 5), mean(grp(lossC, 2))
+            e['top1_acc_mx_r_aug'], e['top5_acc_mx_r_aug'], e['loss_cls_mx_r_aug'] = acc(grp(rankA, 2), 1), acc(grp(rankA, 2), 5), mean(grp(lossA, 2))
+        n_rows = float(B * t)
+        e['loss_pos'] = lsum[0] / n_rows
+        e['top1_acc_pos'], e['top5_acc_pos'] = hits[0].float() / n_rows, hits[1].float() / n_rows
+        total = sum(v for k_, v in e.items() if 'loss' in k_)            # base.py:297-298
+        e['loss'] = total
+        ctx.log_keys = tuple(e.keys())
+        logs = torch.stack([v.float() for v in e.values()])
+        # gradients w.r.t. the differentiable inputs (loss weights folded in by the row scales)
+        dq_rgb = grp(dA, 0) + grp(dC, 1) + (grp(dC, 2) if use_aug_mx else 0)
+        dq_fb = grp(dA, 1) + dB
+        dq_fa = grp(dC, 0) + (grp(dA, 2) if use_aug_mx else 0)
+        dpf = dpf.view(B, 2 * t, C)
+        ctx.save_for_backward(dq_rgb, dq_fb, dq_fa, dpr.view(B * t, C), dpf[:, :t].reshape(B * t, C),
+                              dpf[:, t:].reshape(B * t, C))
+        ctx.mark_non_differentiable(logs)
+        model._log_keys = ctx.log_keys
+        return total.clone(), logs
+
+    @staticmethod
+    def backward(ctx, g, _glogs):
+        grads = tuple(g * t for t in ctx.saved_tensors)
+        return grads + (None, None, None, None)
+
+
+@RECOGNIZERS.register_module()
+class MSCLWithAug(nn.Module):
+    def __init__(self, recognizer, recognizer_flow, moco_mx_head, sup_head, im_key='imgs', flow_key='flow_imgs',
+                 aux_info=[], aug=dict(type='SyncMoCoAugmentV5', crop_size=112, t=(8, 8)), same_kn=True,
+                 update_aug_flow=False, weight_aug_flow=(1.0, 1.0), train_cfg=None, test_cfg=None):
+        super().__init__()
+        from .registry import build_recognizer
+        self.recognizer = build_recognizer(recognizer)
+        self.recognizer_flow = build_recognizer(recognizer_flow)
+        self.im_key, self.same_kn = im_key, same_kn
+        self.update_aug_flow, self.weight_aug_flow = update_aug_flow, tuple(weight_aug_flow)
+        if isinstance(flow_key, (list, tuple)):
+            raise NotImplementedError('separate base/rotated flow keys (cat_flow=False) are not used by mscl_r18')
+        self.cat_flow, self.flow_key = True, (flow_key,)
+        self.aux_info = aux_info
+        self.moco_mx_head = build_head(moco_mx_head)
+        self.sup_head = build_head(sup_head)
+        self.aug_gpu = build_ssl_aug(aug)
+        self.arena = None
+        self._log_keys = LOG_KEYS
+        self._step = 0
+
+    # ------------------------------------------------------------------ device placement
+    def materialize(self, device='cuda'):
+        """Move buffers to `device`, re-home every parameter into the flat arenas and bind the kernels'
+        runtime views.  Must be called once before the first step; state_dict()/load_state_dict() keep
+        working afterwards (parameters are views into the arenas)."""
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise MsclError('materialize() needs a GPU device: the HIP path has no CPU fallback')
+        from .lib import load
+        load()
+        ar = ParamArena(device)
+        plan = []
+        for name, rec in (('rgb', self.recognizer), ('flow', self.recognizer_flow)):
+            ar.begin_group(name)
+            for mq, mk in zip(rec.q_modules(), rec.k_modules()):
+                for (nq, pq), (nk, pk) in zip(mq.named_parameters(), mk.named_parameters()):
+                    assert nq == nk and pq.shape == pk.shape
+                    plan.append((ar.add(nq, pq.shape), pq, pk))
+            ar.end_group(name)
+        ar.allocate()
+        for slot, pq, pk in plan:
+            vq, vk = ar.view('Q', slot), ar.view('KX', slot)
+            vq.copy_(pq.data.to(device)); vk.copy_(pk.data.to(device))
+            pq.data, pk.data = vq, vk
+            pq.grad = ar.view('G', slot)
+            pq._mscl_slot = pk._mscl_slot = slot
+        for mod in self.modules():
+            for bname, buf in list(mod._buffers.items()):
+                if buf is not None:
+                    mod._buffers[bname] = buf.to(device)
+        self.arena = ar
+        for name, rec in (('rgb', self.recognizer), ('flow', self.recognizer_flow)):
+            rec._arena, rec._range = ar, tuple(ar.ranges[name])
+            rec._k_refresh, rec._q_refresh = [], []
+            for mods, key in ((rec.q_modules(), False), (rec.k_modules(), True)):
+                for top in mods:
+                    for m in top.modules():
+                        self._bind(m, ar, key, rec)
+        self.sync_shadows()
+        return self
+
+    def _bind(self, m, ar, key, rec):
+        P, Pb = ('KX', 'Kb') if key else ('Q', 'Qb')
+        if isinstance(m, Conv3dHip):
+            sw = m.weight._mscl_slot
+            sb = m.bias._mscl_slot if m.bias is not None else None
+            rt = dict(slot_w=sw, slot_b=sb, bias=ar.view(P, sb) if sb is not None else None,
+                      dbias=None if key or sb is None else ar.view('G', sb), wT=None, dw=None)
+            dev = ar.device
+            if m.cin_eff == m.in_channels:
+                rt['w'] = ar.packed(Pb, sw)
+                if not key:
+                    rt['dw'] = ar.packed('G', sw)
+            else:       # 3-channel stems: zero-padded 8-channel shadow (and padded gradient staging)
+                w8 = torch.zeros((m.out_channels, *m.kernel_size, 8), dtype=torch.bfloat16, device=dev)
+                rt['w'] = w8
+                src = ar.packed(P, sw)
+
+                def refresh(w8=w8, src=src, cin=m.in_channels):
+                    w8[..., :cin].copy_(src)
+                (rec._k_refresh if key else rec._q_refresh).append(refresh)
+                if not key:
+                    dw8 = torch.zeros((m.out_channels, *m.kernel_size, 8), dtype=torch.float32, device=dev)
+                    rt['dw'] = dw8
+                    rt['dw8_flush'] = (dw8, ar.packed('G', sw), m.in_channels)
+            if not key and m.cin_eff == m.in_channels:
+                wT = torch.empty((m.in_channels, *m.kernel_size, m.out_channels), dtype=torch.bfloat16, device=dev)
+                rt['wT'] = wT
+
+                def refresh_t(w=rt['w'], wT=wT, co=m.out_channels, taps=m.taps, ci=m.in_channels):
+                    K.weight_transpose(w, wT, co, taps, ci)
+                rec._q_refresh.append(refresh_t)
+            m._rt = rt
+        elif isinstance(m, BatchNorm3dHip):
+            sg, sb = m.weight._mscl_slot, m.bias._mscl_slot
+            m._rt = dict(gamma=ar.view(P, sg), beta=ar.view(P, sb), slot_g=sg, slot_b=sb,
+                         dgamma=None if key else ar.view('G', sg), dbeta=None if key else ar.view('G', sb))
+        elif isinstance(m, LinearHip):
+            sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
+            m._rt = dict(w=ar.view(P, sw), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
+                         dw=None if key else ar.view('G', sw), db=None if key else ar.view('G', sb))
+
+    @torch.no_grad()
+    def sync_shadows(self):
+        """bf16 shadows / transposed kernels / padded stems from the fp32 masters (after load or fill)."""
+        ar = self.arena
+        K.cast_bf16(ar.Q, ar.Qb)
+        K.cast_bf16(ar.KX, ar.Kb)
+        for rec in (self.recognizer, self.recognizer_flow):
+            for fn in rec._q_refresh + rec._k_refresh:
+                fn()
+
+    @torch.no_grad()
+    def refresh_after_optimizer(self):
+        for rec in (self.recognizer, self.recognizer_flow):
+            for fn in rec._q_refresh:
+                fn()
+
+    @torch.no_grad()
+    def flush_padded_grads(self):
+        """fold the stems' 8-channel gradient staging buffers into the arena (3 real channels)."""
+        for rec in (self.recognizer, self.recognizer_flow):
+            conv = rec.encoder_q.stem[0]
+            dw8, gview, cin = conv._rt['dw8_flush']
+            gview.add_(dw8[..., :cin])
+            dw8.zero_()
+
+    def zero_grad(self, set_to_none=False):
+        if self.arena is not None:
+            self.arena.G.zero_()
+        else:
+            super().zero_grad(set_to_none)
+
+    # ------------------------------------------------------------------ step
+    def train_step(self, data_batch, optimizer=None, sync_logs=True, **kwargs):
+        """ref: mscl.py:192-212.  Returns dict(loss, log_vars, num_samples).  With sync_logs=False
+        `log_vars` holds 0-d device tensors (no host sync in the step), else Python floats."""
+        im_q, im_k = data_batch[self.im_key][0], data_batch[self.im_key][1]
+        aux = {}
+        for fk in self.flow_key:
+            aux[f'{fk}_q'], aux[f'{fk}_k'] = data_batch[fk][0], data_batch[fk][1]
+        for item in self.aux_info:
+            assert item in data_batch
+            aux[item] = data_batch[item]
+        loss, logs = self.forward_train(im_q, im_k, aux)
+        log_vars = self._parse_logs(logs, sync_logs)
+        return dict(loss=loss, log_vars=log_vars, num_samples=im_q.shape[0])
+
+    def forward(self, im_q, im_k, aux_info, return_loss=True, **kwargs):
+        if not return_loss:
+            raise NotImplementedError('MoCo doesnt support test mode')
+        return self.forward_train(im_q, im_k, aux_info)
+
+    def _parse_logs(self, logs, sync):
+        """ref: base.py:287-306, as ONE packed all-reduce instead of 23 scalar collectives."""
+        if parallel.world_size() > 1:
+            logs = logs.clone()
+            dist.all_reduce(logs)
+            logs = logs / parallel.world_size()
+        keys = self._log_keys
+        if sync:
+            vals = logs.tolist()
+            return OrderedDict(zip(keys, vals))
+        return OrderedDict((k, logs[i]) for i, k in enumerate(keys))
+
+    def forward_train(self, im_q, im_k, aux_info):
+        """ref: mscl.py:225-277."""
+        if self.arena is None:
+            raise MsclError('call model.materialize("cuda") before the first step')
+        rec, recf = self.recognizer, self.recognizer_flow
+        fk = self.flow_key[0]
+        flow_q, flow_k = aux_info[f'{fk}_q'], aux_info[f'{fk}_k']
+        T2 = flow_q.shape[2]
+        if T2 % 2:
+            raise ValueError('flow clips must hold base and rotated halves along T')
+        Th = T2 // 2
+        aug = self.aug_gpu
+        B = im_q.shape[0]
+        bg = B * parallel.world_size()
+        step = self._step
+        # -- RGB stream
+        x_q = aug.pack_rgb(im_q)
+        x_k = aug.pack_rgb(parallel.shuffle_select(im_k, step, 0))
+        rec.momentum_update()
+        q_rgb, maps_rgb = rec.encode_q(x_q)
+        k_rgb, _ = rec.encode_k(x_k)
+        k_rgb = parallel.unshuffle_select(k_rgb, step, 0)
+        # -- flow stream, base then rotated (two EMA updates, two BN-statistics passes; App. E-5)
+        iters0 = recf.iters
+        recf.momentum_update(iters0)
+        q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th))
+        k_fb, _ = recf.encode_k(aug.pack_flow(parallel.shuffle_select(flow_k, step, 1), 0, Th))
+        k_fb = parallel.unshuffle_select(k_fb, step, 1)
+        recf.momentum_update(iters0 + (bg if self.training else 0))
+        q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th))
+        k_fa, _ = recf.encode_k(aug.pack_flow(parallel.shuffle_select(flow_k, step, 2), Th, Th))
+        k_fa = parallel.unshuffle_select(k_fa, step, 2)
+        # -- LMCL inputs (local_cl_head.py:57-62): TPN level 0 of RGB, raw layer-4 maps of both flow passes
+        ids = self.sup_head.mlvl_ids
+        m_rgb, m_fb, m_fa = maps_rgb[ids[0]], maps_fb[ids[1]], maps_fa[ids[1]]
+        hw = lambda m: m.shape[2] * m.shape[3]
+        p_rgb = pool(m_rgb, m_rgb.shape[0] * m_rgb.shape[1], hw(m_rgb))
+        p_fb = pool(m_fb, m_fb.shape[0] * m_fb.shape[1], hw(m_fb))
+        p_fa = pool(m_fa, m_fa.shape[0] * m_fa.shape[1], hw(m_fa))
+        if m_rgb.shape[1] != m_fb.shape[1] or m_rgb.shape[1] != self.sup_head.t:
+            raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {m_fb.shape[1]}, head t={self.sup_head.t}')
+        self._dbg = dict(q_rgb=q_rgb.detach(), q_fb=q_fb.detach(), q_fa=q_fa.detach(), k_rgb=k_rgb, k_fb=k_fb, k_fa=k_fa)
+        loss, logs = _MSCLLossFn.apply(q_rgb, q_fb, q_fa, p_rgb, p_fb, p_fa, k_rgb, k_fb, k_fa, self)
+        if self.training:                       # moco.py:504-505; the flow recognizer ran twice
+            rec.iters += rec.batch_size
+            recf.iters += 2 * recf.batch_size
+        self._step += 1
+        return loss, logs
+
+    def forward_test(self, imgs):
+        raise NotImplementedError('Not support for ssl recognizer !!!')

@@ -253,6 +253,14 @@ def test_nce(R, K, dev):
     gq, = torch.autograd.grad(neg_only, q)
     dq = K_.nce_backward(queue.to(dev), count.to(dev), q.detach().to(dev), lse, scale.to(dev), 1.0 / T)
     close(dq, gq, 1e-4, 'nce dq')
+    # full gradient incl. the positive key: d/dq of sum_r scale_r * CE_r with k_pos held constant
+    posd = K_.rowdot(q.detach().to(dev), kpos.to(dev))
+    close(posd, pos, 1e-5, 'rowdot')
+    full = (F.cross_entropy(torch.cat([(q * kpos).sum(1, keepdim=True), q @ w], 1) / T,
+                            torch.zeros(R, dtype=torch.long), reduction='none') * scale).sum()
+    gfull, = torch.autograd.grad(full, q)
+    K_.nce_pos_bwd(kpos.to(dev), posd, lse, scale.to(dev), dq, 1.0 / T)
+    close(dq, gfull, 1e-4, 'nce dq incl. positive')
 
 
 def test_enqueue_bit_exact(dev):

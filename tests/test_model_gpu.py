@@ -1,0 +1,148 @@
+"""Step-level parity on the GPU: the HIP model against (a) the golden vectors captured from the reference's
+own Python (tests/golden, tools/oracle/make_golden.py) and (b) the oracle/ restatement run on the host CPU.
+
+The HIP path computes convolutions in bf16 with fp32 accumulation (fp32 masters, fp32 BN statistics,
+fp32 contrastive / optimizer math); the reference is fp32 end to end.  Stated tolerances:
+  losses            |d| <= 0.02 * max(1, |ref|) + 0.03
+  features q, k     cosine >= 0.995 per row
+  gradients         global norm within 8 %, per-tensor cosine >= 0.95 for tensors carrying >= 1 % of the norm
+  integer state     bit-exact (queue_ptr, count, iters, batch_size)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def build(num_frames, K, dev):
+    import mscl_amd
+    from mscl_amd import Config, build_model
+    from mscl_amd.fill import fill_module
+    cfg = Config.fromfile(os.path.join(os.path.dirname(GOLD), '..', 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    cfg.model.sup_head.t = num_frames // 2
+    cfg.model.recognizer.K = K
+    cfg.model.recognizer_flow.K = K
+    torch.manual_seed(0)
+    m = build_model(cfg.model)
+    fill_module(m)
+    m.materialize(dev)
+    m.train()
+    return m, cfg
+
+
+def loss_close(got, ref, what):
+    assert abs(got - ref) <= 0.02 * max(1.0, abs(ref)) + 0.03, f'{what}: hip {got} vs ref {ref}'
+
+
+def test_step_vs_golden_and_oracle(dev):
+    from mscl_amd import ClipSGD
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    g = np.load(os.path.join(GOLD, 'step_b2_t8_h112.npz'))
+    meta = json.loads(str(g['meta']))
+    B, T, H, Kq = meta['B'], meta['T'], meta['H'], meta['K']
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
+    oopt = om.SGDClip(orc.parameters())
+    keys = [str(k) for k in g['log_keys']]
+    for s in range(2):
+        batch = synthetic_batch(B, T, H, H, 0, s)
+        out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
+        assert list(out['log_vars'].keys()) == keys
+        gold = dict(zip(keys, g[f's{s}_log_vals']))
+        if s == 0:          # later steps diverge chaotically even between fp32 implementations; step 0 is pinned
+            for k in keys:
+                if 'loss' in k:
+                    loss_close(out['log_vars'][k], gold[k], f'step{s} {k}')
+        opt.zero_grad()
+        out['loss'].backward()
+        torch.manual_seed(100 + s)
+        oo = orc.train_step(batch); oopt.zero_grad(); oo['loss'].backward()
+        if s == 0:
+            for k in keys:
+                if 'loss' in k:
+                    loss_close(out['log_vars'][k], oo['log_vars'][k], f'oracle step{s} {k}')
+            cos = torch.nn.functional.cosine_similarity
+            for nm, a, b in (('q_rgb', model._dbg['q_rgb'], orc._features['img']['q']),
+                             ('k_rgb', model._dbg['k_rgb'], orc._features['img']['k']),
+                             ('q_flow', model._dbg['q_fb'], orc._features['base']['q']),
+                             ('q_flow_aug', model._dbg['q_fa'], orc._features['aug']['q'])):
+                c = cos(a.float().cpu(), b.detach(), dim=1).min().item()
+                assert c >= 0.995, f'{nm} cosine {c}'
+            # gradients
+            model.flush_padded_grads()
+            tot_h, tot_o, bad = 0.0, 0.0, []
+            gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
+            for (n, p), (n2, q) in zip(model.named_parameters(), orc.named_parameters()):
+                assert n == n2
+                if not p.requires_grad:
+                    continue
+                gh = p.grad.detach().float().cpu()
+                if q.grad is None:
+                    assert float(gh.abs().max()) == 0.0, f'{n} must receive no gradient'
+                    continue
+                go = q.grad
+                tot_h += float((gh.double() ** 2).sum()); tot_o += float((go.double() ** 2).sum())
+                if float(go.norm()) >= 0.01 * gn_o:
+                    c = float(cos(gh.flatten(), go.flatten(), dim=0))
+                    if c < 0.95:
+                        bad.append((n, c))
+            assert not bad, bad
+            assert abs(tot_h ** 0.5 - tot_o ** 0.5) <= 0.08 * tot_o ** 0.5, (tot_h ** 0.5, tot_o ** 0.5)
+            loss_close(tot_o ** 0.5 / 100, float(g['s0_grad_norm']) / 100, 'golden grad norm (oracle)')
+        opt.step(); oopt.step()
+        # integer bookkeeping: bit-exact against the reference's goldens
+        for nm, rec in (('rgb', model.recognizer), ('flow', model.recognizer_flow)):
+            assert int(rec.queue_ptr) == int(g[f's{s}_{nm}_ptr'])
+            assert rec.iters == int(g[f's{s}_{nm}_iters']) and rec.batch_size == int(g[f's{s}_{nm}_bs'])
+            assert abs(rec.m - float(g[f's{s}_{nm}_m'])) < 1e-12
+            vals, cnts = np.unique(rec.count.cpu().numpy(), return_counts=True)
+            assert np.array_equal(np.stack([vals, cnts]), g[f's{s}_{nm}_count_hist'])
+
+
+def test_bookkeeping_40_steps_small_queue(dev):
+    """K=64 wraps after 32 steps of 2 keys: queue_ptr / count / iters / m bit-exact vs the reference goldens."""
+    from mscl_amd import ClipSGD
+    from mscl_amd.synthetic import synthetic_batch
+    g = np.load(os.path.join(GOLD, 'book_b2_t8_h32_k64.npz'))
+    meta = json.loads(str(g['meta']))
+    B, T, H, Kq, n = meta['B'], meta['T'], meta['H'], meta['K'], meta['n_steps']
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    for s in range(n):
+        batch = synthetic_batch(B, T, H, H, 0, s, device=dev)
+        out = model.train_step(batch, sync_logs=False)
+        opt.zero_grad(); out['loss'].backward(); opt.step()
+        for nm, rec in (('rgb', model.recognizer), ('flow', model.recognizer_flow)):
+            assert int(rec.queue_ptr) == int(g[f's{s}_{nm}_ptr']), (s, nm)
+            assert np.array_equal(rec.count.cpu().numpy(), g[f's{s}_{nm}_count']), (s, nm)
+            assert rec.iters == int(g[f's{s}_{nm}_iters']) and rec.batch_size == int(g[f's{s}_{nm}_bs'])
+            assert abs(rec.m - float(g[f's{s}_{nm}_m'])) < 1e-12
+    assert torch.isfinite(out['loss']).item()
+    # the one tensor pair the reference never trains: untouched by SGD incl. weight decay
+    from mscl_amd.fill import fill_value
+    p = dict(model.named_parameters())['recognizer.neck_q.tpn.sepc.Pconvs.1.Pconv.2.weight']
+    want = torch.from_numpy(fill_value('recognizer.neck_q.tpn.sepc.Pconvs.1.Pconv.2.weight', tuple(p.shape))).float()
+    assert torch.equal(p.detach().cpu(), want)
+
+
+def test_state_dict_roundtrip(dev):
+    model, _ = build(8, 64, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    man = json.load(open(os.path.join(GOLD, 'state_dict_manifest.json')))
+    assert [m[0] for m in man] == list(sd.keys())
+    model2, _ = build(8, 64, dev)
+    with torch.no_grad():
+        for p in model2.parameters():
+            p.zero_()
+    model2.load_state_dict(sd)
+    model2.sync_shadows()
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+    assert torch.equal(model.arena.Qb, model2.arena.Qb) and torch.equal(model.arena.Kb, model2.arena.Kb)
