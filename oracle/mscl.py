@@ -56,7 +56,7 @@ def cross_entropy(logits, labels, ignore_index=-1, loss_weight=1.0):
 def ce_with_topk(logits, labels, suffix):
     """ref: heads/moco_head.py:38-77 == heads/moco_head_v2.py:55-94: top-1/top-5 then CE."""
     out = OrderedDict()
-    acc = top_k_accuracy(logits.detach().cpu().numpy(), labels.detach().cpu().numpy(), (1, 5))
+    acc = top_k_accuracy(logits.detach().float().cpu().numpy(), labels.detach().cpu().numpy(), (1, 5))
     out[f'top1_acc{suffix}'] = torch.tensor(acc[0], device=logits.device)
     out[f'top5_acc{suffix}'] = torch.tensor(acc[1], device=logits.device)
     out[f'loss_cls{suffix}'] = cross_entropy(logits, labels)
@@ -237,7 +237,7 @@ class MSCLWithAug(nn.Module):
             losses.update(ce_with_topk(fr, lab, '_mx_r_aug'))
         scores, labels = lmcl_scores(f_img['q_mlvl'][0], f_base['q_mlvl'][-1], f_aug['q_mlvl'][-1], self.T)
         losses['loss_pos'] = cross_entropy(scores, labels)
-        acc = top_k_accuracy(scores.detach().cpu().numpy(), labels.cpu().numpy(), (1, 5))
+        acc = top_k_accuracy(scores.detach().float().cpu().numpy(), labels.cpu().numpy(), (1, 5))
         losses['top1_acc_pos'] = torch.tensor(acc[0], device=scores.device)
         losses['top5_acc_pos'] = torch.tensor(acc[1], device=scores.device)
         self._features = dict(img=f_img, base=f_base, aug=f_aug)

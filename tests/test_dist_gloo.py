@@ -1,0 +1,67 @@
+"""world_size-2 gloo tests on CPU for the data-parallel exchange steps: shuffle-BN
+select/unselect, key all-gather + replicated queue write, gradient averaging."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mscl_amd import parallel
+        from oracle import mscl as om
+        torch.manual_seed(7 + rank)
+        b = 4
+        x = torch.arange(b, dtype=torch.float32).view(b, 1) + 100 * rank           # sample ids
+        # shuffle: every sample lands on exactly one rank, unshuffle restores the owner's order
+        xs = parallel.shuffle_select(x, step=5, slot=0)
+        allx = parallel.all_gather_cat(xs)
+        assert sorted(allx.flatten().tolist()) == sorted((torch.arange(b).repeat(world) + 100 * torch.arange(world).repeat_interleave(b)).tolist())
+        k = xs * 2.0                                                              # "encode"
+        ku = parallel.unshuffle_select(k, step=5, slot=0)
+        assert torch.equal(ku, x * 2.0)
+        # gradient averaging over buckets
+        g = torch.full((1000,), float(rank + 1))
+        parallel.allreduce_mean_(g, bucket_elems=300)
+        assert torch.allclose(g, torch.full((1000,), (1 + world) * world / 2 / world))
+        # replicated queue: the oracle's enqueue under 2 ranks keeps queue/ptr/count identical everywhere
+        rec = om.MoCoV2('flow', 128, K=16, max_iters=100)
+        with torch.no_grad():
+            rec.queue.copy_(torch.zeros_like(rec.queue))
+        keys = torch.nn.functional.normalize(torch.randn(b, 128), dim=1)
+        rec.dequeue_and_enqueue(keys)
+        gathered = parallel.all_gather_cat(keys)
+        assert torch.equal(rec.queue[:, :world * b], gathered.T) and int(rec.queue_ptr) == world * b
+        assert rec.batch_size == world * b and torch.equal(rec.count[:world * b], torch.ones(world * b, dtype=torch.long))
+        state = torch.cat([rec.queue.flatten(), rec.count.float(), rec.queue_ptr.float()])
+        states = parallel.all_gather_cat(state[None])
+        assert torch.equal(states[0], states[1])
+        q.put((rank, 'ok'))
+    except Exception as e:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in res:
+        assert msg == 'ok', f'rank {r}: {msg}'

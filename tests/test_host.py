@@ -1,0 +1,125 @@
+"""Host logic that needs no GPU: registry / config surface, state-dict compatibility, C-ABI exports,
+loud failure without a GPU, fill determinism, distributed helpers' pure logic."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import mscl_amd
+from mscl_amd import Config, build_model
+from mscl_amd.lib import MsclError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+CFG = os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py')
+
+
+def test_config_equals_reference_dicts():
+    cfg = Config.fromfile(CFG)
+    ref = json.load(open(os.path.join(GOLD, 'ref_config.json')))
+    norm = lambda x: {k: norm(v) for k, v in x.items()} if isinstance(x, dict) else ([norm(v) for v in x] if isinstance(x, (list, tuple)) else x)
+    for k in ('model', 'optimizer', 'optimizer_config', 'lr_config', 'total_epochs', 'dataset_size', 'num_frames', 'find_unused_parameters'):
+        assert norm(cfg[k]) == norm(ref[k]), k
+    assert cfg.dist_params.backend == 'nccl' and cfg.model.recognizer.K == 65536      # _base_ merge + attribute access
+
+
+def test_registry_surface():
+    from mscl_amd.registry import BACKBONES, HEADS, LOSSES, MODELS, NECKS, RECOGNIZERS, SSL_AUGS
+    assert BACKBONES is NECKS is HEADS is RECOGNIZERS is LOSSES is MODELS          # builder.py:9-15
+    for n in ('MSCLWithAug', 'MoCoV2', 'TPNMoCo', 'BaseMoCo', 'MoCoHead', 'MSCLWithAugMxHead', 'MSCLWithAugPosHeadV2', 'CrossEntropyLoss_torch'):
+        assert n in MODELS, n
+    for n in ('SyncMoCoAugmentV5', 'IdentityAug'):
+        assert n in SSL_AUGS, n
+    with pytest.raises(KeyError):
+        MODELS.build(dict(type='NoSuchModel'))
+    with pytest.raises(ValueError):
+        build_model(dict(type='NoSuchRecognizer'))                               # builder.py:85-87
+    with pytest.raises(KeyError):
+        MODELS.register_module(name='MoCoV2', module=type('X', (), {}))
+
+
+@pytest.fixture(scope='module')
+def model():
+    return build_model(Config.fromfile(CFG).model)
+
+
+def test_state_dict_matches_reference_manifest(model):
+    man = json.load(open(os.path.join(GOLD, 'state_dict_manifest.json')))
+    sd = model.state_dict()
+    assert len(sd) == 551 and [m[0] for m in man] == list(sd.keys())
+    for (n, t), (_, shape, dtype) in zip(sd.items(), man):
+        assert list(t.shape) == shape and str(t.dtype) == dtype, n
+    assert sum(p.numel() for p in model.parameters()) == 74885024
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 37442512
+
+
+def test_no_cpu_fallback(model):
+    from mscl_amd.synthetic import synthetic_batch
+    with pytest.raises(MsclError):
+        model.train_step(synthetic_batch(2, 8, 32, 32))           # not materialized
+    with pytest.raises(MsclError):
+        model.materialize('cpu')
+    from mscl_amd import kernels
+    with pytest.raises(MsclError):
+        kernels.add_relu(torch.zeros(8, dtype=torch.bfloat16))       # CPU tensor refused
+
+
+def test_product_never_imports_oracle():
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for dp, _, files in os.walk(os.path.join(ROOT, 'mscl_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                assert not pat.search(open(os.path.join(dp, f)).read()), f
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from mscl_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    handle = lib.load()
+    header = open(os.path.join(ROOT, 'include', 'mscl_hip.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(mscl_\w+)\s*\(', header, re.M))
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    for n in declared:
+        assert hasattr(handle, n), n
+    assert handle.mscl_abi_version() == 1
+    # argument validation happens before any device work: callable without a GPU
+    assert handle.mscl_sumsq(None, None, 0, None) == -1
+
+
+def test_fill_is_deterministic_and_q_k_twins_equal(model):
+    from mscl_amd.fill import fill_module, fill_value
+    import numpy as np
+    fill_module(model)
+    sd = model.state_dict()
+    a, b = sd['recognizer.encoder_q.layer3.0.conv1.0.weight'], sd['recognizer.encoder_k.layer3.0.conv1.0.weight']
+    assert torch.equal(a, b)
+    v = fill_value('recognizer.queue', (128, 65536))
+    assert np.allclose((v * v).sum(0), 1.0)
+    assert float(a.std()) == pytest.approx((2.0 / (256 * 27)) ** 0.5, rel=0.02)
+
+
+def test_arena_layout_logic():
+    from mscl_amd.arena import ParamArena, ALIGN
+    ar = ParamArena('cpu')
+    s1 = ar.add('a', (4, 3, 1, 2, 2)); s2 = ar.add('b', (5,)); s3 = ar.add('c', (7,))
+    assert s2.off % ALIGN == 0 and s3.off % ALIGN == 0
+    ar.allocate()
+    v = ar.view('Q', s1)
+    assert tuple(v.shape) == (4, 3, 1, 2, 2) and v.permute(0, 2, 3, 4, 1).is_contiguous()     # [Cout][kT][kH][kW][Cin]
+    s1.touched = s3.touched = True
+    assert ar.active_ranges() == [(0, ALIGN), (2 * ALIGN, 3 * ALIGN)]
+    s2.touched = True
+    assert ar.active_ranges() == [(0, 3 * ALIGN)]
+
+
+def test_shuffle_perm_is_shared_and_invertible():
+    from mscl_amd.parallel import bucket_plan, shuffle_perm
+    p1, p2 = shuffle_perm(16, 3, 1), shuffle_perm(16, 3, 1)
+    assert torch.equal(p1, p2) and sorted(p1.tolist()) == list(range(16))
+    assert not torch.equal(p1, shuffle_perm(16, 4, 1))
+    assert bucket_plan(10, 4) == [(0, 4), (4, 8), (8, 10)]

@@ -1,0 +1,87 @@
+"""The oracle (CPU restatement) against the golden vectors captured from the reference's own Python
+(tools/oracle/make_golden.py) and against the only known-answer vectors the reference's tests hold for
+this path (top_k_accuracy, reference tests/test_metrics/test_accuracy.py:118-163)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from mscl_amd.synthetic import synthetic_batch
+from oracle import fill, mscl as om
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _run(tag, max_steps):
+    g = np.load(os.path.join(GOLD, f'{tag}.npz'))
+    meta = json.loads(str(g['meta']))
+    B, T, H, K = meta['B'], meta['T'], meta['H'], meta['K']
+    orc = om.MSCLWithAug(num_frames=T, K=K)
+    fill.fill_module(orc)
+    orc.train()
+    opt = om.SGDClip(orc.parameters())
+    keys = [str(k) for k in g['log_keys']]
+    names = [str(n) for n in g['param_names']]
+    for s in range(min(max_steps, meta['n_steps'])):
+        batch = synthetic_batch(B, T, H, H, 0, s)
+        torch.manual_seed(100 + s)
+        out = orc.train_step(batch)
+        assert list(out['log_vars'].keys()) == keys
+        tol = 1e-6 if s == 0 else 2e-3
+        for k, ref in zip(keys, g[f's{s}_log_vals']):
+            assert abs(out['log_vars'][k] - ref) <= tol * max(1.0, abs(ref)), (tag, s, k, out['log_vars'][k], ref)
+        opt.zero_grad()
+        out['loss'].backward()
+        grads = dict(orc.named_parameters())
+        for n, ref in zip(names, g[f's{s}_grad_l2']):
+            gr = grads[n].grad
+            if ref < 0:
+                assert gr is None, n
+            else:
+                assert abs(float(gr.double().norm()) - ref) <= (1e-5 if s == 0 else 2e-2) * max(ref, 1e-6), (n, s)
+        gn = opt.step()
+        assert abs(gn - float(g[f's{s}_grad_norm'])) <= (1e-5 if s == 0 else 1e-2) * gn
+        for nm, rec in (('rgb', orc.recognizer), ('flow', orc.recognizer_flow)):
+            assert int(rec.queue_ptr) == int(g[f's{s}_{nm}_ptr'])
+            assert rec.iters == int(g[f's{s}_{nm}_iters']) and rec.batch_size == int(g[f's{s}_{nm}_bs'])
+            assert rec.m == float(g[f's{s}_{nm}_m'])
+            if f's{s}_{nm}_count' in g:
+                assert np.array_equal(rec.count.numpy(), g[f's{s}_{nm}_count'])
+    return g
+
+
+def test_oracle_matches_reference_small_queue_bookkeeping():
+    _run('book_b2_t8_h32_k64', 40)
+
+
+def test_oracle_matches_reference_step_t8():
+    _run('step_b2_t8_h112', 1)
+
+
+def test_log_keys_are_the_23_reference_keys():
+    g = np.load(os.path.join(GOLD, 'step_b2_t8_h112.npz'))
+    from mscl_amd.recognizers import LOG_KEYS
+    assert tuple(str(k) for k in g['log_keys']) == LOG_KEYS and len(LOG_KEYS) == 23
+
+
+def test_top_k_known_answers():
+    # data of reference tests/test_metrics/test_accuracy.py:118-163
+    scores = [np.array([-0.2203, -0.7538, 1.8789, 0.4451, -0.2526]), np.array([-0.0413, 0.6366, 1.1155, 0.3484, 0.0395]),
+              np.array([0.0365, 0.5158, 1.1067, -0.9276, -0.2124]), np.array([0.6232, 0.9912, -0.8562, 0.0148, 1.6413])]
+    cases = [((1,), [0, 2, 0, 3], [0.25]), ((2,), [0, 2, 0, 3], [0.25]), ((1,), [0, 1, 2, 3], [0.25]),
+             ((1, 2), [0, 1, 2, 3], [0.25, 0.5]), ((1, 2, 3), [0, 1, 2, 3], [0.25, 0.5, 0.75]),
+             ((1, 2, 3, 4), [0, 1, 2, 3], [0.25, 0.5, 0.75, 1.0])]
+    for topk, labels, want in cases:
+        assert om.top_k_accuracy(scores, labels, topk) == want
+        # the product's rank-count form agrees (no ties in this table)
+        from mscl_amd.heads import logits_topk
+        got = logits_topk(torch.tensor(np.stack(scores)), torch.tensor(labels), topk)
+        assert [float(v) for v in got] == want
+
+
+def test_momentum_schedule_closed_form():
+    from mscl_amd.recognizers import momentum_at
+    for it in (0, 1, 10 ** 6, 219136 * 400, 10 ** 9):
+        assert momentum_at(it, 219136 * 400, 0.994) == om.momentum_at(it, 219136 * 400, 0.994)
+    assert om.momentum_at(0, 100, 0.994) == 0.994 and abs(om.momentum_at(100, 100, 0.994) - 1.0) < 1e-15
