@@ -39,12 +39,15 @@ int mscl_abi_version(void);
  * the BatchNorm batch statistics of r3d.py:103-127 fused into the producer. */
 int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w_bf16, uint16_t* y,
                     const float* bias, const uint16_t* addend, int relu,
-                    float* stat_sum, float* stat_sq, void* stream);
+                    float* stat_sum, float* stat_sq, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
+/* splitk_ws: optional fp32 scratch of splitk_ws_floats floats; when it holds >= 2 copies of the output and
+ * the layer has too few position tiles to fill 256 CUs, the K loop is split over the grid (one fp32 slab
+ * per split, then a summing finalize pass that also applies the epilogue and the BN statistics). */
 
 /* dx = conv_transpose(dy, w) [+ addend]; wT_bf16 is the kernel re-laid out [Cin][kT][kH][kW][Cout]
  * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient. */
 int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT_bf16, uint16_t* dx,
-                      const uint16_t* addend, void* stream);
+                      const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
 
 /* dw[Cout][taps][Cin] (fp32) += sum over positions of dy (x) x ; atomically accumulated, so the
  * caller zeroes dw once per step and repeated traversals of a shared trunk simply add up
@@ -55,6 +58,10 @@ int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
 
 /* [Cout][taps][Cin] bf16 -> [Cin][taps][Cout] bf16 */
 int mscl_weight_transpose(const uint16_t* w, uint16_t* wT, int Cout, int taps, int Cin, void* stream);
+/* the same for every conv kernel of a model in ONE launch: `table` is a device array of n entries
+ * {const uint16_t* w; uint16_t* wT; int32 Cout, taps, Cin, first_block;} (32 bytes each), entry i owning
+ * blocks [first_block_i, first_block_{i+1}) of 256 elements; total_blocks = sum of ceil(elems_i / 256). */
+int mscl_weight_transpose_batched(const void* table, int n, int total_blocks, void* stream);
 
 /* ---- BatchNorm3d (training mode) + ReLU + residual -------------------------------------------
  * replaces nn.BatchNorm3d/ReLU/`out += residual` in r3d.py:95-127, fastonly.py:104-136.

@@ -51,6 +51,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// exact floor(n / d) for 0 <= n < 2^31 via one 32x32->64 multiply (Granlund-Montgomery round-up method)
+struct FastDiv { uint32_t magic; int shift; };
+static inline FastDiv make_fastdiv(int d) {
+  int L = 0; while ((1 << L) < d) ++L;
+  FastDiv f; f.shift = 31 + L;
+  f.magic = (uint32_t)((((uint64_t)1) << f.shift) / (uint64_t)d + 1);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((uint64_t)(uint32_t)n * f.magic) >> f.shift); }
+
 #define MSCL_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 static inline int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -5,110 +5,125 @@
 // (dim, K) buffer; query rows are wave-uniform and come through the scalar cache.
 #include "common.h"
 
-#define NCE_COLS 128          // queue columns per block (threads per block)
+#define NCE_COLS 64           // queue columns per block; 4 waves split the feature dimension
+#define NCE_WAVES 4
 
+// Each block owns 64 queue columns; wave w accumulates channels [w*dim/4, (w+1)*dim/4) of the dot products
+// (4x the loads in flight of a column-per-thread loop: the pass is latency-bound otherwise), partials are
+// summed through LDS.  lg[r] = logit of (row r, this lane's column) is returned to wave 0's lanes.
 template <int RT>
-__device__ __forceinline__ void nce_logits(const float* __restrict__ queue, const int64_t* __restrict__ count,
-                                           const float* __restrict__ q, int k, int R, int dim, int K, float inv_T,
-                                           float* lg, float& decay) {
+__device__ __forceinline__ void nce_partial(const float* __restrict__ queue, const float* __restrict__ q, int k, int R, int dim,
+                                            int K, int wave, float* acc) {
+  const int cq = dim / NCE_WAVES, c0 = wave * cq;
 #pragma unroll
-  for (int r = 0; r < RT; ++r) lg[r] = 0.f;
-  for (int c = 0; c < dim; ++c) {
+  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int c = c0; c < c0 + cq; ++c) {
     const float w = queue[(long)c * K + k];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) lg[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, lg[r]);
+    for (int r = 0; r < RT; ++r) acc[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, acc[r]);
   }
-  decay = powf(0.99999f, (float)count[k]);      // recognizers/moco.py:484: 0.99999 ** (1.0 * count)
-#pragma unroll
-  for (int r = 0; r < RT; ++r) lg[r] = lg[r] * decay * inv_T;
 }
 
 // part[(blk*R + r)*3 + {0: max, 1: sum exp(l - max), 2: #(l > pos)}]
 template <int RT>
-__global__ __launch_bounds__(NCE_COLS) void nce_fwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
-                                                           const float* __restrict__ q, const float* __restrict__ pos,
-                                                           float* __restrict__ part, int R, int dim, int K, float inv_T) {
-  __shared__ float red[2][RT * 3];
-  const int k = blockIdx.x * NCE_COLS + threadIdx.x;
+__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                      const float* __restrict__ q, const float* __restrict__ pos,
+                                                      float* __restrict__ part, int R, int dim, int K, float inv_T) {
+  __shared__ float red[NCE_WAVES][RT][NCE_COLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float lg[RT], decay;
-  nce_logits<RT>(queue, count, q, k < K ? k : K - 1, R, dim, K, inv_T, lg, decay);
+  const int k = blockIdx.x * NCE_COLS + lane;
   const bool live = k < K;
+  float acc[RT];
+  nce_partial<RT>(queue, q, live ? k : K - 1, R, dim, K, wave, acc);
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    const float l = live ? lg[r] : -INFINITY;
+  for (int r = 0; r < RT; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes rows r = w, w+4, ...
+  const float decay = powf(0.99999f, (float)count[live ? k : K - 1]);      // recognizers/moco.py:484
+  for (int r = wave; r < R; r += NCE_WAVES) {
+    const float dot = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    const float l = live ? dot * decay * inv_T : -INFINITY;
     const float m = wave_max(l);
     const float s = wave_sum(live ? __expf(l - m) : 0.f);
-    const float c = wave_sum((live && r < R && l > pos[r < R ? r : 0] * inv_T) ? 1.f : 0.f);
-    if (lane == 0) { red[wave][r * 3] = m; red[wave][r * 3 + 1] = s; red[wave][r * 3 + 2] = c; }
-  }
-  __syncthreads();
-  for (int r = threadIdx.x; r < R; r += NCE_COLS) {
-    const float m0 = red[0][r * 3], m1 = red[1][r * 3];
-    const float m = fmaxf(m0, m1);
-    const float s = red[0][r * 3 + 1] * __expf(m0 - m) + red[1][r * 3 + 1] * __expf(m1 - m);
-    float* o = part + ((long)blockIdx.x * R + r) * 3;
-    o[0] = m; o[1] = s; o[2] = red[0][r * 3 + 2] + red[1][r * 3 + 2];
+    const float c = wave_sum((live && l > pos[r] * inv_T) ? 1.f : 0.f);
+    if (lane == 0) { float* o = part + ((long)blockIdx.x * R + r) * 3; o[0] = m; o[1] = s; o[2] = c; }
   }
 }
 
-__global__ void nce_finish_kernel(const float* __restrict__ part, const float* __restrict__ pos, float* __restrict__ lse,
-                                  float* __restrict__ loss_rows, int32_t* __restrict__ rank, int R, int nblk, float inv_T) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+// one wave per row: merge the per-block partials
+__global__ __launch_bounds__(64) void nce_finish_kernel(const float* __restrict__ part, const float* __restrict__ pos,
+                                                        float* __restrict__ lse, float* __restrict__ loss_rows,
+                                                        int32_t* __restrict__ rank, int R, int nblk, float inv_T) {
+  const int r = blockIdx.x, lane = threadIdx.x;
   const float p = pos[r] * inv_T;
   float m = p;
-  for (int b = 0; b < nblk; ++b) m = fmaxf(m, part[((long)b * R + r) * 3]);
-  float s = expf(p - m), c = 0.f;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) m = fmaxf(m, part[((long)b * R + r) * 3]);
+  m = wave_max(m);
+  float s = 0.f, c = 0.f;
+  for (int b = lane; b < nblk; b += 64) {
     const float* o = part + ((long)b * R + r) * 3;
     s += o[1] * expf(o[0] - m); c += o[2];
   }
-  const float l = m + logf(s);
-  lse[r] = l; loss_rows[r] = l - p; rank[r] = (int32_t)c;
+  s = wave_sum(s) + expf(p - m); c = wave_sum(c);
+  if (lane == 0) { const float l = m + logf(s); lse[r] = l; loss_rows[r] = l - p; rank[r] = (int32_t)(c + 0.5f); }
 }
 
 // dq[r][c] += inv_T * row_scale[r] * sum_k softmax_k * decay_k * queue[c][k]
 template <int RT>
-__global__ __launch_bounds__(NCE_COLS) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
-                                                           const float* __restrict__ q, const float* __restrict__ lse,
-                                                           const float* __restrict__ row_scale, float* __restrict__ dq,
-                                                           int R, int dim, int K, float inv_T) {
-  extern __shared__ float sm[];                 // Wt[dim][NCE_COLS+1], gcoef[RT][NCE_COLS]
-  float* Wt = sm; float* gc = sm + dim * (NCE_COLS + 1);
-  const int k = blockIdx.x * NCE_COLS + threadIdx.x;
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                      const float* __restrict__ q, const float* __restrict__ lse,
+                                                      const float* __restrict__ row_scale, float* __restrict__ dq,
+                                                      int R, int dim, int K, float inv_T) {
+  extern __shared__ float sm[];                 // Wt[dim][NCE_COLS+1], red[4][RT][NCE_COLS] (reused as gcoef[RT][NCE_COLS])
+  float* Wt = sm; float* red = sm + dim * (NCE_COLS + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * NCE_COLS + lane;
   const bool live = k < K;
   const int kk = live ? k : K - 1;
-  float lg[RT];
+  const int cq = dim / NCE_WAVES, c0 = wave * cq;
+  float acc[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) lg[r] = 0.f;
-  for (int c = 0; c < dim; ++c) {
+  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int c = c0; c < c0 + cq; ++c) {
     const float w = queue[(long)c * K + kk];
-    Wt[c * (NCE_COLS + 1) + threadIdx.x] = live ? w : 0.f;
+    Wt[c * (NCE_COLS + 1) + lane] = live ? w : 0.f;
 #pragma unroll
-    for (int r = 0; r < RT; ++r) lg[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, lg[r]);
+    for (int r = 0; r < RT; ++r) acc[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, acc[r]);
   }
-  const float decay = powf(0.99999f, (float)count[kk]);
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    const float l = lg[r] * decay * inv_T;
-    const float coef = (live && r < R) ? __expf(l - lse[r < R ? r : 0]) * decay * inv_T * row_scale[r < R ? r : 0] : 0.f;
-    gc[r * NCE_COLS + threadIdx.x] = coef;
+  for (int r = 0; r < RT; ++r) red[(wave * RT + r) * NCE_COLS + lane] = acc[r];
+  __syncthreads();
+  const float decay = powf(0.99999f, (float)count[kk]);
+  float coef[RT / NCE_WAVES + 1];
+  int nc = 0;
+  for (int r = wave; r < RT; r += NCE_WAVES, ++nc) {
+    float dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NCE_WAVES; ++w) dot += red[(w * RT + r) * NCE_COLS + lane];
+    const float l = dot * decay * inv_T;
+    coef[nc] = (live && r < R) ? __expf(l - lse[r < R ? r : 0]) * decay * inv_T * row_scale[r < R ? r : 0] : 0.f;
   }
   __syncthreads();
-  // phase 2: thread = channel c (dim <= NCE_COLS)
-  const int c = threadIdx.x;
+  float* gc = red;                              // [RT][NCE_COLS]
+  nc = 0;
+  for (int r = wave; r < RT; r += NCE_WAVES, ++nc) gc[r * NCE_COLS + lane] = coef[nc];
+  __syncthreads();
+  // phase 2: thread -> (channel c, half of the rows)
+  const int c = threadIdx.x % 128, half = threadIdx.x / 128;
   if (c < dim) {
-    float acc[RT];
+    constexpr int RH = RT / 2;
+    float a2[RH];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RH; ++r) a2[r] = 0.f;
     for (int j = 0; j < NCE_COLS; ++j) {
       const float w = Wt[c * (NCE_COLS + 1) + j];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) acc[r] = fmaf(gc[r * NCE_COLS + j], w, acc[r]);
+      for (int r = 0; r < RH; ++r) a2[r] = fmaf(gc[(half * RH + r) * NCE_COLS + j], w, a2[r]);
     }
 #pragma unroll
-    for (int r = 0; r < RT; ++r) if (r < R) atomicAdd(&dq[r * dim + c], acc[r]);
+    for (int r = 0; r < RH; ++r) if (half * RH + r < R) atomicAdd(&dq[(half * RH + r) * dim + c], a2[r]);
   }
 }
 
@@ -118,32 +133,32 @@ __global__ __launch_bounds__(NCE_COLS) void nce_bwd_kernel(const float* __restri
 extern "C" int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
                             int R, int dim, int K, float inv_T, void* stream) {
   if (!queue || !count || !q || !pos_logit || !part || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
-  if (R > 32 || dim > NCE_COLS) return MSCL_E_SHAPE;
+  if (R > 32 || dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
   NCE_DISPATCH(R,
-    hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(NCE_COLS), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T))
+    hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T))
   MSCL_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank, int R,
                                int nblk, float inv_T, void* stream) {
   if (!part || !pos_logit || !lse || !loss_rows || !rank || R <= 0 || nblk <= 0) return MSCL_E_ARG;
-  hipLaunchKernelGGL(nce_finish_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, pos_logit, lse, loss_rows, rank, R, nblk, inv_T);
+  hipLaunchKernelGGL(nce_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, part, pos_logit, lse, loss_rows, rank, R, nblk, inv_T);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
                             float* dq, int R, int dim, int K, float inv_T, void* stream) {
   if (!queue || !count || !q || !lse || !row_scale || !dq || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
-  if (R > 32 || dim > NCE_COLS) return MSCL_E_SHAPE;
+  if (R > 32 || dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
   const int rt = R <= 8 ? 8 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32));
-  const size_t lds = ((size_t)dim * (NCE_COLS + 1) + (size_t)rt * NCE_COLS) * sizeof(float);
+  const size_t lds = ((size_t)dim * (NCE_COLS + 1) + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -151,10 +166,10 @@ extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const floa
     attr = true;
   }
   NCE_DISPATCH(R,
-    hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(NCE_COLS), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T))
+    hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T))
   MSCL_LAUNCH_CHECK();
   return 0;
 }

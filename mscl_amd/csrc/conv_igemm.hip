@@ -8,15 +8,27 @@
 // B is the kernel laid out [n][tap][source channel] (K-contiguous, like A), so both operands are read
 // from LDS as 16-byte k-contiguous fragments of v_mfma_f32_16x16x32_bf16.
 //
-// MI355X mapping: 256 threads = 4 waves; block tile BM x BN, depth step BK (64 when the source channel
-// count allows a whole 128-byte row per tap, else 32); double-buffered LDS with one barrier per step,
-// next tile's global loads issued before the current tile's MFMAs (register staging, because padded
-// taps must be zero-filled per 16-byte granule); LDS images XOR-swizzled so every ds_read_b128 lane
-// group hits 16 distinct 16-byte slots; the product is computed transposed (weights as the MFMA A
-// operand) so each lane ends up with 4 consecutive output channels of one position -> 8-byte stores;
-// BatchNorm sum / sum-of-squares are reduced in the epilogue (wave shuffles -> LDS -> one atomic per
-// channel per block); the 1-D grid is remapped so that an XCD's L2 sees neighbouring position tiles.
+// MI355X mapping
+//  * 256 threads = 4 waves, block tile BM x BN, depth step BK (64 = one 128-byte channel row per tap, or 32);
+//    tiles are sized so that >= 3 blocks fit a CU's 160 KB LDS (a 256x64x64 tile = 80 KB + tables fits once:
+//    measured 0.84 waves/SIMD and 258 TFLOP/s, vs 512 TFLOP/s for 128x64x64).
+//  * Staging is LDS-DMA (buffer_load ... lds), double-buffered, one barrier per K step.  A wave-instruction
+//    writes 1 KiB of LDS linearly, so the XOR swizzle that makes every ds_read_b128 lane group hit 16
+//    distinct 16-byte slots is applied to the per-lane SOURCE offset.  Padding taps, the K tail and rows
+//    beyond M use an out-of-range offset: the buffer unit writes zeros, no VALU select, no ds_write.
+//  * The product is computed transposed (weights as the MFMA A operand): a lane owns 4 consecutive output
+//    channels of one position -> 8-byte stores; BatchNorm sum / sum-of-squares are reduced in the epilogue
+//    (shuffles -> LDS -> one atomic per channel per block).
+//  * Strided input-gradient: output positions are split into stride-parity classes; each class only visits
+//    the taps that can reach it (27/8 of the taps on average for 3x3x3 stride 2) -- one launch, class in the grid.
+//  * Small-M layers (layer3/4, pyramid levels): split-K over the grid with fp32 atomic partials + a finalize
+//    pass (bias / addend / ReLU / BN statistics / bf16), so >= 2 blocks per CU exist even at M = 784.
+//  * blockIdx is remapped so that an XCD's L2 sees neighbouring position tiles (halo reuse).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+
+struct ClassInfo { unsigned char ro[3]; unsigned char ntl; unsigned char taps[8]; int TrS, HrS, WrS, M; FastDiv dW, dH, dT; };
 
 struct IGemmGeom {
   int N, Ts, Hs, Ws, Cs;   // source (gathered) tensor
@@ -24,20 +36,29 @@ struct IGemmGeom {
   int kT, kH, kW, sT, sH, sW, pT, pH, pW;
   int M, KG, cgs, ntaps;
   int lsT, lsH, lsW;
-  int mode;                // 0 forward gather, 1 dgrad stride-1 (linear), 2 dgrad strided (generic)
-  int mtiles, ntiles;
+  int mode;                // 0 forward gather, 1 dgrad stride-1 (linear), 2 dgrad strided (parity classes)
+  int mtiles, ntiles, ksplit, nclass;
+  FastDiv dW, dH, dT;      // dense launches: division by Wr, Hr, Tr
+  ClassInfo cls[8];
 };
+
+__device__ __forceinline__ auto make_uniform_rsrc(const void* p, unsigned bytes) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
+  void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 
 template <int BK> __device__ __forceinline__ int swz(int row, int g) {
   if constexpr (BK == 64) return g ^ ((row >> 1) & 7);
   else { const int q = (row >> 2) & 3; return g ^ ((0x78 >> (q * 2)) & 3); }   // q -> {0,2,3,1}
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
     const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
-    float* __restrict__ stat_sq, const int relu) {
+    float* __restrict__ stat_sq, const int relu, float* __restrict__ partial) {
   constexpr int GPR = BK / 8;                 // 16-byte granules per tile row
   constexpr int RPP = 256 / GPR;              // rows covered per staging pass
   constexpr int AP = BM / RPP;                // A staging passes
@@ -46,113 +67,91 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   constexpr int IM = WM / 16, JN = WN / 16;
   constexpr int KSUB = BK / 32;
   static_assert(WAVES_M * WAVES_N == 4 && IM >= 1 && JN >= 1 && AP >= 1, "tile config");
+  // a 3-stage ring waits with a counted vmcnt, so every wave must issue the same number of DMA instructions
+  // per tile: the B tile has to span at least one 1-KiB chunk per wave per pass
+  static_assert(STAGES == 2 || (BN * BK * 2) % 4096 == 0, "3-stage ring needs BN*BK*2 to be a multiple of 4 KiB");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [2][BM*BK]
-  bf16_t* Bs = As + 2 * BM * BK;                                      // [2][BN*BK]
-  int* tap_delta = reinterpret_cast<int*>(Bs + 2 * BN * BK);          // [ntaps]
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [STAGES][BM*BK]
+  bf16_t* Bs = As + STAGES * BM * BK;                                 // [STAGES][BN*BK]
+  int* tap_delta = reinterpret_cast<int*>(Bs + STAGES * BN * BK);     // [ntaps] per tap-list slot
   int* tap_bits = tap_delta + g.ntaps;                                // [ntaps]
+  int* tap_id = tap_bits + g.ntaps;                                   // [ntaps] actual tap (weight addressing)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = bid % g.ntiles, mt = bid / g.ntiles;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases / M0 stay scalar
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid % g.ksplit; bid /= g.ksplit;
+  const int nt = bid % g.ntiles; bid /= g.ntiles;
+  const int mt = bid % g.mtiles; const int ci = bid / g.mtiles;       // parity class (0 when nclass == 0)
   const int m0 = mt * BM, n0 = nt * BN;
 
+  // class geometry (dense launches: one class covering every row, identity tap list)
+  int roT = 0, roH = 0, roW = 0, rsT = 1, rsH = 1, rsW = 1, TrS = g.Tr, HrS = g.Hr, WrS = g.Wr, Mc = g.M, ntl = g.ntaps;
+  FastDiv dW = g.dW, dH = g.dH, dT = g.dT;
+  const int mode = __builtin_amdgcn_readfirstlane(g.mode);
+  ClassInfo csel = g.cls[0];                  // scalar select instead of dynamic indexing of the kernarg table
+#pragma unroll
+  for (int c = 1; c < 8; ++c) if (ci == c) csel = g.cls[c];
+  if (g.nclass > 0) {
+    roT = csel.ro[0]; roH = csel.ro[1]; roW = csel.ro[2]; rsT = g.sT; rsH = g.sH; rsW = g.sW;
+    TrS = csel.TrS; HrS = csel.HrS; WrS = csel.WrS; Mc = csel.M; ntl = csel.ntl;
+    dW = csel.dW; dH = csel.dH; dT = csel.dT;
+  }
+  if (m0 >= Mc) return;                       // class smaller than the grid's (max) tile count
+
+  unsigned csel_lo = 0, csel_hi = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { csel_lo |= (unsigned)csel.taps[t] << (8 * t); csel_hi |= (unsigned)csel.taps[4 + t] << (8 * t); }
   // ---- tap tables ----
-  for (int t = tid; t < g.ntaps; t += 256) {
-    const int kw = t % g.kW, kh = (t / g.kW) % g.kH, kt = t / (g.kW * g.kH);
+  for (int t = tid; t < ntl; t += 256) {
+    const int id = (g.nclass > 0) ? (int)((t < 4 ? (csel_lo >> (8 * t)) : (csel_hi >> (8 * (t - 4)))) & 255u) : t;
+    const int kw = id % g.kW, kh = (id / g.kW) % g.kH, kt = id / (g.kW * g.kH);
     const int lin = (kt * g.Hs + kh) * g.Ws + kw;
-    tap_delta[t] = (g.mode == 0) ? lin : ((g.mode == 1) ? -lin : (kt | (kh << 8) | (kw << 16)));
+    tap_delta[t] = (mode == 0) ? lin : ((mode == 1) ? -lin : (kt | (kh << 8) | (kw << 16)));
     tap_bits[t] = (1 << kt) | (1 << (8 + kh)) | (1 << (16 + kw));
+    tap_id[t] = id;
   }
 
   // ---- per-row gather state (one row per staging pass) ----
-  const int rg = tid % GPR;                   // this thread's granule column within a tile row
+  const int rg = tid % GPR;                   // this thread's physical granule column within a tile row
   const int rr = tid / GPR;                   // row within a pass
   int row_base[AP], row_mask[AP], row_aux[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int m = m0 + p * RPP + rr;
     int mask = 0, base = 0, aux = 0;
-    if (m < g.M) {
-      const int wr = m % g.Wr; int r = m / g.Wr;
-      const int hr = r % g.Hr; r /= g.Hr;
-      const int tr = r % g.Tr; const int n = r / g.Tr;
+    if (m < Mc) {
+      const int q1 = fdiv(m, dW), ws_ = m - q1 * WrS;
+      const int q2 = fdiv(q1, dH), hs_ = q1 - q2 * HrS;
+      const int n = fdiv(q2, dT), ts_ = q2 - n * TrS;
+      const int tr = ts_ * rsT + roT, hr = hs_ * rsH + roH, wr = ws_ * rsW + roW;
       int t0, h0, w0;
-      if (g.mode == 0) { t0 = tr * g.sT - g.pT; h0 = hr * g.sH - g.pH; w0 = wr * g.sW - g.pW; }
+      if (mode == 0) { t0 = tr * g.sT - g.pT; h0 = hr * g.sH - g.pH; w0 = wr * g.sW - g.pW; }
       else { t0 = tr + g.pT; h0 = hr + g.pH; w0 = wr + g.pW; }
       for (int k = 0; k < g.kT; ++k) {
-        const int d = (g.mode == 0) ? t0 + k : t0 - k;
-        const bool ok = (g.mode == 2) ? (d >= 0 && (d & (g.sT - 1)) == 0 && (d >> g.lsT) < g.Ts) : ((unsigned)d < (unsigned)g.Ts);
+        const int d = (mode == 0) ? t0 + k : t0 - k;
+        const bool ok = (mode == 2) ? (d >= 0 && (d & (g.sT - 1)) == 0 && (d >> g.lsT) < g.Ts) : ((unsigned)d < (unsigned)g.Ts);
         mask |= ok ? (1 << k) : 0;
       }
       for (int k = 0; k < g.kH; ++k) {
-        const int d = (g.mode == 0) ? h0 + k : h0 - k;
-        const bool ok = (g.mode == 2) ? (d >= 0 && (d & (g.sH - 1)) == 0 && (d >> g.lsH) < g.Hs) : ((unsigned)d < (unsigned)g.Hs);
+        const int d = (mode == 0) ? h0 + k : h0 - k;
+        const bool ok = (mode == 2) ? (d >= 0 && (d & (g.sH - 1)) == 0 && (d >> g.lsH) < g.Hs) : ((unsigned)d < (unsigned)g.Hs);
         mask |= ok ? (1 << (8 + k)) : 0;
       }
       for (int k = 0; k < g.kW; ++k) {
-        const int d = (g.mode == 0) ? w0 + k : w0 - k;
-        const bool ok = (g.mode == 2) ? (d >= 0 && (d & (g.sW - 1)) == 0 && (d >> g.lsW) < g.Ws) : ((unsigned)d < (unsigned)g.Ws);
+        const int d = (mode == 0) ? w0 + k : w0 - k;
+        const bool ok = (mode == 2) ? (d >= 0 && (d & (g.sW - 1)) == 0 && (d >> g.lsW) < g.Ws) : ((unsigned)d < (unsigned)g.Ws);
         mask |= ok ? (1 << (16 + k)) : 0;
       }
-      if (g.mode == 2) { base = n * g.Ts; aux = t0 | (h0 << 10) | (w0 << 20); }
+      if (mode == 2) { base = n * g.Ts; aux = t0 | (h0 << 10) | (w0 << 20); }
       else base = ((n * g.Ts + t0) * g.Hs + h0) * g.Ws + w0;
     }
     row_base[p] = base; row_mask[p] = mask; row_aux[p] = aux;
   }
   __syncthreads();   // tap tables visible
 
-  uint4 ra[AP], rb[BP];
   const int cmask = (1 << g.cgs) - 1;
-
-  auto load_tiles = [&](int kt) {
-    const int kg = kt * GPR + rg;
-    const bool kin = kg < g.KG;
-    const int tap = kin ? (kg >> g.cgs) : 0;
-    const int c0 = (kg & cmask) << 3;
-    const int td = tap_delta[tap], tb = tap_bits[tap];
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const bool ok = kin && ((row_mask[p] & tb) == tb);
-      int pos;
-      if (g.mode == 2) {
-        const int a = row_aux[p];
-        const int dt = ((a & 1023) - (td & 255)) >> g.lsT;
-        const int dh = (((a >> 10) & 1023) - ((td >> 8) & 255)) >> g.lsH;
-        const int dw = (((a >> 20) & 1023) - ((td >> 16) & 255)) >> g.lsW;
-        pos = ((row_base[p] + dt) * g.Hs + dh) * g.Ws + dw;
-      } else {
-        pos = row_base[p] + td;
-      }
-      const int off = ok ? (pos * g.Cs + c0) : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(src + off);
-      ra[p] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      const int r = p * RPP + rr;
-      const bool ok = kin && (r < BN) && (n0 + r < g.Cr);
-      const long off = ok ? ((long)(n0 + r) * g.KG + kg) * 8 : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(wgt + off);
-      rb[p] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    unsigned char* a = reinterpret_cast<unsigned char*>(As + buf * BM * BK);
-    unsigned char* b = reinterpret_cast<unsigned char*>(Bs + buf * BN * BK);
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const int r = p * RPP + rr;
-      *reinterpret_cast<uint4*>(a + r * (BK * 2) + swz<BK>(r, rg) * 16) = ra[p];
-    }
-#pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      const int r = p * RPP + rr;
-      if (r < BN) *reinterpret_cast<uint4*>(b + r * (BK * 2) + swz<BK>(r, rg) * 16) = rb[p];
-    }
-  };
-
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fq = lane >> 4;
   f32x4_t acc[JN][IM];
@@ -160,16 +159,64 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int KGc = ntl << g.cgs;                       // K granules of this class
+  const int nk_all = (KGc + GPR - 1) / GPR;
+  const int k_beg = (int)((long)nk_all * split / g.ksplit), k_end = (int)((long)nk_all * (split + 1) / g.ksplit);
 
-  const int nk = (g.KG + GPR - 1) / GPR;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    const unsigned char* a = reinterpret_cast<const unsigned char*>(As + cur * BM * BK);
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(Bs + cur * BN * BK);
+  const int rgl = swz<BK>(rr, rg);            // logical granule this lane fetches (pass-invariant)
+  const unsigned src_bytes = (unsigned)((long)g.N * g.Ts * g.Hs * g.Ws * g.Cs * 2);
+  const unsigned wgt_bytes = (unsigned)((long)g.Cr * g.KG * 16);
+  // descriptors built from readfirstlane'd words: otherwise hipcc wraps every buffer op in a waterfall loop
+  const auto rs_src = make_uniform_rsrc(src, src_bytes);
+  const auto rs_wgt = make_uniform_rsrc(wgt, wgt_bytes);
+  const int cs2 = g.Cs * 2;
+  int row_byte[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) row_byte[p] = (mode == 2) ? row_base[p] : row_base[p] * cs2;
+  int wrow_byte[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int r = p * RPP + rr;
+    wrow_byte[p] = (r < BN && n0 + r < g.Cr) ? (n0 + r) * g.KG * 16 : -1;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto issue_tiles = [&](int kt, int buf) {
+    const int kg = kt * GPR + rgl;
+    const bool kin = kg < KGc;
+    const int slot = kin ? (kg >> g.cgs) : 0;
+    const int cgr = kg & cmask;
+    const int td = tap_delta[slot], tb = tap_bits[slot];
+    const int kgw = (tap_id[slot] << g.cgs) + cgr;    // granule index inside a weight row
+    unsigned char* a = reinterpret_cast<unsigned char*>(As + buf * BM * BK) + wave * 1024;
+    unsigned char* b = reinterpret_cast<unsigned char*>(Bs + buf * BN * BK) + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool ok = kin && ((row_mask[p] & tb) == tb);
+      unsigned off;
+      if (mode == 2) {
+        const int aa = row_aux[p];
+        const int dt = ((aa & 1023) - (td & 255)) >> g.lsT;
+        const int dh = (((aa >> 10) & 1023) - ((td >> 8) & 255)) >> g.lsH;
+        const int dw = (((aa >> 20) & 1023) - ((td >> 16) & 255)) >> g.lsW;
+        off = (unsigned)((((row_byte[p] + dt) * g.Hs + dh) * g.Ws + dw) * cs2 + (cgr << 4));
+      } else {
+        off = (unsigned)(row_byte[p] + td * cs2 + (cgr << 4));
+      }
+      off = ok ? off : src_bytes;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(a + p * (RPP * BK * 2)), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      if (p * RPP + (wave * 64) / GPR < BN) {       // wave-uniform: this wave's 1 KiB chunk lies inside the B tile
+        const unsigned off = (kin && wrow_byte[p] >= 0) ? (unsigned)(wrow_byte[p] + kgw * 16) : wgt_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(b + p * (RPP * BK * 2)), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  auto compute_tile = [&](int buf) {
+    const unsigned char* a = reinterpret_cast<const unsigned char*>(As + buf * BM * BK);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(Bs + buf * BN * BK);
 #pragma unroll
     for (int ks = 0; ks < KSUB; ++ks) {
       bf16x8_t fa[IM], fb[JN];
@@ -189,8 +236,68 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         for (int i = 0; i < IM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
-    __syncthreads();
+  };
+
+  if constexpr (STAGES == 2) {
+    if (k_beg < k_end) {
+      issue_tiles(k_beg, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    for (int kt = k_beg; kt < k_end; ++kt) {
+      const int cur = (kt - k_beg) & 1;
+      if (kt + 1 < k_end) issue_tiles(kt + 1, cur ^ 1);
+      compute_tile(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // 3-stage ring: tile kt+2 is issued while tile kt is computed; the wait before the barrier retires only
+    // tile kt (counted vmcnt: ND DMA instructions per wave per tile stay in flight), and the barrier is a raw
+    // s_barrier -- __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise load and compute.
+    constexpr int ND = AP + BP;
+    const int nkt = k_end - k_beg;
+    if (nkt > 0) issue_tiles(k_beg, 0);
+    if (nkt > 1) issue_tiles(k_beg + 1, 1);
+    int buf = 0, nxt = 2;
+    for (int i = 0; i < nkt; ++i) {
+      if (i + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ND) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (i + 2 < nkt) issue_tiles(k_beg + i + 2, nxt);
+      compute_tile(buf);
+      buf = (buf == STAGES - 1) ? 0 : buf + 1;
+      nxt = (nxt == STAGES - 1) ? 0 : nxt + 1;
+    }
+    __builtin_amdgcn_s_barrier();             // the epilogue reuses the tile memory
+  }
+
+  // output position of this lane's rows (class-strided for the parity-split input gradient)
+  long orow[IM];
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int m = m0 + wm0 + i * 16 + fr;
+    if (m < Mc) {
+      const int q1 = fdiv(m, dW), ws_ = m - q1 * WrS;
+      const int q2 = fdiv(q1, dH), hs_ = q1 - q2 * HrS;
+      const int n = fdiv(q2, dT), ts_ = q2 - n * TrS;
+      orow[i] = ((((long)n * g.Tr + ts_ * rsT + roT) * g.Hr + hs_ * rsH + roH) * g.Wr + ws_ * rsW + roW) * g.Cr;
+    } else orow[i] = -1;
+  }
+
+  if (partial != nullptr) {                   // split-K: this split's fp32 slab (plain 16-byte stores); the
+    float* slab = partial + (long)split * ((long)g.N * g.Tr * g.Hr * g.Wr * g.Cr);   // epilogue runs in splitk_finalize_kernel
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      if (orow[i] < 0) continue;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int n = n0 + wn0 + j * 16 + fq * 4;
+        if (n >= g.Cr) continue;
+        *reinterpret_cast<float4*>(slab + orow[i] + n) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+      }
+    }
+    return;
   }
 
   // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
@@ -228,14 +335,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   // ---- epilogue: (+bias) (+addend) (relu) -> bf16, 4 consecutive channels per lane ----
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
-    const int m = m0 + wm0 + i * 16 + fr;
-    if (m >= g.M) continue;
+    if (orow[i] < 0) continue;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int n = n0 + wn0 + j * 16 + fq * 4;
       if (n >= g.Cr) continue;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      const long o = (long)m * g.Cr + n;
+      const long o = orow[i] + n;
       if (bias != nullptr) {
         const float4 bv = *reinterpret_cast<const float4*>(bias + n);
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
@@ -252,39 +358,121 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   }
 }
 
+// split-K epilogue: out = bf16( relu?( sum of slabs + bias + addend ) ), BN statistics of the sum
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
+                                                              const float* __restrict__ bias, const bf16_t* __restrict__ addend,
+                                                              int relu, float* __restrict__ ssum, float* __restrict__ ssq,
+                                                              long rows, int C, int nslab) {
+  __shared__ float red[2 * 2048];
+  const int G = C >> 3;                       // requires 256 % G == 0
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  const int c0 = tg * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long r = (long)blockIdx.x * RP + tr; r < rows; r += (long)gridDim.x * RP) {
+    const long o = r * C + c0;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < nslab; ++sl) {
+      const float* pp = partial + (long)sl * rows * C + o;
+      const float4 a = *reinterpret_cast<const float4*>(pp), b = *reinterpret_cast<const float4*>(pp + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+    if (bias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += bias[c0 + i];
+    }
+    if (addend) { float e[8]; unpack8(*reinterpret_cast<const uint4*>(addend + o), e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += e[i]; }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f); }
+    *reinterpret_cast<uint4*>(out + o) = pack8(v);
+  }
+  if (ssum == nullptr) return;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { atomicAdd(&red[c0 + i], s[i]); atomicAdd(&red[C + c0 + i], q[i]); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(&ssum[i], red[i]); atomicAdd(&ssq[i], red[C + i]); }
+}
+
 // ---------------------------------------------------------------------------------------- host side
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias,
-                      const bf16_t* addend, float* ssum, float* ssq, int relu, hipStream_t st) {
-  g.mtiles = (g.M + BM - 1) / BM;
+                      const bf16_t* addend, float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
+  int maxM = g.M;
+  if (g.nclass > 0) { maxM = 0; for (int c = 0; c < g.nclass; ++c) maxM = g.cls[c].M > maxM ? g.cls[c].M : maxM; }
+  g.mtiles = (maxM + BM - 1) / BM;
   g.ntiles = (g.Cr + BN - 1) / BN;
-  const size_t lds = (size_t)2 * (BM + BN) * BK * 2 + (size_t)g.ntaps * 8;
-  auto kern = conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+  const int ncls = g.nclass > 0 ? g.nclass : 1;
+  const long blocks = (long)g.mtiles * g.ntiles * ncls;
+  int maxtl = g.ntaps;
+  if (g.nclass > 0) { maxtl = 0; for (int c = 0; c < g.nclass; ++c) maxtl = g.cls[c].ntl > maxtl ? g.cls[c].ntl : maxtl; }
+  const int nk = ((maxtl << g.cgs) + BK / 8 - 1) / (BK / 8);
+  g.ksplit = 1;
+  const long out_elems = (long)g.N * g.Tr * g.Hr * g.Wr * g.Cr;
+  if (ws != nullptr && blocks <= 256 && nk >= 32) {           // too few tiles for 256 CUs and a long K loop
+    long want = (512 + blocks - 1) / blocks;
+    if (want > nk / 8) want = nk / 8;
+    if (want > 16) want = 16;
+    if (want * out_elems > ws_floats) want = ws_floats / out_elems;
+    if (want > 1) g.ksplit = (int)want;
+  }
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2 + (size_t)g.ntaps * 12;
+  auto kern = conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, STAGES>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu);
+  float* partial = g.ksplit > 1 ? ws : nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(256), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
+                     relu, partial);
   MSCL_LAUNCH_CHECK();
+  if (g.ksplit > 1) {
+    const long rows = out_elems / g.Cr;
+    const int RP = 256 / (g.Cr / 8);
+    long fb = (rows + RP * 4 - 1) / (RP * 4); if (fb > 1024) fb = 1024; if (fb < 1) fb = 1;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
+                       rows, g.Cr, g.ksplit);
+    MSCL_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias,
-                        const bf16_t* addend, float* ssum, float* ssq, int relu, hipStream_t st) {
-  if ((long)g.N * g.Ts * g.Hs * g.Ws * g.Cs >= (1L << 31) || (long)g.M * g.Cr >= (1L << 31)) return MSCL_E_SHAPE;
+                        const bf16_t* addend, float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
+  if ((long)g.N * g.Ts * g.Hs * g.Ws * g.Cs >= (1L << 31) || (long)g.N * g.Tr * g.Hr * g.Wr * g.Cr >= (1L << 31)) return MSCL_E_SHAPE;
+  if ((long)g.Cr * g.KG * 16 >= (1L << 31)) return MSCL_E_SHAPE;
+  if (g.Cr / 8 > 256 || ilog2_exact(g.Cr / 8) < 0) ws = nullptr;      // finalize kernel's thread layout
   const bool bk64 = (g.Cs % 64) == 0;
   const int Cr = g.Cr;
-  auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((Cr + bn - 1) / bn); };
-#define GO(BM, BN, BK, WMv, WNv) return launch_cfg<BM, BN, BK, WMv, WNv>(g, src, wgt, out, bias, addend, ssum, ssq, relu, st)
+  int rowsM = g.M;
+  if (g.nclass > 0) { rowsM = 0; for (int c = 0; c < g.nclass; ++c) rowsM += g.cls[c].M; }
+  auto blocks = [&](int bm, int bn) { return (long)((rowsM + bm - 1) / bm) * ((Cr + bn - 1) / bn); };
+#define GO3(BM, BN, BK, WMv, WNv, ST) return launch_cfg<BM, BN, BK, WMv, WNv, ST>(g, src, wgt, out, bias, addend, ssum, ssq, relu, ws, ws_floats, st)
+#define GO(BM, BN, BK, WMv, WNv) GO3(BM, BN, BK, WMv, WNv, 2)
+  if (const char* force = getenv("MSCL_IGEMM_CFG")) {       // tuning aid: "BM,BN,BK"
+    int bm = 0, bn = 0, bk = 0, stg = 2;
+    if (sscanf(force, "%d,%d,%d,%d", &bm, &bn, &bk, &stg) >= 3 && (bk == 32 || bk64) && bn <= (Cr < 16 ? 16 : Cr)) {
+#define TRY(BM, BN, BK, WMv, WNv) if (bm == BM && bn == BN && bk == BK) { if (stg == 3) GO3(BM, BN, BK, WMv, WNv, 3); GO(BM, BN, BK, WMv, WNv); }
+      TRY(128, 128, 64, 2, 2); TRY(64, 128, 64, 2, 2); TRY(256, 64, 64, 4, 1); TRY(128, 64, 64, 2, 2); TRY(64, 64, 64, 2, 2);
+      TRY(128, 128, 32, 2, 2); TRY(256, 64, 32, 4, 1); TRY(128, 64, 32, 2, 2); TRY(64, 64, 32, 2, 2);
+      TRY(256, 128, 32, 4, 1); TRY(64, 128, 32, 2, 2);
+#undef TRY
+    }
+  }
+  const bool can_split = ws != nullptr;
   if (bk64) {
     if (Cr >= 128) {
-      if (blocks(128, 128) >= 384) GO(128, 128, 64, 2, 2);
+      if (blocks(128, 128) >= 384 || can_split) GO(128, 128, 64, 2, 2);
       GO(64, 128, 64, 2, 2);
     }
     if (Cr > 32) {
-      if (blocks(256, 64) >= 512) GO(256, 64, 64, 4, 1);
-      if (blocks(128, 64) >= 384) GO(128, 64, 64, 2, 2);
+      if (blocks(128, 64) >= 384 || can_split) GO(128, 64, 64, 2, 2);   // 48 KB LDS: 3 blocks/CU
       GO(64, 64, 64, 2, 2);
     }
     if (Cr > 16) GO(256, 32, 64, 4, 1);
@@ -295,6 +483,7 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   if (Cr > 16) GO(256, 32, 32, 4, 1);
   GO(256, 16, 32, 4, 1);
 #undef GO
+#undef GO3
 }
 
 static int check_desc(const mscl_conv_desc* d) {
@@ -303,6 +492,7 @@ static int check_desc(const mscl_conv_desc* d) {
   if (d->C % 8 || d->K % 8) return MSCL_E_SHAPE;
   if (ilog2_exact(d->C / 8) < 0 || ilog2_exact(d->K / 8) < 0) return MSCL_E_SHAPE;
   if (d->kT < 1 || d->kH < 1 || d->kW < 1 || d->kT > 8 || d->kH > 8 || d->kW > 8) return MSCL_E_SHAPE;
+  if (d->sT < 1 || d->sH < 1 || d->sW < 1) return MSCL_E_ARG;
   if (d->To != (d->T + 2 * d->pT - d->kT) / d->sT + 1 || d->Ho != (d->H + 2 * d->pH - d->kH) / d->sH + 1 ||
       d->Wo != (d->W + 2 * d->pW - d->kW) / d->sW + 1) return MSCL_E_SHAPE;
   if (d->T + d->pT >= 1000 || d->H + d->pH >= 1000 || d->W + d->pW >= 1000) return MSCL_E_SHAPE;
@@ -311,7 +501,7 @@ static int check_desc(const mscl_conv_desc* d) {
 
 extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w, uint16_t* y,
                                const float* bias, const uint16_t* addend, int relu, float* ssum, float* ssq,
-                               void* stream) {
+                               float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!x || !w || !y) return MSCL_E_ARG;
   if ((ssum == nullptr) != (ssq == nullptr)) return MSCL_E_ARG;
@@ -321,12 +511,13 @@ extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const
   g.kT = d->kT; g.kH = d->kH; g.kW = d->kW; g.sT = d->sT; g.sH = d->sH; g.sW = d->sW;
   g.pT = d->pT; g.pH = d->pH; g.pW = d->pW;
   g.M = d->N * d->To * d->Ho * d->Wo; g.ntaps = d->kT * d->kH * d->kW;
-  g.cgs = ilog2_exact(d->C / 8); g.KG = g.ntaps * (d->C / 8); g.mode = 0;
-  return launch_igemm(g, x, w, y, bias, addend, ssum, ssq, relu, (hipStream_t)stream);
+  g.cgs = ilog2_exact(d->C / 8); g.KG = g.ntaps * (d->C / 8); g.mode = 0; g.nclass = 0;
+  g.dW = make_fastdiv(g.Wr); g.dH = make_fastdiv(g.Hr); g.dT = make_fastdiv(g.Tr);
+  return launch_igemm(g, x, w, y, bias, addend, ssum, ssq, relu, splitk_ws, (long)splitk_ws_floats, (hipStream_t)stream);
 }
 
 extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT, uint16_t* dx,
-                                 const uint16_t* addend, void* stream) {
+                                 const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!dy || !wT || !dx) return MSCL_E_ARG;
   IGemmGeom g{};
@@ -337,12 +528,32 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
   g.M = d->N * d->T * d->H * d->W; g.ntaps = d->kT * d->kH * d->kW;
   g.cgs = ilog2_exact(d->K / 8); g.KG = g.ntaps * (d->K / 8);
   const bool unit = d->sT == 1 && d->sH == 1 && d->sW == 1;
-  g.mode = unit ? 1 : 2;
+  g.mode = unit ? 1 : 2; g.nclass = 0;
+  g.dW = make_fastdiv(g.Wr); g.dH = make_fastdiv(g.Hr); g.dT = make_fastdiv(g.Tr);
   if (!unit) {
     g.lsT = ilog2_exact(d->sT); g.lsH = ilog2_exact(d->sH); g.lsW = ilog2_exact(d->sW);
-    if (g.lsT < 0 || g.lsH < 0 || g.lsW < 0) return MSCL_E_STRIDE;
+    if (g.lsT < 0 || g.lsH < 0 || g.lsW < 0 || d->sT > 2 || d->sH > 2 || d->sW > 2) return MSCL_E_STRIDE;
+    // stride-parity classes: input position i receives tap k only if (i + p - k) % s == 0
+    int nc = 0;
+    for (int a = 0; a < d->sT; ++a) for (int b = 0; b < d->sH; ++b) for (int c = 0; c < d->sW; ++c) {
+      ClassInfo& ci = g.cls[nc];
+      ci.ro[0] = (unsigned char)a; ci.ro[1] = (unsigned char)b; ci.ro[2] = (unsigned char)c;
+      ci.TrS = (d->T - a + d->sT - 1) / d->sT; ci.HrS = (d->H - b + d->sH - 1) / d->sH; ci.WrS = (d->W - c + d->sW - 1) / d->sW;
+      ci.M = d->N * ci.TrS * ci.HrS * ci.WrS;
+      ci.dW = make_fastdiv(ci.WrS > 0 ? ci.WrS : 1); ci.dH = make_fastdiv(ci.HrS > 0 ? ci.HrS : 1); ci.dT = make_fastdiv(ci.TrS > 0 ? ci.TrS : 1);
+      int n = 0;
+      for (int kt = 0; kt < d->kT; ++kt) for (int kh = 0; kh < d->kH; ++kh) for (int kw = 0; kw < d->kW; ++kw) {
+        if ((a + d->pT - kt) % d->sT == 0 && (b + d->pH - kh) % d->sH == 0 && (c + d->pW - kw) % d->sW == 0) {
+          if (n >= 8) return MSCL_E_SHAPE;            // kernels wider than 4 taps per parity are not needed here
+          ci.taps[n++] = (unsigned char)((kt * d->kH + kh) * d->kW + kw);
+        }
+      }
+      ci.ntl = (unsigned char)n;
+      if (ci.M > 0) ++nc;
+    }
+    g.nclass = nc;
   }
-  return launch_igemm(g, dy, wT, dx, nullptr, addend, nullptr, nullptr, 0, (hipStream_t)stream);
+  return launch_igemm(g, dy, wT, dx, nullptr, addend, nullptr, nullptr, 0, splitk_ws, (long)splitk_ws_floats, (hipStream_t)stream);
 }
 
 __global__ void weight_transpose_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wT, int Cout, int taps, int Cin) {
@@ -359,6 +570,27 @@ extern "C" int mscl_weight_transpose(const uint16_t* w, uint16_t* wT, int Cout, 
   const long total = (long)Cout * taps * Cin;
   const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipLaunchKernelGGL(weight_transpose_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wT, Cout, taps, Cin);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// all kernels of a model in one launch: table[i] = {src ptr, dst ptr, Cout, taps, Cin, first block}
+struct TransposeEntry { const bf16_t* w; bf16_t* wT; int Cout, taps, Cin, first_block; };
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const TransposeEntry* __restrict__ table, int n) {
+  int e = 0;
+  for (int i = 1; i < n; ++i) if ((int)blockIdx.x >= table[i].first_block) e = i;      // uniform scan, n ~ 40
+  const TransposeEntry t = table[e];
+  const long total = (long)t.Cout * t.taps * t.Cin;
+  const long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % t.Cout); const long r = i / t.Cout;
+  const int tap = (int)(r % t.taps); const int ci = (int)(r / t.taps);
+  t.wT[i] = t.w[((long)co * t.taps + tap) * t.Cin + ci];
+}
+extern "C" int mscl_weight_transpose_batched(const void* table, int n, int total_blocks, void* stream) {
+  if (!table || n <= 0 || total_blocks <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const TransposeEntry*>(table), n);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -11,15 +11,6 @@
 // fp32 atomic per element per block (dW is caller-zeroed; repeated trunk traversals accumulate).
 #include "common.h"
 
-struct FastDiv { uint32_t magic; int shift; };
-static FastDiv make_fastdiv(int d) {            // exact for 0 <= n < 2^31
-  int L = 0; while ((1 << L) < d) ++L;
-  FastDiv f; f.shift = 31 + L;
-  f.magic = (uint32_t)((((uint64_t)1) << f.shift) / (uint64_t)d + 1);
-  return f;
-}
-__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((uint64_t)(uint32_t)n * f.magic) >> f.shift); }
-
 struct WGeom {
   int N, T, H, W, C;       // x
   int To, Ho, Wo, K;       // dy

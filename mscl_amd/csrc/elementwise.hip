@@ -279,25 +279,33 @@ extern "C" int mscl_linear_fwd(const float* x, const float* w, const float* b, f
   return 0;
 }
 // backward: g = dy * (y>0 if relu);  dx[r][i] = sum_o g[r][o] w[o][i];  dw[o][i] += sum_r g[r][o] x[r][i];  db[o] += sum_r g[r][o]
+// dx[r][i] += sum over this block's 32 output features; grid = (in_f/256, out_f/32); dx is pre-zeroed
+#define LIN_OCHUNK 32
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dx, int rows,
                                                             int in_f, int out_f, int relu) {
+  __shared__ float g[LIN_MAX_ROWS * LIN_OCHUNK];
+  const int o0 = blockIdx.y * LIN_OCHUNK;
+  for (int e = threadIdx.x; e < rows * LIN_OCHUNK; e += 256) {
+    const int r = e / LIN_OCHUNK, o = o0 + e % LIN_OCHUNK;
+    float v = 0.f;
+    if (o < out_f) { v = dy[(long)r * out_f + o]; if (relu && !(y[(long)r * out_f + o] > 0.f)) v = 0.f; }
+    g[e] = v;
+  }
+  __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= in_f) return;
   float acc[LIN_MAX_ROWS];
 #pragma unroll
   for (int r = 0; r < LIN_MAX_ROWS; ++r) acc[r] = 0.f;
-  for (int o = 0; o < out_f; ++o) {
-    const float wv = w[(long)o * in_f + i];
+  const int on = min(LIN_OCHUNK, out_f - o0);
+  for (int oo = 0; oo < on; ++oo) {
+    const float wv = w[(long)(o0 + oo) * in_f + i];
 #pragma unroll
-    for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) {
-      float g = dy[(long)r * out_f + o];
-      if (relu && !(y[(long)r * out_f + o] > 0.f)) g = 0.f;
-      acc[r] += g * wv;
-    }
+    for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) acc[r] = fmaf(g[r * LIN_OCHUNK + oo], wv, acc[r]);
   }
 #pragma unroll
-  for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) dx[(long)r * in_f + i] = acc[r];
+  for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) atomicAdd(&dx[(long)r * in_f + i], acc[r]);
 }
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dw,
@@ -320,7 +328,10 @@ extern "C" int mscl_linear_bwd(const float* x, const float* w, const float* y, c
   if (rows > LIN_MAX_ROWS) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((in_f + 255) / 256), dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
+    hipError_t me = hipMemsetAsync(dx, 0, (size_t)rows * in_f * sizeof(float), st);
+    if (me != hipSuccess) return (int)me;
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((in_f + 255) / 256, (out_f + LIN_OCHUNK - 1) / LIN_OCHUNK), dim3(256), 0, st, w, y,
+                       dy, dx, rows, in_f, out_f, relu);
     MSCL_LAUNCH_CHECK();
   }
   const long tot = (long)out_f * in_f;

@@ -29,6 +29,15 @@ def out_shape(d):
     return (d.N, d.To, d.Ho, d.Wo, d.K)
 
 
+def _splitk_ws(rows, chans, device):
+    """fp32 scratch for split-K when the layer has too few position tiles to fill 256 CUs (else None)."""
+    tiles = ((rows + 127) // 128) * ((chans + 127) // 128 if chans >= 128 else 1)
+    if tiles > 256 or chans < 64:
+        return None
+    nslab = min(16, (512 + tiles - 1) // tiles)
+    return torch.empty((nslab * rows * chans,), dtype=torch.float32, device=device)
+
+
 PROFILE_CONV = None      # bench.py: dict(sig=(N,T,H,W,C,K,kT), events=[]) -> event pairs around matching launches
 
 
@@ -41,8 +50,9 @@ def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = _splitk_ws(d.N * d.To * d.Ho * d.Wo, d.K, x.device)
     call('mscl_conv3d_fwd', ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(addend), int(relu),
-         ptr(s0), ptr(s1), stream_ptr())
+         ptr(s0), ptr(s1), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
     if timed:
         e1.record()
         prof['events'].append((e0, e1))
@@ -51,7 +61,8 @@ def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
 
 def conv3d_dgrad(dy, wT, d, addend=None):
     dx = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
-    call('mscl_conv3d_dgrad', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dx), ptr(addend), stream_ptr())
+    ws = _splitk_ws(d.N * d.T * d.H * d.W, d.C, dy.device)
+    call('mscl_conv3d_dgrad', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dx), ptr(addend), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
     return dx
 
 
@@ -62,6 +73,47 @@ def conv3d_wgrad(x, dy, d, dw, dbias=None):
 
 def weight_transpose(w, wT, Cout, taps, Cin):
     call('mscl_weight_transpose', ptr(w), ptr(wT), Cout, taps, Cin, stream_ptr())
+
+
+def build_transpose_table(entries, device):
+    """entries: [(w bf16 tensor, wT bf16 tensor, Cout, taps, Cin)] -> (device table, n, total_blocks)"""
+    import struct
+    raw, first = b'', 0
+    for w, wT, co, taps, ci in entries:
+        raw += struct.pack('<QQiiii', w.data_ptr(), wT.data_ptr(), co, taps, ci, first)
+        first += (co * taps * ci + 255) // 256
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return table, len(entries), first
+
+
+def weight_transpose_batched(table, n, total_blocks):
+    call('mscl_weight_transpose_batched', ptr(table), n, total_blocks, stream_ptr())
+
+
+class ZeroPool:
+    """Pre-zeroed fp32 scratch handed out in slices and re-zeroed with ONE memset per step (BatchNorm
+    statistics / reduction scratch used to cost ~190 tiny fill launches per step)."""
+
+    def __init__(self):
+        self.buf, self.used = None, 0
+
+    def reset(self, device, size=4 << 20):
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(size, dtype=torch.float32, device=device)
+        elif self.used:
+            self.buf[:self.used].zero_()
+        self.used = 0
+
+    def take(self, n, device):
+        n64 = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != torch.device(device) or self.used + n64 > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)     # outside a step, or pool exhausted
+        out = self.buf[self.used:self.used + n]
+        self.used += n64
+        return out
+
+
+ZEROS = ZeroPool()
 
 
 def _bnp(stats, gamma, beta, rm, rv, nbt, smean, sinv):
@@ -175,7 +227,7 @@ def l2norm_bwd(y, norms, dy):
     return dx
 
 
-NCE_COLS = 128
+NCE_COLS = 64
 
 
 def nce_forward(queue, count, q, pos, inv_T):

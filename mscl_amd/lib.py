@@ -31,10 +31,11 @@ class BnParams(Structure):
 P = c_void_p
 _SIGS = {
     'mscl_abi_version': [],
-    'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P],
-    'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P],
+    'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
+    'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P],
     'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],
+    'mscl_weight_transpose_batched': [P, c_int, c_int, P],
     'mscl_bn_act_fwd': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, P],
     'mscl_bn_act_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P],
     'mscl_pack_input': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P],

@@ -87,7 +87,7 @@ def cba_fwd(conv, bn, x, residual, relu):
     if not bn.training:
         raise MsclError('BatchNorm3dHip implements training-mode statistics only (both MoCo encoders run in train(), SURVEY App. E-6)')
     C = conv.out_channels
-    stats = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+    stats = K.ZEROS.take(2 * C, x.device).view(2, C)
     y = conv.fwd(x, stats=(stats[0], stats[1]))
     save = torch.empty((2, C), dtype=torch.float32, device=x.device)
     rt = bn._rt
@@ -102,7 +102,7 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
     gradient (optionally fused with `dx_addend`).  Returns (dx|None, dres|None)."""
     rt = bn._rt
     C = conv.out_channels
-    scratch = torch.zeros((4 * C,), dtype=torch.float32, device=dout.device)
+    scratch = K.ZEROS.take(4 * C, dout.device)
     dy, dres = K.bn_act_bwd(dout, out, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], relu, scratch,
                             want_identity_dres=want_dres)
     rt['slot_g'].touched = True

@@ -271,6 +271,13 @@ class MSCLWithAug(nn.Module):
                 for top in mods:
                     for m in top.modules():
                         self._bind(m, ar, key, rec)
+        entries = []
+        for rec in (self.recognizer, self.recognizer_flow):
+            for top in rec.q_modules():
+                for m in top.modules():
+                    if isinstance(m, Conv3dHip) and m._rt.get('wT') is not None:
+                        entries.append((m._rt['w'], m._rt['wT'], m.out_channels, m.taps, m.in_channels))
+        self._tr_table = K.build_transpose_table(entries, device)
         self.sync_shadows()
         return self
 
@@ -300,11 +307,7 @@ class MSCLWithAug(nn.Module):
                     rt['dw8_flush'] = (dw8, ar.packed('G', sw), m.in_channels)
             if not key and m.cin_eff == m.in_channels:
                 wT = torch.empty((m.in_channels, *m.kernel_size, m.out_channels), dtype=torch.bfloat16, device=dev)
-                rt['wT'] = wT
-
-                def refresh_t(w=rt['w'], wT=wT, co=m.out_channels, taps=m.taps, ci=m.in_channels):
-                    K.weight_transpose(w, wT, co, taps, ci)
-                rec._q_refresh.append(refresh_t)
+                rt['wT'] = wT          # refreshed by ONE batched transpose launch (refresh_after_optimizer)
             m._rt = rt
         elif isinstance(m, BatchNorm3dHip):
             sg, sb = m.weight._mscl_slot, m.bias._mscl_slot
@@ -324,12 +327,14 @@ class MSCLWithAug(nn.Module):
         for rec in (self.recognizer, self.recognizer_flow):
             for fn in rec._q_refresh + rec._k_refresh:
                 fn()
+        K.weight_transpose_batched(*self._tr_table)
 
     @torch.no_grad()
     def refresh_after_optimizer(self):
         for rec in (self.recognizer, self.recognizer_flow):
             for fn in rec._q_refresh:
                 fn()
+        K.weight_transpose_batched(*self._tr_table)
 
     @torch.no_grad()
     def flush_padded_grads(self):
@@ -392,6 +397,7 @@ class MSCLWithAug(nn.Module):
         aug = self.aug_gpu
         B = im_q.shape[0]
         bg = B * parallel.world_size()
+        K.ZEROS.reset(im_q.device)
         step = self._step
         # -- RGB stream
         x_q = aug.pack_rgb(im_q)

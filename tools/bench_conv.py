@@ -1,0 +1,79 @@
+"""Micro-benchmark of the conv kernels on the shapes of one mscl_r18 step (B=8, T=16, 112^2).
+usage: python tools/bench_conv.py [--only NAME] [--iters N] [--modes fwd,dgrad,wgrad]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mscl_amd import kernels as K  # noqa: E402
+
+SHAPES = [
+    # name, (N,T,H,W,C), K, kernel, stride, pad
+    ('l1_64_64', (8, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('l2_64_128_s2', (8, 16, 56, 56, 64), 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ('l2_128_128', (8, 8, 28, 28, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('l3_128_256_s2', (8, 8, 28, 28, 128), 256, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ('l3_256_256', (8, 4, 14, 14, 256), 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('l4_256_512_s2', (8, 4, 14, 14, 256), 512, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ('l4_512_512', (8, 2, 7, 7, 512), 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('stem_rgb', (8, 16, 112, 112, 8), 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
+    ('sepc_128', (8, 8, 28, 28, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('fpn_133', (8, 8, 28, 28, 128), 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('flow_stem', (8, 16, 112, 112, 8), 16, (1, 7, 7), (2, 2, 2), (0, 3, 3)),
+    ('flow_l1', (8, 8, 56, 56, 16), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('flow_l2', (8, 8, 28, 28, 32), 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('flow_l3', (8, 8, 14, 14, 64), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('flow_l4', (8, 8, 7, 7, 128), 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--modes', default='fwd,dgrad,wgrad')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    modes = a.modes.split(',')
+    for name, xs, Kc, kern, st, pad in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        C = xs[-1]
+        d = K.conv_desc(xs, Kc, kern, st, pad)
+        x = torch.randn(xs, device=dev).to(torch.bfloat16)
+        w = (torch.randn((Kc, *kern, C), device=dev) * 0.05).to(torch.bfloat16)
+        wT = w.permute(4, 1, 2, 3, 0).contiguous()
+        dy = torch.randn(K.out_shape(d), device=dev).to(torch.bfloat16)
+        dw = torch.zeros((Kc, *kern, C), device=dev)
+        stats = torch.zeros((2, Kc), device=dev)
+        flops = 2.0 * d.N * d.To * d.Ho * d.Wo * Kc * kern[0] * kern[1] * kern[2] * C
+        out = [f'{name:16s} {flops/1e9:7.2f} GF']
+        if 'fwd' in modes:
+            ms = timeit(lambda: K.conv3d_fwd(x, w, d, stats=(stats[0], stats[1])), a.iters)
+            out.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF')
+        if 'dgrad' in modes and C >= 16:
+            ms = timeit(lambda: K.conv3d_dgrad(dy, wT, d), a.iters)
+            out.append(f'dgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF')
+        if 'wgrad' in modes:
+            ms = timeit(lambda: K.conv3d_wgrad(x, dy, d, dw), a.iters)
+            out.append(f'wgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF')
+        print('  '.join(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()
