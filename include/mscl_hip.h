@@ -166,6 +166,8 @@ int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, int32_t* hit
 /* ---- parameter-sized elementwise passes --------------------------------------------------------
  * key-encoder EMA (recognizers/moco.py:408-421): pk = m*pk + (1-m)*pq, and refresh pk's bf16 shadow */
 int mscl_ema_update(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, float m, void* stream);
+/* same with m read from device memory, so a captured HIP graph can follow the cosine momentum schedule */
+int mscl_ema_update_dev(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, const float* m_dev, void* stream);
 /* sum of squares of g into *out (fp32, caller-zeroed): first half of clip_grad_norm_ */
 int mscl_sumsq(const float* g, float* out, int64_t n, void* stream);
 /* second half + torch.optim.SGD (momentum, dampening 0, no nesterov), mmcv OptimizerHook wiring at
@@ -174,6 +176,9 @@ int mscl_sumsq(const float* g, float* out, int64_t n, void* stream);
  * `first` selects the buffer initialisation of the very first step (buf = g). */
 int mscl_sgd_step(float* p, const float* g, float* buf, uint16_t* p_bf16, int64_t n, const float* sumsq,
                   float max_norm, float lr, float momentum, float wd, int first, void* stream);
+/* lr read from device memory (graph replay); momentum buffers must be zero-initialised */
+int mscl_sgd_step_dev(float* p, const float* g, float* buf, uint16_t* p_bf16, int64_t n, const float* sumsq,
+                      float max_norm, const float* lr_dev, float momentum, float wd, void* stream);
 int mscl_cast_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ mean, const float* __restrict__ inv, const bf16_t* __restrict__ ry,
     const float* __restrict__ rmean, const float* __restrict__ rinv, float* __restrict__ scratch, long rows, int C,
     int relu) {
-  extern __shared__ float sm[];     // red[3*C]
+  extern __shared__ float sm[];     // red[3][4 waves][C]
   const int G = C >> 3;             // threads per row; 256 % G == 0 required (C/8 power of two)
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const int c0 = tg * 8;
@@ -126,16 +126,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       for (int i = 0; i < 8; ++i) s2[i] += d[i] * (rr[i] - rmu[i]) * riv[i];
     }
   }
-  for (int i = threadIdx.x; i < 3 * C; i += 256) sm[i] = 0.f;
+  // block reduction without LDS atomics: shuffles inside a wave, plain LDS stores across waves
+  const int nvec = ry ? 3 : 2;
+  block_channel_sum(s0, sm, G, C, nvec, 0);
+  block_channel_sum(s1, sm, G, C, nvec, 1);
+  if (ry) block_channel_sum(s2, sm, G, C, nvec, 2);
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    atomicAdd(&sm[c0 + i], s0[i]); atomicAdd(&sm[C + c0 + i], s1[i]);
-    if (ry) atomicAdd(&sm[2 * C + c0 + i], s2[i]);
+  const int lim = nvec * C;
+  for (int i = threadIdx.x; i < lim; i += 256) {
+    const int vv = i / C, c = i % C;
+    float t = 0.f;
+    for (int w = 0; w < 4; ++w) t += sm[(vv * 4 + w) * C + c];
+    atomicAdd(&scratch[i], t);
   }
-  __syncthreads();
-  const int lim = ry ? 3 * C : 2 * C;
-  for (int i = threadIdx.x; i < lim; i += 256) atomicAdd(&scratch[i], sm[i]);
 }
 
 // ---- backward pass 2: dy = gamma*inv*(dz - sum_dz/n - xhat*sum_dzxhat/n); residual gradient ----
@@ -201,13 +204,13 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
   if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
   if (relu && !out) return MSCL_E_ARG;
   if (rows <= 0 || C <= 0) return MSCL_E_ARG;
-  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 2048) return MSCL_E_SHAPE;
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 512) return MSCL_E_SHAPE;      // block_channel_sum needs C/8 <= 64
   if (res_y && (!res_gamma || !res_mean || !res_invstd || !res_dgamma || !res_dbeta || !dres)) return MSCL_E_ARG;
   if (want_identity_dres && !dres) return MSCL_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int RP = 256 / (C / 8);
   long blocks = (rows + RP * 8 - 1) / (RP * 8); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)3 * C * sizeof(float), st, dout,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)12 * C * sizeof(float), st, dout,
                      out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu);
   MSCL_LAUNCH_CHECK();
   const long total = rows * (C / 8);

@@ -16,7 +16,4 @@ for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o libmscl_hip.so build/*.o
 echo "built $(pwd)/libmscl_hip.so"
 # a library with unresolved kernel stubs links fine but cannot be dlopen()ed: check now, not on the GPU box
-python3 - <<PY
-import ctypes, sys
-ctypes.CDLL("$(pwd)/libmscl_hip.so")
-PY
+python3 -c "import ctypes; ctypes.CDLL('$(pwd)/libmscl_hip.so')" || { echo "error: libmscl_hip.so has unresolved symbols (dlopen failed)"; exit 1; }

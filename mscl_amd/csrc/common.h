@@ -43,6 +43,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Block-wide per-channel sum for the "G = C/8 threads per row, 256/G rows per pass" thread layout used by the
+// channel-reduction kernels: lanes that own the same channel granule sit G apart inside a wave (G < 64), so
+// they are combined with shuffles, then the (<= 4) waves are combined through LDS with plain stores --
+// no LDS atomics (64-way contention cost ~10 us per launch on small maps).  v[8] are this thread's partial
+// sums for channels c0..c0+7; on return red[c] holds the block total for every channel (after a barrier).
+__device__ __forceinline__ void block_channel_sum(float* v, float* red, int G, int C, int nvec, int vec) {
+  // red layout: [nvec][4 waves][C]
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += __shfl_xor(v[i], o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tg = threadIdx.x % G;
+  if (G >= 64 || lane < G) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[(vec * 4 + wave) * C + tg * 8 + i] = v[i];
+  }
+}
+
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (bid % 8) get a contiguous
 // run of logical ids, so neighbouring tiles (shared halos / weight panels) meet in one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

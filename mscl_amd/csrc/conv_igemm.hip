@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
                                                               const float* __restrict__ bias, const bf16_t* __restrict__ addend,
                                                               int relu, float* __restrict__ ssum, float* __restrict__ ssq,
                                                               long rows, int C, int nslab) {
-  __shared__ float red[2 * 2048];
-  const int G = C >> 3;                       // requires 256 % G == 0
+  __shared__ float red[8 * 512];
+  const int G = C >> 3;                       // requires 256 % G == 0 and C <= 512
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const int c0 = tg * 8;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -391,12 +391,13 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
     *reinterpret_cast<uint4*>(out + o) = pack8(v);
   }
   if (ssum == nullptr) return;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  block_channel_sum(s, red, G, C, 2, 0);
+  block_channel_sum(q, red, G, C, 2, 1);
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { atomicAdd(&red[c0 + i], s[i]); atomicAdd(&red[C + c0 + i], q[i]); }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(&ssum[i], red[i]); atomicAdd(&ssq[i], red[C + i]); }
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(&ssum[i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
+    atomicAdd(&ssq[i], red[4 * C + i] + red[5 * C + i] + red[6 * C + i] + red[7 * C + i]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------- host side
@@ -447,7 +448,7 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
                         const bf16_t* addend, float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
   if ((long)g.N * g.Ts * g.Hs * g.Ws * g.Cs >= (1L << 31) || (long)g.N * g.Tr * g.Hr * g.Wr * g.Cr >= (1L << 31)) return MSCL_E_SHAPE;
   if ((long)g.Cr * g.KG * 16 >= (1L << 31)) return MSCL_E_SHAPE;
-  if (g.Cr / 8 > 256 || ilog2_exact(g.Cr / 8) < 0) ws = nullptr;      // finalize kernel's thread layout
+  if (g.Cr > 512 || ilog2_exact(g.Cr / 8) < 0) ws = nullptr;          // finalize kernel's thread layout
   const bool bk64 = (g.Cs % 64) == 0;
   const int Cr = g.Cr;
   int rowsM = g.M;

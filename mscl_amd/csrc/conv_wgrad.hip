@@ -1,90 +1,150 @@
 // Conv3d weight gradient on bf16 MFMA (gfx950):  dW[co][tap][ci] += sum_m dy[m][co] * x[src(m,tap)][ci]
 //
-// GEMM view per tap: D[co][ci] = sum over positions m.  Both operands are stored position-major in HBM
-// (NDHWC), i.e. the reduction index is the *row* of both tiles, so the MFMA fragments (8 consecutive
-// reduction indices per lane) are column reads of the LDS images: ds_read_b64_tr_b16, CDNA4's
-// transposing LDS read, delivers them without any data shuffling.
+// GEMM view: D[co][col] with col = tap*Cin + ci (the memory order of dW), reduction over positions m.
+// Both operands are position-major in HBM (NDHWC), i.e. the reduction index is the ROW of both LDS
+// tiles, so the MFMA fragments (8 consecutive reduction indices per lane) are column reads:
+// ds_read_b64_tr_b16, CDNA4's transposing LDS read, delivers them with no shuffles.
 //
-// Work split: one block = (co tile <=64) x (ci tile <=64 of ONE tap) x (a slice of the positions).
-// The four waves of a block each take 32 of the 128 positions staged per step and keep a full
-// co x ci accumulator tile; they are summed through LDS at the end and added to dW with one
-// fp32 atomic per element per block (dW is caller-zeroed; repeated trunk traversals accumulate).
+// One block = CO output channels x NCOL columns (NCOL = 192 = three 64-channel taps that share ONE dy
+// tile, or 64) x a slice of the positions, 64 positions per step:
+//  * both tiles are staged by LDS-DMA (buffer_load ... lds), double-buffered; padded taps / tails use an
+//    out-of-range offset -> hardware zero fill; the XOR swizzle that spreads the transposing reads over
+//    the banks is applied on the source side (the LDS image of a wave-instruction is linear);
+//  * the per-position decode (n,t,h,w -> base offset + separable tap-validity mask) is done ONCE per row
+//    by 64 threads two steps ahead and shared through LDS -- it used to be redone per 16-byte granule;
+//  * the 4 waves split the columns (no cross-wave reduction); each adds its fp32 tile to dW with one
+//    atomic per element (dW is caller-zeroed; repeated trunk traversals accumulate).
 #include "common.h"
+#include <cstdlib>
 
 struct WGeom {
   int N, T, H, W, C;       // x
   int To, Ho, Wo, K;       // dy
   int kT, kH, kW, sT, sH, sW, pT, pH, pW;
-  int M, ntaps;
-  int co_tiles, ci_tiles, splits, per_split;   // per_split: positions per split (multiple of 128)
+  int M, ntaps, cgs, ncols;                    // ncols = ntaps*C
+  int co_tiles, col_tiles, splits, per_split;  // per_split: positions per split (multiple of 64)
   FastDiv dWo, dHo, dTo;
 };
 
-template <int CH> __device__ __forceinline__ int wswz(int row) {
-  if constexpr (CH == 64) return (row & 2) | ((row >> 1) & 4);    // XOR on the 16-byte granule index
-  else return 0;
+__device__ __forceinline__ int wswz(int row) { return (row & 2) | ((row >> 1) & 4); }   // XOR on the 16-byte granule index
+
+__device__ __forceinline__ auto wg_rsrc(const void* p, unsigned bytes) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
+  void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-// CO, CI: channel extents of the block tile (16, 32 or 64)
-template <int CO, int CI>
+template <int CO, int NCOL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf16_t* __restrict__ x,
                                                          const bf16_t* __restrict__ dy, float* __restrict__ dw) {
-  constexpr int PB = 128;                       // positions staged per step
-  constexpr int GA = CO / 8, GB = CI / 8;       // granules per row
-  constexpr int PA = (PB * GA + 255) / 256, PBs = (PB * GB + 255) / 256;
-  constexpr int IA = CO / 16, JB = CI / 16;
+  constexpr int PB = 64;                        // positions per step
+  constexpr int GA = CO / 8, GB = NCOL / 8;     // granules per tile row
+  constexpr int NA = (PB * GA + 255) / 256;     // dy DMA passes (one 1-KiB chunk per wave per pass)
+  constexpr int NB = PB * GB / 256;             // x DMA passes
+  constexpr int IA = CO / 16;
+  constexpr int WN = NCOL / 4, JB = WN / 16;    // columns per wave
+  static_assert((PB * GB) % 256 == 0 && WN % 16 == 0 && (PB * GA) % 64 == 0, "tile config");
+  constexpr bool SWA = GA >= 8, SWB = GB >= 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* At = smem;                               // [2][PB][CO] bf16
-  unsigned char* Bt = smem + 2 * PB * CO * 2;             // [2][PB][CI] bf16
+  unsigned char* Bt = At + 2 * PB * CO * 2;               // [2][PB][NCOL] bf16
+  int2* rinfo = reinterpret_cast<int2*>(Bt + 2 * PB * NCOL * 2);   // [8][PB] ring of {base position, validity mask}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
-  const int split = bid % g.splits; bid /= g.splits;
-  const int cit = bid % g.ci_tiles; bid /= g.ci_tiles;
-  const int tap = bid % g.ntaps; const int cot = bid / g.ntaps;
-  const int kw = tap % g.kW, kh = (tap / g.kW) % g.kH, kt = tap / (g.kW * g.kH);
-  const int co0 = cot * CO, ci0 = cit * CI;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block order: all column tiles (taps) of ONE position slice are consecutive logical ids and the ids are
+  // remapped so that an XCD gets a contiguous run: the slice's x / dy rows are then served 27x from that
+  // XCD's L2 instead of the Infinity Cache (layer 1 re-reads 2.8 GB per launch otherwise)
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int colt = bid % g.col_tiles; bid /= g.col_tiles;
+  const int split = bid % g.splits; const int cot = bid / g.splits;
+  const int co0 = cot * CO, n0 = colt * NCOL;
   const int mbeg = split * g.per_split;
   const int mend = min(g.M, mbeg + g.per_split);
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + PB - 1) / PB : 0;
+  if (nsteps == 0) return;
 
-  uint4 ra[PA], rb[PBs];
-  auto load_tiles = [&](int mb) {
+  const unsigned x_bytes = (unsigned)((long)g.N * g.T * g.H * g.W * g.C * 2);
+  const unsigned dy_bytes = (unsigned)((long)g.M * g.K * 2);
+  const auto rs_x = wg_rsrc(x, x_bytes);
+  const auto rs_dy = wg_rsrc(dy, dy_bytes);
+  const int c2 = g.C * 2, k2 = g.K * 2;
+  const int cmask = (1 << g.cgs) - 1;
+
+  // ---- per-thread constants of the x-tile DMA: pass p moves granule G = (p*4 + wave)*64 + lane of the tile
+  int xb_row[NB], xb_delta[NB], xb_bits[NB];    // tile row, byte delta of (tap, channel granule), tap validity bits (0 = dead column)
 #pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int e = p * 256 + tid; const int r = e / GA, gq = e % GA;
-      const int m = mb + r;
-      const bool ok = (e < PB * GA) && (m < mend);
-      const long off = ok ? ((long)m * g.K + co0 + gq * 8) : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(dy + off);
-      ra[p] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+  for (int p = 0; p < NB; ++p) {
+    const int G = (p * 4 + wave) * 64 + lane;
+    const int row = G / GB, pg = G % GB;
+    const int lg = SWB ? (pg ^ wswz(row)) : pg;             // logical granule fetched into physical slot pg
+    const int jg = (n0 >> 3) + lg;                          // global column granule
+    int delta = 0, bits = 0;
+    if (jg * 8 < g.ncols) {
+      const int tap = jg >> g.cgs, cig = jg & cmask;
+      const int kw = tap % g.kW, kh = (tap / g.kW) % g.kH, kt = tap / (g.kW * g.kH);
+      delta = ((kt * g.H + kh) * g.W + kw) * c2 + cig * 16;
+      bits = (1 << kt) | (1 << (8 + kh)) | (1 << (16 + kw));
     }
+    xb_row[p] = row; xb_delta[p] = delta; xb_bits[p] = bits;
+  }
+  int ya_row[NA], ya_off[NA];
 #pragma unroll
-    for (int p = 0; p < PBs; ++p) {
-      const int e = p * 256 + tid; const int r = e / GB, gq = e % GB;
-      const int m = mb + r;
-      bool ok = (e < PB * GB) && (m < mend) && (ci0 + gq * 8 < g.C);
-      int q1 = fdiv(m, g.dWo); const int wo = m - q1 * g.Wo;
-      int q2 = fdiv(q1, g.dHo); const int ho = q1 - q2 * g.Ho;
-      const int n = fdiv(q2, g.dTo); const int to = q2 - n * g.To;
-      const int ti = to * g.sT - g.pT + kt, hi = ho * g.sH - g.pH + kh, wi = wo * g.sW - g.pW + kw;
-      ok = ok && (unsigned)ti < (unsigned)g.T && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      const long off = ok ? ((((long)(n * g.T + ti) * g.H + hi) * g.W + wi) * g.C + ci0 + gq * 8) : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(x + off);
-      rb[p] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+  for (int p = 0; p < NA; ++p) {
+    const int G = (p * 4 + wave) * 64 + lane;
+    const int row = G / GA, pg = G % GA;
+    const int lg = SWA ? (pg ^ wswz(row)) : pg;
+    ya_row[p] = row; ya_off[p] = (co0 + lg * 8 < g.K) ? (co0 + lg * 8) * 2 : -1;
+  }
+
+  // rows of 4 consecutive steps (256 positions) are decoded at once by all 256 threads, every 4th step,
+  // into an 8-slot ring: slot of step s is s & 7
+  auto decode_rows = [&](int step0) {
+    {
+      const int m = mbeg + step0 * PB + tid;
+      int base = 0, mask = 0;
+      if (m < mend) {
+        const int q1 = fdiv(m, g.dWo), wo = m - q1 * g.Wo;
+        const int q2 = fdiv(q1, g.dHo), ho = q1 - q2 * g.Ho;
+        const int n = fdiv(q2, g.dTo), to = q2 - n * g.To;
+        const int t0 = to * g.sT - g.pT, h0 = ho * g.sH - g.pH, w0 = wo * g.sW - g.pW;
+        for (int k = 0; k < g.kT; ++k) mask |= ((unsigned)(t0 + k) < (unsigned)g.T) ? (1 << k) : 0;
+        for (int k = 0; k < g.kH; ++k) mask |= ((unsigned)(h0 + k) < (unsigned)g.H) ? (1 << (8 + k)) : 0;
+        for (int k = 0; k < g.kW; ++k) mask |= ((unsigned)(w0 + k) < (unsigned)g.W) ? (1 << (16 + k)) : 0;
+        base = ((n * g.T + t0) * g.H + h0) * g.W + w0;
+      }
+      rinfo[((step0 & 7) * PB + tid) & (8 * PB - 1)] = make_int2(base, mask);
     }
   };
-  auto store_tiles = [&](int buf) {
-    unsigned char* a = At + buf * PB * CO * 2;
-    unsigned char* b = Bt + buf * PB * CI * 2;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  unsigned xoff[NB];
+  auto issue_tiles = [&](int step, int buf) {
+    const int mb = mbeg + step * PB;
+    unsigned char* a = At + buf * PB * CO * 2 + wave * 1024;
+    unsigned char* b = Bt + buf * PB * NCOL * 2 + wave * 1024;
+    const int2* ri = rinfo + (step & 7) * PB;
+    // all LDS reads of the row table come BEFORE the first DMA of this tile: with an LDS-DMA in flight hipcc
+    // guards every ds_read with s_waitcnt vmcnt(0), which would serialise the DMA instructions one by one
 #pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int e = p * 256 + tid; const int r = e / GA, gq = e % GA;
-      if (e < PB * GA) *reinterpret_cast<uint4*>(a + r * (CO * 2) + ((gq ^ wswz<CO>(r)) * 16)) = ra[p];
+    for (int p = 0; p < NB; ++p) {
+      const int2 r = ri[xb_row[p]];
+      const bool ok = xb_bits[p] != 0 && (r.y & xb_bits[p]) == xb_bits[p];
+      xoff[p] = ok ? (unsigned)(r.x * c2 + xb_delta[p]) : x_bytes;
+    }
+
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      if ((p * 4 + wave) * 64 < PB * GA) {                 // wave-uniform (tiles narrower than 4 KiB)
+        const int m = mb + ya_row[p];
+        const unsigned off = (m < mend && ya_off[p] >= 0) ? (unsigned)(m * k2 + ya_off[p]) : dy_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(a + p * 4096), 16, off, 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int p = 0; p < PBs; ++p) {
-      const int e = p * 256 + tid; const int r = e / GB, gq = e % GB;
-      if (e < PB * GB) *reinterpret_cast<uint4*>(b + r * (CI * 2) + ((gq ^ wswz<CI>(r)) * 16)) = rb[p];
+    for (int p = 0; p < NB; ++p) {
+      const unsigned off = xoff[p];       // (a captured array element passed directly makes hipcc drop the host stub)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(b + p * 4096), 16, off, 0, 0, 0);
     }
   };
 
@@ -95,75 +155,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
     for (int j = 0; j < JB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-  const int nsteps = (mend > mbeg) ? (mend - mbeg + PB - 1) / PB : 0;
-  if (nsteps > 0) { load_tiles(mbeg); store_tiles(0); }
+  decode_rows(0);
+  decode_rows(4);
+  __syncthreads();
+  issue_tiles(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nsteps) load_tiles(mbeg + (s + 1) * PB);
+    if (s + 1 < nsteps) issue_tiles(s + 1, cur ^ 1);     // row info of step s+1 was published >= one barrier ago
     const unsigned char* a = At + cur * PB * CO * 2;
-    const unsigned char* b = Bt + cur * PB * CI * 2;
-    // this wave's 32 positions: rows wave*32 .. +31 ; lane (grp,qq,pp) addresses row 8*grp + 4*h + qq
-    bf16x8_t fa[IA], fb[JB];
+    const unsigned char* b = Bt + cur * PB * NCOL * 2;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) {
-      s16x4_t v[2];
+    for (int ks = 0; ks < PB / 32; ++ks) {
+      bf16x8_t fa[IA], fb[JB];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = wave * 32 + 8 * grp + 4 * h + qq;
-        const int gq = i * 2 + (pp >> 1);
-        const unsigned char* ad = a + r * (CO * 2) + ((gq ^ wswz<CO>(r)) * 16) + (pp & 1) * 8;
-        v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(ad));
+      for (int i = 0; i < IA; ++i) {
+        s16x4_t v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + 8 * grp + 4 * h + qq;
+          const int gq = i * 2 + (pp >> 1);
+          const unsigned char* ad = a + r * (CO * 2) + ((SWA ? (gq ^ wswz(r)) : gq) * 16) + (pp & 1) * 8;
+          v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(ad));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        s16x8_t w8 = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
+        fa[i] = __builtin_bit_cast(bf16x8_t, w8);
       }
-      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-      s16x8_t w8 = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
-      fa[i] = __builtin_bit_cast(bf16x8_t, w8);
-    }
 #pragma unroll
-    for (int j = 0; j < JB; ++j) {
-      s16x4_t v[2];
+      for (int j = 0; j < JB; ++j) {
+        s16x4_t v[2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = wave * 32 + 8 * grp + 4 * h + qq;
-        const int gq = j * 2 + (pp >> 1);
-        const unsigned char* bd = b + r * (CI * 2) + ((gq ^ wswz<CI>(r)) * 16) + (pp & 1) * 8;
-        v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bd));
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + 8 * grp + 4 * h + qq;
+          const int gq = (wave * WN) / 8 + j * 2 + (pp >> 1);
+          const unsigned char* bd = b + r * (NCOL * 2) + ((SWB ? (gq ^ wswz(r)) : gq) * 16) + (pp & 1) * 8;
+          v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bd));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        s16x8_t w8 = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
+        fb[j] = __builtin_bit_cast(bf16x8_t, w8);
       }
-      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-      s16x8_t w8 = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
-      fb[j] = __builtin_bit_cast(bf16x8_t, w8);
-    }
-#pragma unroll
-    for (int i = 0; i < IA; ++i)
-#pragma unroll
-      for (int j = 0; j < JB; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    if (s + 1 < nsteps) store_tiles(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- cross-wave sum through LDS, then one atomic per element ----
-  float* red = reinterpret_cast<float*>(smem);            // [CO][CI]
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
 #pragma unroll
       for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = i * 16 + (lane >> 4) * 4 + r, ci = j * 16 + (lane & 15);
-            if (w == 0) red[co * CI + ci] = acc[i][j][r]; else red[co * CI + ci] += acc[i][j][r];
-          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    if ((s & 3) == 3 && s + 5 < nsteps) decode_rows(s + 5);           // steps s+5..s+8 reuse the slots of s-3..s (all consumed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  const int KC = g.ntaps * g.C;
-  for (int e = tid; e < CO * CI; e += 256) {
-    const int co = e / CI, ci = e % CI;
-    if (co0 + co < g.K && ci0 + ci < g.C && nsteps > 0)
-      atomicAdd(&dw[(long)(co0 + co) * KC + (long)tap * g.C + ci0 + ci], red[e]);
-  }
+
+  // ---- each wave adds its CO x WN tile: D row = co, col = column within the wave's slice ----
+#pragma unroll
+  for (int i = 0; i < IA; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
+        const int col = n0 + wave * WN + j * 16 + (lane & 15);
+        if (co < g.K && col < g.ncols) atomicAdd(&dw[(long)co * g.ncols + col], acc[i][j][r]);
+      }
 }
 
 // column sums of a bf16 (rows, C) matrix into fp32 out[C] (+=): conv bias gradient
@@ -178,29 +233,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] += f[i];
   }
-  __shared__ float red[2048];
-  for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+  __shared__ float red[4 * 512];
+  block_channel_sum(s, red, G, C, 1, 0);
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) atomicAdd(&red[tg * 8 + i], s[i]);
-  __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], red[i]);
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
 }
 
-template <int CO, int CI>
+template <int CO, int NCOL>
 static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipStream_t st) {
   g.co_tiles = (g.K + CO - 1) / CO;
-  g.ci_tiles = (g.C + CI - 1) / CI;
-  const long tiles = (long)g.co_tiles * g.ci_tiles * g.ntaps;
-  long want = (1536 + tiles - 1) / tiles;                 // ~6 blocks per CU overall
-  long maxs = (g.M + 127) / 128;
+  g.col_tiles = (g.ncols + NCOL - 1) / NCOL;
+  const long tiles = (long)g.co_tiles * g.col_tiles;
+  long want = (768 + tiles - 1) / tiles;                  // ~3 blocks per CU overall
+  long maxs = (g.M + 255) / 256;                          // at least 4 steps per block
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
-  long per = ((g.M + want - 1) / want + 127) / 128 * 128;
+  long per = ((g.M + want - 1) / want + 63) / 64 * 64;
   g.per_split = (int)per;
   g.splits = (int)((g.M + per - 1) / per);
-  const size_t lds = (size_t)2 * 128 * (CO + CI) * 2 > (size_t)CO * CI * 4 ? (size_t)2 * 128 * (CO + CI) * 2 : (size_t)CO * CI * 4;
-  hipLaunchKernelGGL((conv_wgrad_kernel<CO, CI>), dim3((unsigned)(tiles * g.splits)), dim3(256), lds, st, g, x, dy, dw);
+  const size_t lds = (size_t)2 * 64 * (CO + NCOL) * 2 + (size_t)8 * 64 * sizeof(int2);
+  auto kern = conv_wgrad_kernel<CO, NCOL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * g.splits)), dim3(256), lds, st, g, x, dy, dw);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -209,26 +267,27 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
                                  float* dbias, void* stream) {
   if (!d || !x || !dy || !dw) return MSCL_E_ARG;
   if (d->C % 8 || d->K % 8) return MSCL_E_SHAPE;
-  if (ilog2_exact(d->K / 8) < 0 || d->K / 8 > 256) return MSCL_E_SHAPE;
+  if (ilog2_exact(d->K / 8) < 0 || d->K / 8 > 256 || ilog2_exact(d->C / 8) < 0) return MSCL_E_SHAPE;
+  if (d->kT > 8 || d->kH > 8 || d->kW > 8) return MSCL_E_SHAPE;
   WGeom g{};
   g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.C = d->C;
   g.To = d->To; g.Ho = d->Ho; g.Wo = d->Wo; g.K = d->K;
   g.kT = d->kT; g.kH = d->kH; g.kW = d->kW; g.sT = d->sT; g.sH = d->sH; g.sW = d->sW;
   g.pT = d->pT; g.pH = d->pH; g.pW = d->pW;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
-  if (M >= (1L << 31) - 256 || (long)d->N * d->T * d->H * d->W * d->C >= (1L << 40)) return MSCL_E_SHAPE;
-  g.M = (int)M; g.ntaps = d->kT * d->kH * d->kW;
+  if (M * d->K >= (1L << 30) || (long)d->N * d->T * d->H * d->W * d->C >= (1L << 30)) return MSCL_E_SHAPE;   // 32-bit byte offsets
+  g.M = (int)M; g.ntaps = d->kT * d->kH * d->kW; g.cgs = ilog2_exact(d->C / 8); g.ncols = g.ntaps * d->C;
   g.dWo = make_fastdiv(d->Wo); g.dHo = make_fastdiv(d->Ho); g.dTo = make_fastdiv(d->To);
   hipStream_t st = (hipStream_t)stream;
   int e;
-  const int co = d->K >= 64 ? 64 : d->K, ci = d->C >= 64 ? 64 : (d->C < 16 ? 16 : d->C);   // C=8 (padded stems) rides the 16-wide tile
-#define W(CO, CI) if (co == CO && ci == CI) { e = launch_w<CO, CI>(g, x, dy, dw, st); goto done; }
-  W(64, 64) W(64, 32) W(64, 16) W(32, 64) W(32, 32) W(32, 16) W(16, 64) W(16, 32) W(16, 16)
-#undef W
-  return MSCL_E_SHAPE;   // channel counts must be 8/16/32 or a multiple of 64
-done:
+  bool wide = false;     // NCOL = 192 (three taps share one dy tile) measured slower than 64: fewer blocks per CU
+  if (const char* f = getenv("MSCL_WGRAD_NCOL")) wide = atoi(f) == 192;
+  if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st) : launch_w<64, 64>(g, x, dy, dw, st);
+  else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st) : launch_w<32, 64>(g, x, dy, dw, st);
+  else if (d->K == 16) e = wide ? launch_w<16, 192>(g, x, dy, dw, st) : launch_w<16, 64>(g, x, dy, dw, st);
+  else return MSCL_E_SHAPE;
   if (e) return e;
-  if (dbias) {
+  if (dbias && d->K <= 512) {
     long blocks = (M + 2047) / 2048; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, dbias, M, d->K);
     MSCL_LAUNCH_CHECK();

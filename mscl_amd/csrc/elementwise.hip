@@ -194,7 +194,7 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
 // x (outer, inner, C) bf16 -> out (outer, C) fp32.  One block per (outer, 64-channel group... ) :
 // block = 256 threads = G channel-granules x (256/G) row lanes; LDS reduce.
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C) {
-  __shared__ float red[2048];
+  __shared__ float red[4 * 512];
   const int G = C >> 3;
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const long base = (long)blockIdx.x * inner * C;
@@ -204,17 +204,15 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] += f[i];
   }
-  for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) atomicAdd(&red[tg * 8 + i], s[i]);
+  block_channel_sum(s, red, G, C, 1, 0);
   __syncthreads();
   const float inv = 1.f / (float)inner;
-  for (int i = threadIdx.x; i < C; i += 256) out[(long)blockIdx.x * C + i] = red[i] * inv;
+  for (int i = threadIdx.x; i < C; i += 256)
+    out[(long)blockIdx.x * C + i] = (red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]) * inv;
 }
 extern "C" int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream) {
   if (!x || !out || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
-  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 2048) return MSCL_E_SHAPE;
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 512) return MSCL_E_SHAPE;
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer), dim3(256), 0, (hipStream_t)stream, x, out, inner, C);
   MSCL_LAUNCH_CHECK();
   return 0;

@@ -3,7 +3,8 @@
 #include "common.h"
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq,
-                                                  bf16_t* __restrict__ pkb, long n, float m) {
+                                                  bf16_t* __restrict__ pkb, long n, float m_val, const float* __restrict__ m_dev) {
+  const float m = m_dev ? *m_dev : m_val;
   const float om = 1.0f - m;
   const long n4 = n >> 2;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
@@ -22,7 +23,16 @@ extern "C" int mscl_ema_update(float* pk, const float* pq, uint16_t* pk_bf16, in
   if (!pk || !pq || n <= 0) return MSCL_E_ARG;
   if (((uintptr_t)pk | (uintptr_t)pq) & 15 || ((uintptr_t)pk_bf16 & 7)) return MSCL_E_SHAPE;
   long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, pq, pk_bf16, (long)n, m);
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, pq, pk_bf16, (long)n, m,
+                     (const float*)nullptr);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mscl_ema_update_dev(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, const float* m_dev, void* stream) {
+  if (!pk || !pq || !m_dev || n <= 0) return MSCL_E_ARG;
+  if (((uintptr_t)pk | (uintptr_t)pq) & 15 || ((uintptr_t)pk_bf16 & 7)) return MSCL_E_SHAPE;
+  long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, pq, pk_bf16, (long)n, 0.f, m_dev);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -52,7 +62,9 @@ extern "C" int mscl_sumsq(const float* g, float* out, int64_t n, void* stream) {
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   bf16_t* __restrict__ pb, long n, const float* __restrict__ sumsq,
-                                                  float max_norm, float lr, float mom, float wd, int first) {
+                                                  float max_norm, float lr_val, float mom, float wd, int first,
+                                                  const float* __restrict__ lr_dev) {
+  const float lr = lr_dev ? *lr_dev : lr_val;
   float coef = 1.f;
   if (max_norm > 0.f && sumsq) { const float tn = sqrtf(*sumsq); coef = fminf(max_norm / (tn + 1e-6f), 1.f); }
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -70,7 +82,18 @@ extern "C" int mscl_sgd_step(float* p, const float* g, float* buf, uint16_t* p_b
   if (!p || !g || !buf || n <= 0) return MSCL_E_ARG;
   long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, p_bf16, (long)n, sumsq,
-                     max_norm, lr, momentum, wd, first);
+                     max_norm, lr, momentum, wd, first, (const float*)nullptr);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+/* lr read from device memory (graph replay with a changing schedule); momentum buffers must start at zero
+ * (buf = mom*0 + d reproduces torch.optim.SGD's first-step buffer initialisation exactly) */
+extern "C" int mscl_sgd_step_dev(float* p, const float* g, float* buf, uint16_t* p_bf16, int64_t n, const float* sumsq,
+                                 float max_norm, const float* lr_dev, float momentum, float wd, void* stream) {
+  if (!p || !g || !buf || !lr_dev || n <= 0) return MSCL_E_ARG;
+  long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, p_bf16, (long)n, sumsq,
+                     max_norm, 0.f, momentum, wd, 0, lr_dev);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,70 @@
+"""Whole-step HIP-graph capture: forward + loss + backward + clip/SGD of MSCLWithAug as ONE graph launch.
+
+Why: at ~900 kernel launches per step the eager step is host-bound (24 ms wall for 18 ms of kernels on an
+MI355X).  Everything that changes from step to step is either device state (queues, counters, parameters),
+an input copied into static buffers, or a scalar that travels through a pinned staging word (EMA momentum,
+learning rate, shuffle indices) -- so the captured graph stays valid for the whole run.
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, model, optimizer, example_batch, warmup=2):
+        self.model, self.opt = model, optimizer
+        dev = model.arena.device
+        self.static = {k: [t.to(dev).clone() for t in v] for k, v in example_batch.items()}
+        self.B = self.static[model.im_key][0].shape[0]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):            # eager warm-up: touched-parameter ranges, lazy kernel attributes
+            for _ in range(warmup):
+                self._eager()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        # host-side state mutated by the (non-executing) capture pass is rolled back afterwards
+        snap = self._host_state()
+        self.graph = torch.cuda.CUDAGraph()
+        fk = model.flow_key[0]
+        model._pre_step_host(self.B)
+        with torch.cuda.graph(self.graph):
+            loss, logs = model._device_step(self.static[model.im_key][0], self.static[model.im_key][1],
+                                            self.static[fk][0], self.static[fk][1])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        self._restore(snap)
+        self.loss, self.logs = loss.detach(), logs
+
+    def _eager(self):
+        out = self.model.train_step(self.static, sync_logs=False)
+        self.opt.zero_grad()
+        out['loss'].backward()
+        self.opt.step()
+
+    def _host_state(self):
+        m = self.model
+        return dict(step=m._step, steps=self.opt.steps,
+                    rec=[(r.iters, r.batch_size, r.m) for r in (m.recognizer, m.recognizer_flow)])
+
+    def _restore(self, s):
+        m = self.model
+        m._step, self.opt.steps = s['step'], s['steps']
+        for r, (it, bs, mm) in zip((m.recognizer, m.recognizer_flow), s['rec']):
+            r.iters, r.batch_size, r.m = it, bs, mm
+
+    def step(self, batch):
+        """one training step on `batch` (device tensors); returns (loss, logs) as static device tensors."""
+        for k, v in self.static.items():
+            for dst, src in zip(v, batch[k]):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        self.model._pre_step_host(self.B)
+        self.opt.sync_lr()
+        self.graph.replay()
+        self.model._post_step_host()
+        self.opt.steps += 1
+        return self.loss, self.logs
+
+    def log_vars(self):
+        return self.model._parse_logs(self.logs, True)

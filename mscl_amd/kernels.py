@@ -283,6 +283,15 @@ def ema_update(pk, pq, pk_bf16, m):
     call('mscl_ema_update', ptr(pk), ptr(pq), ptr(pk_bf16), pk.numel(), float(m), stream_ptr())
 
 
+def ema_update_dev(pk, pq, pk_bf16, m_dev):
+    call('mscl_ema_update_dev', ptr(pk), ptr(pq), ptr(pk_bf16), pk.numel(), ptr(m_dev), stream_ptr())
+
+
+def sgd_step_dev(p, g, buf, p_bf16, sumsq_t, max_norm, lr_dev, momentum, wd):
+    call('mscl_sgd_step_dev', ptr(p), ptr(g), ptr(buf), ptr(p_bf16), p.numel(), ptr(sumsq_t), float(max_norm), ptr(lr_dev),
+         float(momentum), float(wd), stream_ptr())
+
+
 def sumsq(g, out):
     call('mscl_sumsq', ptr(g), ptr(out), g.numel(), stream_ptr())
 

@@ -57,6 +57,8 @@ _SIGS = {
     'mscl_queue_enqueue': [P, P, P, P, c_int, c_int, c_int, P],
     'mscl_lmcl': [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'mscl_ema_update': [P, P, P, c_int64, c_float, P],
+    'mscl_ema_update_dev': [P, P, P, c_int64, P, P],
+    'mscl_sgd_step_dev': [P, P, P, P, c_int64, P, c_float, P, c_float, c_float, P],
     'mscl_sumsq': [P, P, c_int64, P],
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],

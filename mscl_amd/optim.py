@@ -28,6 +28,9 @@ class ClipSGD:
         self._ranges = None
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay)]
+        # lr travels through a pinned staging word -> device word, so a captured graph sees schedule changes
+        self._lr_host = torch.full((1,), float(lr), dtype=torch.float32).pin_memory()
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.arena.device)
 
     @classmethod
     def from_cfg(cls, model, optimizer, optimizer_config=None):
@@ -56,9 +59,14 @@ class ClipSGD:
             raise RuntimeError('the set of parameters receiving gradients changed between steps')
         self._sumsq.zero_()
         K.sumsq(ar.G, self._sumsq)
-        lr = self.param_groups[0]['lr']
-        for a, b in ranges:
-            K.sgd_step(ar.Q[a:b], ar.G[a:b], ar.MOM[a:b], ar.Qb[a:b], self._sumsq, self.max_norm, lr, self.momentum,
-                       self.wd, first=(self.steps == 0))
+        self.sync_lr()
+        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+        for a, b in ranges:     # momentum buffers start at zero: buf = mom*0 + d == torch's first-step buf = d
+            K.sgd_step_dev(ar.Q[a:b], ar.G[a:b], ar.MOM[a:b], ar.Qb[a:b], self._sumsq, self.max_norm, self._lr_dev,
+                           self.momentum, self.wd)
         self.model.refresh_after_optimizer()
         self.steps += 1
+
+    def sync_lr(self):
+        """publish param_groups[0]['lr'] to the pinned staging word (call before a graph replay)"""
+        self._lr_host[0] = float(self.param_groups[0]['lr'])

@@ -99,12 +99,13 @@ class MoCoV2(nn.Module):
                         'contrastive kernels); use queue / count')
 
     @torch.no_grad()
-    def momentum_update(self, iters=None):
-        """ref: moco.py:408-421 -- one kernel over this recognizer's contiguous arena range."""
-        self.m = momentum_at(self.iters if iters is None else iters, self.max_iters, self.m_base)
+    def momentum_update(self, m_dev):
+        """ref: moco.py:408-421 -- one kernel over this recognizer's contiguous arena range.  The momentum
+        value is read from device memory (`m_dev`, written by MSCLWithAug._pre_step_host through a pinned
+        staging buffer) so that a captured HIP graph follows the cosine schedule."""
         a, b = self._range
         ar = self._arena
-        K.ema_update(ar.KX[a:b], ar.Q[a:b], ar.Kb[a:b], self.m)
+        K.ema_update_dev(ar.KX[a:b], ar.Q[a:b], ar.Kb[a:b], m_dev)
         for fn in self._k_refresh:
             fn()
 
@@ -123,8 +124,7 @@ class MoCoV2(nn.Module):
     def dequeue_and_enqueue(self, keys):
         """ref: moco.py:423-440 (keys are all-gathered first; bookkeeping is bit-exact int64 on device)."""
         keys = parallel.all_gather_cat(keys)
-        self.batch_size = keys.shape[0]
-        if self.K % self.batch_size != 0:
+        if self.K % keys.shape[0] != 0:
             raise AssertionError('K % batch_size == 0 (moco.py:432)')
         K.queue_enqueue(self.queue, self.count, self.queue_ptr, keys.contiguous())
 
@@ -232,6 +232,8 @@ class MSCLWithAug(nn.Module):
         self.arena = None
         self._log_keys = LOG_KEYS
         self._step = 0
+        self._scal_host = self._scal_dev = None
+        self._bg = 0
 
     # ------------------------------------------------------------------ device placement
     def materialize(self, device='cuda'):
@@ -387,35 +389,82 @@ class MSCLWithAug(nn.Module):
         """ref: mscl.py:225-277."""
         if self.arena is None:
             raise MsclError('call model.materialize("cuda") before the first step')
-        rec, recf = self.recognizer, self.recognizer_flow
         fk = self.flow_key[0]
-        flow_q, flow_k = aux_info[f'{fk}_q'], aux_info[f'{fk}_k']
+        self._pre_step_host(im_q.shape[0])
+        loss, logs = self._device_step(im_q, im_k, aux_info[f'{fk}_q'], aux_info[f'{fk}_k'])
+        self._post_step_host()
+        return loss, logs
+
+    # The step is split into host bookkeeping (Python ints / the momentum schedule) and device work, so that
+    # the device work can be captured once into a HIP graph and replayed (mscl_amd/graph.py).
+    def _pre_step_host(self, B):
+        rec, recf = self.recognizer, self.recognizer_flow
+        W = parallel.world_size()
+        bg = B * W
+        if self._scal_host is None:
+            dev = self.arena.device
+            self._scal_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._scal_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._idx_host = torch.zeros((6, B), dtype=torch.long).pin_memory()
+            self._idx_dev = torch.zeros((6, B), dtype=torch.long, device=dev)
+        rec.m = momentum_at(rec.iters, rec.max_iters, rec.m_base)
+        m1 = momentum_at(recf.iters, recf.max_iters, recf.m_base)
+        recf.m = momentum_at(recf.iters + (bg if self.training else 0), recf.max_iters, recf.m_base)   # value after the 2nd pass
+        self._scal_host[0], self._scal_host[1], self._scal_host[2] = rec.m, m1, recf.m
+        if W > 1:
+            r = parallel.rank()
+            for slot in range(3):
+                perm = parallel.shuffle_perm(W * B, self._step, slot)
+                self._idx_host[slot] = perm.view(W, B)[r]
+                self._idx_host[3 + slot] = torch.argsort(perm).view(W, B)[r]
+        self._bg = bg
+
+    def _post_step_host(self):
+        rec, recf = self.recognizer, self.recognizer_flow
+        rec.batch_size = recf.batch_size = self._bg
+        if self.training:                       # moco.py:504-505; the flow recognizer ran twice
+            rec.iters += rec.batch_size
+            recf.iters += 2 * recf.batch_size
+        self._step += 1
+
+    def _shuffle(self, x, slot):
+        if parallel.world_size() == 1:
+            return x          # a within-batch permutation does not change per-GPU BN statistics
+        return parallel.all_gather_cat(x).index_select(0, self._idx_dev[slot])
+
+    def _unshuffle(self, k, slot):
+        if parallel.world_size() == 1:
+            return k
+        return parallel.all_gather_cat(k).index_select(0, self._idx_dev[3 + slot])
+
+    def _device_step(self, im_q, im_k, flow_q, flow_k):
+        rec, recf = self.recognizer, self.recognizer_flow
         T2 = flow_q.shape[2]
         if T2 % 2:
             raise ValueError('flow clips must hold base and rotated halves along T')
         Th = T2 // 2
         aug = self.aug_gpu
-        B = im_q.shape[0]
-        bg = B * parallel.world_size()
         K.ZEROS.reset(im_q.device)
-        step = self._step
+        self._scal_dev.copy_(self._scal_host, non_blocking=True)
+        if parallel.world_size() > 1:
+            self._idx_dev.copy_(self._idx_host, non_blocking=True)
+        sc = self._scal_dev
         # -- RGB stream
         x_q = aug.pack_rgb(im_q)
-        x_k = aug.pack_rgb(parallel.shuffle_select(im_k, step, 0))
-        rec.momentum_update()
+        x_k = aug.pack_rgb(self._shuffle(im_k, 0))
+        rec.momentum_update(sc[0:1])
         q_rgb, maps_rgb = rec.encode_q(x_q)
         k_rgb, _ = rec.encode_k(x_k)
-        k_rgb = parallel.unshuffle_select(k_rgb, step, 0)
+        k_rgb = self._unshuffle(k_rgb, 0)
         # -- flow stream, base then rotated (two EMA updates, two BN-statistics passes; App. E-5)
-        iters0 = recf.iters
-        recf.momentum_update(iters0)
+        recf.momentum_update(sc[1:2])
         q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th))
-        k_fb, _ = recf.encode_k(aug.pack_flow(parallel.shuffle_select(flow_k, step, 1), 0, Th))
-        k_fb = parallel.unshuffle_select(k_fb, step, 1)
-        recf.momentum_update(iters0 + (bg if self.training else 0))
+        k_fb, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 1), 0, Th))
+        k_fb = self._unshuffle(k_fb, 1)
+        recf.momentum_update(sc[2:3])
         q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th))
-        k_fa, _ = recf.encode_k(aug.pack_flow(parallel.shuffle_select(flow_k, step, 2), Th, Th))
-        k_fa = parallel.unshuffle_select(k_fa, step, 2)
+        k_fa, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 2), Th, Th))
+        k_fa = self._unshuffle(k_fa, 2)
         # -- LMCL inputs (local_cl_head.py:57-62): TPN level 0 of RGB, raw layer-4 maps of both flow passes
         ids = self.sup_head.mlvl_ids
         m_rgb, m_fb, m_fa = maps_rgb[ids[0]], maps_fb[ids[1]], maps_fa[ids[1]]
@@ -426,12 +475,7 @@ class MSCLWithAug(nn.Module):
         if m_rgb.shape[1] != m_fb.shape[1] or m_rgb.shape[1] != self.sup_head.t:
             raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {m_fb.shape[1]}, head t={self.sup_head.t}')
         self._dbg = dict(q_rgb=q_rgb.detach(), q_fb=q_fb.detach(), q_fa=q_fa.detach(), k_rgb=k_rgb, k_fb=k_fb, k_fa=k_fa)
-        loss, logs = _MSCLLossFn.apply(q_rgb, q_fb, q_fa, p_rgb, p_fb, p_fa, k_rgb, k_fb, k_fa, self)
-        if self.training:                       # moco.py:504-505; the flow recognizer ran twice
-            rec.iters += rec.batch_size
-            recf.iters += 2 * recf.batch_size
-        self._step += 1
-        return loss, logs
+        return _MSCLLossFn.apply(q_rgb, q_fb, q_fa, p_rgb, p_fb, p_fa, k_rgb, k_fb, k_fa, self)
 
     def forward_test(self, imgs):
         raise NotImplementedError('Not support for ssl recognizer !!!')
