@@ -436,7 +436,7 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   if (g.ksplit > 1) {
     const long rows = out_elems / g.Cr;
     const int RP = 256 / (g.Cr / 8);
-    long fb = (rows + RP * 4 - 1) / (RP * 4); if (fb > 1024) fb = 1024; if (fb < 1) fb = 1;
+    long fb = (rows + RP - 1) / RP; if (fb > 2048) fb = 2048; if (fb < 1) fb = 1;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
                        rows, g.Cr, g.ksplit);
     MSCL_LAUNCH_CHECK();
@@ -577,12 +577,40 @@ extern "C" int mscl_weight_transpose(const uint16_t* w, uint16_t* wT, int Cout, 
 
 // all kernels of a model in one launch: table[i] = {src ptr, dst ptr, Cout, taps, Cin, first block}
 struct TransposeEntry { const bf16_t* w; bf16_t* wT; int Cout, taps, Cin, first_block; };
+// Entry i owns blocks [first_block_i, first_block_{i+1}).  Kernels whose channel counts are multiples of 64 are
+// moved as 64x64 (co x ci) tiles of one tap through LDS: 128-byte rows in, 128-byte rows out (the element-wise
+// form reads 2-byte elements at a stride of taps*Cin and took 460 us for the 37 M weights of a step).
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const TransposeEntry* __restrict__ table, int n) {
+  __shared__ bf16_t tile[64][66];
   int e = 0;
   for (int i = 1; i < n; ++i) if ((int)blockIdx.x >= table[i].first_block) e = i;      // uniform scan, n ~ 40
   const TransposeEntry t = table[e];
+  const int lb = blockIdx.x - t.first_block;
+  if ((t.Cout & 63) == 0 && (t.Cin & 63) == 0) {
+    const int cit = t.Cin >> 6, cot = t.Cout >> 6;
+    const int tiles = cit * cot * t.taps;
+    if (lb >= tiles) return;
+    const int ci0 = (lb % cit) << 6; const int r = lb / cit;
+    const int co0 = (r % cot) << 6; const int tap = r / cot;
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {            // 64 rows (co) x 8 granules (ci)
+      const int row = i >> 3, gq = i & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(t.w + ((long)(co0 + row) * t.taps + tap) * t.Cin + ci0 + gq * 8);
+      const bf16_t* pv = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[row][gq * 8 + k] = pv[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {            // 64 rows (ci) x 8 granules (co)
+      const int row = i >> 3, gq = i & 7;
+      bf16_t o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = tile[gq * 8 + k][row];
+      *reinterpret_cast<uint4*>(t.wT + ((long)(ci0 + row) * t.taps + tap) * t.Cout + co0 + gq * 8) = *reinterpret_cast<uint4*>(o);
+    }
+    return;
+  }
   const long total = (long)t.Cout * t.taps * t.Cin;
-  const long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x;
+  const long i = (long)lb * 256 + threadIdx.x;
   if (i >= total) return;
   const int co = (int)(i % t.Cout); const long r = i / t.Cout;
   const int tap = (int)(r % t.taps); const int ci = (int)(r / t.taps);

@@ -288,7 +288,8 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   else return MSCL_E_SHAPE;
   if (e) return e;
   if (dbias && d->K <= 512) {
-    long blocks = (M + 2047) / 2048; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    const int RPc = 256 / (d->K / 8);
+    long blocks = (M + RPc * 2 - 1) / (RPc * 2); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, dbias, M, d->K);
     MSCL_LAUNCH_CHECK();
   }

@@ -81,7 +81,8 @@ def build_transpose_table(entries, device):
     raw, first = b'', 0
     for w, wT, co, taps, ci in entries:
         raw += struct.pack('<QQiiii', w.data_ptr(), wT.data_ptr(), co, taps, ci, first)
-        first += (co * taps * ci + 255) // 256
+        # block ownership must mirror weight_transpose_batched_kernel: 64x64 tiles per tap, else 256 elements
+        first += (co // 64) * (ci // 64) * taps if (co % 64 == 0 and ci % 64 == 0) else (co * taps * ci + 255) // 256
     table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     return table, len(entries), first
 

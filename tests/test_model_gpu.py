@@ -168,18 +168,20 @@ def test_state_dict_roundtrip(dev):
 
 
 def test_graphed_step_matches_eager(dev):
-    """The captured-graph step must produce the same device state as eager launches (same kernels, same order)."""
+    """The captured-graph step must behave like eager launches: integer state identical, floats within the
+    run-to-run noise of the eager path itself (fp32 atomics reorder between runs and batch-2 BatchNorm amplifies
+    that chaotically) -- calibrated live with a second eager run."""
     from mscl_amd import ClipSGD
     from mscl_amd.graph import GraphedStep
     from mscl_amd.synthetic import synthetic_batch
     B, T, H, Kq = 2, 8, 32, 64
     runs = []
-    for use_graph in (False, True):
+    for mode in ('eager', 'eager', 'graph'):
         model, cfg = build(T, Kq, dev)
         opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
         batches = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(5)]
         losses = []
-        if use_graph:
+        if mode == 'graph':
             gs = GraphedStep(model, opt, batches[0], warmup=2)        # 2 eager warm-up steps on batch 0
             for s in range(3):
                 losses.append(float(gs.step(batches[s])[0]))
@@ -190,12 +192,12 @@ def test_graphed_step_matches_eager(dev):
                 losses.append(float(out['loss'].detach()))
             losses = losses[2:]
         runs.append((losses, model.arena.Q.clone(), model.recognizer.count.clone(), int(model.recognizer.queue_ptr),
-                     model.recognizer_flow.iters, model.recognizer.m))
-    (l0, q0, c0, p0, i0, m0), (l1, q1, c1, p1, i1, m1) = runs
-    assert p0 == p1 and i0 == i1 and m0 == m1 and torch.equal(c0, c1)
-    # fp32 atomics (BN statistics, weight gradients) reorder between runs and batch-2 BatchNorm amplifies
-    # that by ~500x per step, so floats are compared loosely; integer state is exact
-    for a, b in zip(l0, l1):
-        assert abs(a - b) <= 0.03 * max(1.0, abs(a)), (l0, l1)
+                     model.recognizer_flow.iters, model.recognizer.m, model.recognizer_flow.count.clone()))
+    (l0, q0, c0, p0, i0, m0, f0), (l0b, q0b, _, _, _, _, _), (l1, q1, c1, p1, i1, m1, f1) = runs
+    assert p0 == p1 and i0 == i1 and m0 == m1 and torch.equal(c0, c1) and torch.equal(f0, f1)
+    noise = float((q0 - q0b).norm() / q0.norm())
     rel = float((q0 - q1).norm() / q0.norm())
-    assert rel < 5e-3, rel
+    assert rel <= 3.0 * noise + 1e-3, (rel, noise)
+    lnoise = max(abs(a - b) for a, b in zip(l0, l0b))
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 3.0 * lnoise + 1e-3 * max(1.0, abs(a)), (l0, l0b, l1)
