@@ -44,6 +44,12 @@ int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* 
  * the layer has too few position tiles to fill 256 CUs, the K loop is split over the grid (one fp32 slab
  * per split, then a summing finalize pass that also applies the epilogue and the BN statistics). */
 
+/* Specialised 3x3x3 / stride 1 / pad 1 / 64->64 path (halo-resident window in LDS, conv_halo.hip); mode 0 =
+ * forward (w laid out [Cout][tap][Cin]), 1 = input gradient (wT laid out [Cin][tap][Cout]).  Returns 1 when it
+ * handled the shape, 0 when the shape is not covered (mscl_conv3d_fwd / _dgrad call it first and fall back). */
+int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
+                     const uint16_t* addend, float* stat_sum, float* stat_sq, void* stream);
+
 /* dx = conv_transpose(dy, w) [+ addend]; wT_bf16 is the kernel re-laid out [Cin][kT][kH][kW][Cout]
  * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient. */
 int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT_bf16, uint16_t* dx,

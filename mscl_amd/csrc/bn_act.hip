@@ -209,9 +209,7 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
   if (want_identity_dres && !dres) return MSCL_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int RP = 256 / (C / 8);
-  // one row per thread until the grid is full: a thread that walks 8 rows serially pays 8 dependent
-  // HBM/L2 round trips (~15 us on small maps, measured), more blocks overlap them
-  long blocks = (rows + RP - 1) / RP; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  long blocks = (rows + RP * 8 - 1) / (RP * 8); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;   // wider grids measured slower (more atomics)
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)12 * C * sizeof(float), st, dout,
                      out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu);
   MSCL_LAUNCH_CHECK();

@@ -500,12 +500,21 @@ static int check_desc(const mscl_conv_desc* d) {
   return 0;
 }
 
+extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
+                                const uint16_t* addend, float* ssum, float* ssq, void* stream);
+// opt-in: the halo-resident kernel ties the implicit-GEMM one on layer 1 (179 vs 177 us), see DESIGN.md
+static bool halo_enabled() { const char* e = getenv("MSCL_HALO"); return e && e[0] == '1'; }
+
 extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w, uint16_t* y,
                                const float* bias, const uint16_t* addend, int relu, float* ssum, float* ssq,
                                float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!x || !w || !y) return MSCL_E_ARG;
   if ((ssum == nullptr) != (ssq == nullptr)) return MSCL_E_ARG;
+  if (bias == nullptr && !relu && halo_enabled()) {           // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
+    const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
   IGemmGeom g{};
   g.N = d->N; g.Ts = d->T; g.Hs = d->H; g.Ws = d->W; g.Cs = d->C;
   g.Tr = d->To; g.Hr = d->Ho; g.Wr = d->Wo; g.Cr = d->K;
@@ -521,6 +530,10 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
                                  const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!dy || !wT || !dx) return MSCL_E_ARG;
+  if (halo_enabled()) {
+    const int h = mscl_conv_halo64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
   IGemmGeom g{};
   g.N = d->N; g.Ts = d->To; g.Hs = d->Ho; g.Ws = d->Wo; g.Cs = d->K;
   g.Tr = d->T; g.Hr = d->H; g.Wr = d->W; g.Cr = d->C;

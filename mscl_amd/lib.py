@@ -32,6 +32,7 @@ P = c_void_p
 _SIGS = {
     'mscl_abi_version': [],
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
+    'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
     'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P],
     'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],

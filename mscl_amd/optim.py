@@ -41,6 +41,7 @@ class ClipSGD:
         return cls(model, grad_clip=clip, **o)
 
     def zero_grad(self):
+        self.model.sync_streams()
         self.arena.G.zero_()
 
     def grad_norm(self):
@@ -50,6 +51,7 @@ class ClipSGD:
     @torch.no_grad()
     def step(self):
         ar = self.arena
+        self.model.sync_streams()
         self.model.flush_padded_grads()
         parallel.allreduce_mean_(ar.G)
         ranges = ar.active_ranges()

@@ -234,6 +234,8 @@ class MSCLWithAug(nn.Module):
         self._step = 0
         self._scal_host = self._scal_dev = None
         self._bg = 0
+        self.two_streams = True
+        self._side = None
 
     # ------------------------------------------------------------------ device placement
     def materialize(self, device='cuda'):
@@ -427,6 +429,17 @@ class MSCLWithAug(nn.Module):
             recf.iters += 2 * recf.batch_size
         self._step += 1
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.arena.device)
+        return self._side
+
+    def sync_streams(self):
+        """make the current stream wait for the flow stream (parameter gradients are written by kernels, not by
+        autograd's AccumulateGrad, so the optimizer orders itself explicitly)"""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _shuffle(self, x, slot):
         if parallel.world_size() == 1:
             return x          # a within-batch permutation does not change per-GPU BN statistics
@@ -449,6 +462,29 @@ class MSCLWithAug(nn.Module):
         if parallel.world_size() > 1:
             self._idx_dev.copy_(self._idx_host, non_blocking=True)
         sc = self._scal_dev
+        ids = self.sup_head.mlvl_ids
+        hw = lambda m: m.shape[2] * m.shape[3]
+        # The flow stream (thin 2-D ResNet: ~100 small, latency-bound launches forward and as many backward) is
+        # independent of the RGB stream until the loss, so it runs on a second HIP stream and fills the CUs the
+        # big RGB kernels leave idle; autograd replays each node's backward on its forward stream, so the two
+        # backward passes overlap too.  World size > 1 keeps one stream (the collectives share one communicator).
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if (self.two_streams and parallel.world_size() == 1) else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            # -- flow stream, base then rotated (two EMA updates, two BN-statistics passes; App. E-5)
+            recf.momentum_update(sc[1:2])
+            q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th))
+            k_fb, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 1), 0, Th))
+            k_fb = self._unshuffle(k_fb, 1)
+            recf.momentum_update(sc[2:3])
+            q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th))
+            k_fa, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 2), Th, Th))
+            k_fa = self._unshuffle(k_fa, 2)
+            m_fb, m_fa = maps_fb[ids[1]], maps_fa[ids[1]]
+            p_fb = pool(m_fb, m_fb.shape[0] * m_fb.shape[1], hw(m_fb))
+            p_fa = pool(m_fa, m_fa.shape[0] * m_fa.shape[1], hw(m_fa))
         # -- RGB stream
         x_q = aug.pack_rgb(im_q)
         x_k = aug.pack_rgb(self._shuffle(im_k, 0))
@@ -456,22 +492,13 @@ class MSCLWithAug(nn.Module):
         q_rgb, maps_rgb = rec.encode_q(x_q)
         k_rgb, _ = rec.encode_k(x_k)
         k_rgb = self._unshuffle(k_rgb, 0)
-        # -- flow stream, base then rotated (two EMA updates, two BN-statistics passes; App. E-5)
-        recf.momentum_update(sc[1:2])
-        q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th))
-        k_fb, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 1), 0, Th))
-        k_fb = self._unshuffle(k_fb, 1)
-        recf.momentum_update(sc[2:3])
-        q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th))
-        k_fa, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 2), Th, Th))
-        k_fa = self._unshuffle(k_fa, 2)
         # -- LMCL inputs (local_cl_head.py:57-62): TPN level 0 of RGB, raw layer-4 maps of both flow passes
-        ids = self.sup_head.mlvl_ids
-        m_rgb, m_fb, m_fa = maps_rgb[ids[0]], maps_fb[ids[1]], maps_fa[ids[1]]
-        hw = lambda m: m.shape[2] * m.shape[3]
+        m_rgb = maps_rgb[ids[0]]
         p_rgb = pool(m_rgb, m_rgb.shape[0] * m_rgb.shape[1], hw(m_rgb))
-        p_fb = pool(m_fb, m_fb.shape[0] * m_fb.shape[1], hw(m_fb))
-        p_fa = pool(m_fa, m_fa.shape[0] * m_fa.shape[1], hw(m_fa))
+        if side is not main:
+            main.wait_stream(side)
+            for tns in (q_fb, k_fb, q_fa, k_fa, p_fb, p_fa):
+                tns.record_stream(main)
         if m_rgb.shape[1] != m_fb.shape[1] or m_rgb.shape[1] != self.sup_head.t:
             raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {m_fb.shape[1]}, head t={self.sup_head.t}')
         self._dbg = dict(q_rgb=q_rgb.detach(), q_fb=q_fb.detach(), q_fa=q_fa.detach(), k_rgb=k_rgb, k_fb=k_fb, k_fa=k_fa)

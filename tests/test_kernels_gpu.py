@@ -48,6 +48,7 @@ CONV_CASES = [
     ('stem_rgb', 1, 4, 20, 20, 8, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
     ('stem_flow', 1, 4, 20, 20, 8, 16, (1, 7, 7), (2, 2, 2), (0, 3, 3)),
     ('big_m_tail', 3, 5, 13, 11, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('l1_plane_56', 1, 3, 56, 56, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # real layer-1 plane: 13 halo tiles, last partial
 ]
 
 
