@@ -174,8 +174,10 @@ int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, int32_t* hit
 int mscl_ema_update(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, float m, void* stream);
 /* same with m read from device memory, so a captured HIP graph can follow the cosine momentum schedule */
 int mscl_ema_update_dev(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, const float* m_dev, void* stream);
-/* sum of squares of g into *out (fp32, caller-zeroed): first half of clip_grad_norm_ */
-int mscl_sumsq(const float* g, float* out, int64_t n, void* stream);
+/* *out = sum of squares of g (fp32, overwritten): first half of clip_grad_norm_.  Bit-reproducible (no atomics): every
+ * data-parallel replica derives the same clip coefficient from the same all-reduced gradient.  `partials` is caller
+ * scratch of n_partials floats (one per block of the first phase; 1024 is the most that is used). */
+int mscl_sumsq(const float* g, float* out, int64_t n, float* partials, int n_partials, void* stream);
 /* second half + torch.optim.SGD (momentum, dampening 0, no nesterov), mmcv OptimizerHook wiring at
  * mmaction/apis/train.py:111-119: coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)) (coef = 1 when max_norm <= 0);
  * g = g*coef + wd*p; buf = first ? g : mom*buf + g; p -= lr*buf; p_bf16 = bf16(p).

@@ -37,7 +37,10 @@ extern "C" int mscl_ema_update_dev(float* pk, const float* pq, uint16_t* pk_bf16
   return 0;
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long n) {
+/* Deterministic two-phase sum of squares: every data-parallel replica must derive the SAME clip coefficient from the
+ * same all-reduced gradient, or the replicas drift apart (there is no parameter broadcast after step 0).  Phase 1
+ * writes one partial per block (fixed grid-stride order), phase 2 adds the partials in a fixed tree -- no atomics. */
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, float* __restrict__ partial, long n) {
   __shared__ float red[4];
   float s = 0.f;
   const long n4 = n >> 2;
@@ -49,13 +52,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-extern "C" int mscl_sumsq(const float* g, float* out, int64_t n, void* stream) {
-  if (!g || !out || n <= 0) return MSCL_E_ARG;
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int np, float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)red[0];
+}
+extern "C" int mscl_sumsq(const float* g, float* out, int64_t n, float* partials, int n_partials, void* stream) {
+  if (!g || !out || !partials || n <= 0 || n_partials < 1) return MSCL_E_ARG;
   if ((uintptr_t)g & 15) return MSCL_E_SHAPE;
   long blocks = (n / 4 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, out, (long)n);
+  if (blocks > n_partials) blocks = n_partials;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, partials, (long)n);
+  MSCL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)blocks, out);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -293,8 +293,15 @@ def sgd_step_dev(p, g, buf, p_bf16, sumsq_t, max_norm, lr_dev, momentum, wd):
          float(momentum), float(wd), stream_ptr())
 
 
+_SUMSQ_PARTIALS = {}
+
+
 def sumsq(g, out):
-    call('mscl_sumsq', ptr(g), ptr(out), g.numel(), stream_ptr())
+    """out[0] = sum(g^2), bit-reproducible (two-phase, no atomics)"""
+    part = _SUMSQ_PARTIALS.get(g.device)
+    if part is None:
+        part = _SUMSQ_PARTIALS[g.device] = torch.empty(1024, dtype=torch.float32, device=g.device)
+    call('mscl_sumsq', ptr(g), ptr(out), g.numel(), ptr(part), part.numel(), stream_ptr())
 
 
 def sgd_step(p, g, buf, p_bf16, sumsq_t, max_norm, lr, momentum, wd, first):

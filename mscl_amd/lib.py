@@ -60,7 +60,7 @@ _SIGS = {
     'mscl_ema_update': [P, P, P, c_int64, c_float, P],
     'mscl_ema_update_dev': [P, P, P, c_int64, P, P],
     'mscl_sgd_step_dev': [P, P, P, P, c_int64, P, c_float, P, c_float, c_float, P],
-    'mscl_sumsq': [P, P, c_int64, P],
+    'mscl_sumsq': [P, P, c_int64, P, c_int, P],
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }

@@ -112,6 +112,12 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
     return dx, dres
 
 
+def _bucket_done(mod):
+    """data-parallel hook: this module's backward completes a gradient bucket -> start its all-reduce now"""
+    for red, i in getattr(mod, '_grad_buckets', ()):
+        red.bucket_done(i)
+
+
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, stem):
@@ -126,6 +132,12 @@ class _StemFn(torch.autograd.Function):
         x, y, out, save = ctx.saved_tensors
         conv, bn = ctx.stem[0], ctx.stem[1]
         cba_bwd(conv, bn, dout.contiguous(), out, y, save, x, True, need_dx=False)
+        fl = conv._rt.get('dw8_flush')
+        if fl is not None:                      # 3-channel stem: fold the 8-channel staging gradient into the arena now,
+            dw8, gview, cin = fl                # so the bucket all-reduce launched below sees it
+            gview.add_(dw8[..., :cin])
+            dw8.zero_()
+        _bucket_done(ctx.stem)
         return None, None, None
 
 
@@ -169,6 +181,7 @@ class _BlockFn(torch.autograd.Function):
         else:
             shortcut_grad = dz
         dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
+        _bucket_done(block)
         return dx, None
 
 

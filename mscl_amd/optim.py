@@ -53,7 +53,10 @@ class ClipSGD:
         ar = self.arena
         self.model.sync_streams()
         self.model.flush_padded_grads()
-        parallel.allreduce_mean_(ar.G)
+        if getattr(self.model, 'reducer', None) is not None:
+            self.model.reducer.finish()         # buckets were launched from backward; wait for them
+        else:
+            parallel.allreduce_mean_(ar.G)
         ranges = ar.active_ranges()
         if self._ranges is None:
             self._ranges = ranges

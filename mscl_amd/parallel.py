@@ -30,7 +30,10 @@ def all_gather_cat(t):
         return t
     t = t.contiguous()
     out = torch.empty((world_size() * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t) if t.is_cuda else dist.all_gather(list(out.chunk(world_size())), t)
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(out, t)
+    else:
+        dist.all_gather(list(out.chunk(world_size())), t)
     return out
 
 
@@ -74,6 +77,51 @@ def bucket_plan(total, bucket_elems):
     return out
 
 
+def _sum_then_scale():
+    """gloo has no ReduceOp.AVG (CPU tests, and the 1-GPU 2-rank GPU test); RCCL does"""
+    return dist.get_backend() != 'nccl'
+
+
+class GradReducer:
+    """Bucketed, overlapped mean all-reduce of the flat gradient arena.
+
+    Buckets are contiguous arena ranges in the order backward finishes them (projection MLP + neck, layer4,
+    layer3, layer2 .. stem; the flow trunk last).  `bucket_done(i)` is called from the backward of the module
+    that completes a bucket: the all-reduce is issued at once (async) and runs on the communicator's stream
+    while backward continues with the earlier layers; `finish()` waits for all of them before the optimizer.
+    Layer 4 alone is 100 MB of the 150 MB: it is reduced under the whole layer3..stem backward."""
+
+    def __init__(self, flat, ranges, need=None):
+        self.flat, self.ranges = flat, list(ranges)
+        self.need = list(need) if need is not None else [1] * len(self.ranges)   # trigger calls that complete a bucket
+        self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)
+
+    def bucket_done(self, i, force=False):
+        if world_size() == 1 or i in self.launched:
+            return
+        self.hits[i] += 1
+        if self.hits[i] < self.need[i] and not force:
+            return                                  # e.g. the flow trunk is traversed twice per step
+        self.launched.add(i)
+        a, b = self.ranges[i]
+        seg = self.flat[a:b]
+        if _sum_then_scale():
+            self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), seg))
+        else:
+            self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True), None))
+
+    def finish(self):
+        if world_size() == 1:
+            return
+        for i in range(len(self.ranges)):          # anything a trigger missed (e.g. unused branches)
+            self.bucket_done(i, force=True)
+        for w, seg in self.works:
+            w.wait()
+            if seg is not None:
+                seg.div_(world_size())
+        self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)
+
+
 @torch.no_grad()
 def allreduce_mean_(flat, bucket_elems=8 << 20):
     """average a flat gradient buffer over the replicas, bucket by bucket (async, waited at the end).
@@ -85,7 +133,7 @@ def allreduce_mean_(flat, bucket_elems=8 << 20):
     works = []
     for a, b in bucket_plan(flat.numel(), bucket_elems):
         seg = flat[a:b]
-        if flat.is_cuda:
+        if not _sum_then_scale():
             works.append(dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True))
         else:
             works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), seg))

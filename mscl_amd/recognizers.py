@@ -282,6 +282,20 @@ class MSCLWithAug(nn.Module):
                     if isinstance(m, Conv3dHip) and m._rt.get('wT') is not None:
                         entries.append((m._rt['w'], m._rt['wT'], m.out_channels, m.taps, m.in_channels))
         self._tr_table = K.build_transpose_table(entries, device)
+        # gradient all-reduce buckets (contiguous arena ranges, in backward-completion order) and their triggers
+        def span(mods):
+            slots = [p._mscl_slot for m in mods for p in m.parameters()]
+            return (min(s.off for s in slots), max(s.off + (s.numel + 63) // 64 * 64 for s in slots))
+        rgb, flw = self.recognizer, self.recognizer_flow
+        eq = rgb.encoder_q
+        # (range, trigger module whose backward completes it, traversals per step).  The neck / MLP bucket rides the
+        # RGB stem trigger: autograd's ready-queue order of neck nodes vs trunk nodes is not a contract.
+        buckets = [(span([eq.layer4]), eq.layer4[0], 1), (span([eq.layer3]), eq.layer3[0], 1),
+                   (span([eq.stem, eq.layer1, eq.layer2]), eq.stem, 1), (span([rgb.neck_q, rgb.mlp_q]), eq.stem, 1),
+                   (span([flw.encoder_q, flw.neck_q, flw.mlp_q]), flw.encoder_q.stem, 2)]
+        self.reducer = parallel.GradReducer(ar.G, [b[0] for b in buckets], need=[b[2] for b in buckets])
+        for i, (_, trig, _n) in enumerate(buckets):
+            trig._grad_buckets = getattr(trig, '_grad_buckets', ()) + ((self.reducer, i),)
         self.sync_shadows()
         return self
 
@@ -342,12 +356,9 @@ class MSCLWithAug(nn.Module):
 
     @torch.no_grad()
     def flush_padded_grads(self):
-        """fold the stems' 8-channel gradient staging buffers into the arena (3 real channels)."""
-        for rec in (self.recognizer, self.recognizer_flow):
-            conv = rec.encoder_q.stem[0]
-            dw8, gview, cin = conv._rt['dw8_flush']
-            gview.add_(dw8[..., :cin])
-            dw8.zero_()
+        """the stems' 8-channel gradient staging buffers are folded into the arena inside the stem backward
+        (mscl_amd/nn.py); kept as a no-op for callers of the earlier API."""
+        return None
 
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:

@@ -88,7 +88,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(handle, n), n
     assert handle.mscl_abi_version() == 1
     # argument validation happens before any device work: callable without a GPU
-    assert handle.mscl_sumsq(None, None, 0, None) == -1
+    assert handle.mscl_sumsq(None, None, 0, None, 0, None) == -1
 
 
 def test_fill_is_deterministic_and_q_k_twins_equal(model):

@@ -316,6 +316,9 @@ def test_ema_sgd(dev):
         ss = torch.zeros(1, device=dev)
         K_.sumsq(g.to(dev), ss)
         close(ss.sqrt(), tn.reshape(1), 1e-5, 'grad norm')
+        ss2 = torch.full((1,), 7.0, device=dev)                     # overwritten, and bit-reproducible (replicas must agree)
+        K_.sumsq(g.to(dev), ss2)
+        assert torch.equal(ss, ss2)
         K_.sgd_step(pd, g.to(dev), buf, pbf, ss, 40.0, 0.02, 0.9, 1e-4, first=(step == 0))
         close(pd, p.detach(), 2e-6, f'sgd step {step}')
     assert torch.equal(pbf.cpu(), pd.cpu().to(torch.bfloat16))

@@ -201,3 +201,100 @@ def test_graphed_step_matches_eager(dev):
     lnoise = max(abs(a - b) for a, b in zip(l0, l0b))
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 3.0 * lnoise + 1e-3 * max(1.0, abs(a)), (l0, l0b, l1)
+
+
+# ----------------------------------------------------------------------------- 2 ranks on one GPU
+def _two_rank_worker(rank, world, port, q):
+    """Both ranks drive cuda:0 through gloo (RCCL refuses two ranks on one device).  The oracle runs the
+    reference's own collectives on the CPU in the same processes; its randperm is replaced with the product's
+    seeded permutation so that both encode the same key shards (any permutation is valid shuffle-BN)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mscl_amd import ClipSGD, parallel
+        from mscl_amd.synthetic import synthetic_batch
+        from oracle import fill as ofill, mscl as om
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+        B, T, H, Kq = 2, 8, 64, 64
+        model, cfg = build(T, Kq, dev)
+        opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+        orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
+        oopt = om.SGDClip(orc.parameters())
+        state = dict(step=0, flow_calls=0)
+
+        def patched(rec, slot_of):
+            def batch_shuffle(x):
+                b = x.shape[0]
+                xg = om.concat_all_gather(x)
+                perm = parallel.shuffle_perm(xg.shape[0], state['step'], slot_of())
+                return xg[perm.view(-1, b)[rank]], torch.argsort(perm)
+            rec.batch_shuffle = batch_shuffle
+
+        def flow_slot():
+            state['flow_calls'] += 1
+            return 1 if state['flow_calls'] % 2 == 1 else 2
+        patched(orc.recognizer, lambda: 0)
+        patched(orc.recognizer_flow, flow_slot)
+        cos = torch.nn.functional.cosine_similarity
+        for s in range(2):
+            state['step'] = s
+            batch = synthetic_batch(B, T, H, H, rank, s)
+            out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
+            opt.zero_grad(); out['loss'].backward()
+            oo = orc.train_step(batch); oopt.zero_grad(); oo['loss'].backward()
+            for p in orc.parameters():              # what DDP does for the reference
+                if p.grad is not None:
+                    dist.all_reduce(p.grad); p.grad.div_(world)
+            if s == 0:
+                for k, v in oo['log_vars'].items():
+                    if 'loss' in k:
+                        loss_close(out['log_vars'][k], v, f'rank{rank} {k}')
+                for nm, a, b in (('q_rgb', model._dbg['q_rgb'], orc._features['img']['q']),
+                                 ('k_rgb', model._dbg['k_rgb'], orc._features['img']['k']),
+                                 ('k_flow', model._dbg['k_fb'], orc._features['base']['k'])):
+                    c = cos(a.float().cpu(), b.detach(), dim=1).min().item()
+                    assert c >= 0.995, f'{nm} cosine {c}'
+            go = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
+            opt.step(); oopt.step()                 # (the oracle clips .grad in place; the HIP path scales inside SGD)
+            if s == 0:                              # opt.step() finished the bucketed all-reduce: averaged gradients
+                gh = float(model.arena.G.double().pow(2).sum().sqrt())
+                assert abs(gh - go) <= 0.08 * go, (gh, go)
+            for nm, rec, orec in (('rgb', model.recognizer, orc.recognizer), ('flow', model.recognizer_flow, orc.recognizer_flow)):
+                assert int(rec.queue_ptr) == int(orec.queue_ptr) and rec.iters == orec.iters, nm
+                assert rec.batch_size == orec.batch_size == world * B
+                assert torch.equal(rec.count.cpu(), orec.count), nm
+                assert abs(rec.m - orec.m) < 1e-12
+        # replicas stay bit-identical: masters, momentum, both queues
+        blob = torch.cat([model.arena.Q.flatten(), model.arena.MOM.flatten(), model.arena.KX.flatten(),
+                          model.recognizer.queue.flatten().float(), model.recognizer_flow.queue.flatten().float()]).cpu()
+        both = parallel.all_gather_cat(blob[None])
+        assert torch.equal(both[0], both[1]), 'ranks diverged'
+        qo = orc.recognizer.queue[:, :2 * world * B]
+        c = cos(model.recognizer.queue[:, :2 * world * B].float().cpu().T, qo.T, dim=1).min().item()
+        assert c >= 0.98, f'queue columns vs oracle: cosine {c}'
+        q.put((rank, 'ok'))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu(dev):
+    """world_size 2 through the whole step: shuffle-BN shards, key all-gather, replicated queues, overlapped bucketed
+    gradient averaging -- against the oracle running the reference's collectives in the same two processes."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for r, msg in res:
+        assert msg == 'ok', f'rank {r}:\n{msg}'
