@@ -96,8 +96,10 @@ def main():
         opt.step()
         return out['loss']
 
+    # World size > 1 launches eagerly unless MSCL_GRAPH_DP=1: capturing RCCL collectives issued from three streams
+    # into one HIP graph could only be validated on a single-GPU box this round.
     graphed = None
-    if not args.no_graph:
+    if not args.no_graph and (world == 1 or os.environ.get('MSCL_GRAPH_DP') == '1'):
         try:
             from mscl_amd.graph import GraphedStep
             graphed = GraphedStep(model, opt, batches[0], warmup=2)

@@ -16,6 +16,7 @@ queue snapshot is streamed exactly once forward and once backward -- SURVEY.md A
   5. backward through necks / trunks (fused block nodes), gradients accumulate in the flat arena.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -234,7 +235,7 @@ class MSCLWithAug(nn.Module):
         self._step = 0
         self._scal_host = self._scal_dev = None
         self._bg = 0
-        self.two_streams = True
+        self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'     # MSCL_STREAMS=1: everything on the current stream
         self._side = None
 
     # ------------------------------------------------------------------ device placement
@@ -480,9 +481,10 @@ class MSCLWithAug(nn.Module):
         # The flow chain is ~200 small, latency-bound launches and the key chains carry no gradient, so they
         # run on side HIP streams and fill the CUs the big RGB-query kernels leave idle (tail waves, small layers);
         # autograd replays each node's backward on its forward stream, so the backward passes overlap too.
-        # World size > 1 keeps one stream (the collectives share one communicator).
+        # Collectives issued from the side streams are still enqueued in host program order (identical on every
+        # rank) on the communicator's own stream, so the same layout holds for world size > 1.
         main = torch.cuda.current_stream()
-        multi = self.two_streams and parallel.world_size() == 1
+        multi = self.two_streams
         s_fq = self._side_stream(0) if multi else main       # flow query passes (base, rotated): share BN running stats -> in order
         s_fk = s_fq                                          # flow key passes share the flow stream (a 4th stream measured 3 % slower)
         side = s_fq
