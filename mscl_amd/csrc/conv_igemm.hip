@@ -39,6 +39,7 @@ struct IGemmGeom {
   int mode;                // 0 forward gather, 1 dgrad stride-1 (linear), 2 dgrad strided (parity classes)
   int mtiles, ntiles, ksplit, nclass;
   FastDiv dW, dH, dT;      // dense launches: division by Wr, Hr, Tr
+  FastDiv dKW, dKH;        // tap index -> (kt, kh, kw) (uniform-tap kernel)
   ClassInfo cls[8];
 };
 
@@ -52,6 +53,100 @@ __device__ __forceinline__ auto make_uniform_rsrc(const void* p, unsigned bytes)
 template <int BK> __device__ __forceinline__ int swz(int row, int g) {
   if constexpr (BK == 64) return g ^ ((row >> 1) & 7);
   else { const int q = (row >> 2) & 3; return g ^ ((0x78 >> (q * 2)) & 3); }   // q -> {0,2,3,1}
+}
+
+// Shared epilogue: split-K slab store, or BatchNorm statistics + (+bias)(+addend)(relu) -> bf16.
+template <int BM, int BN, int IM, int JN>
+__device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc)[JN][IM], unsigned char* smem, int tid, int fr, int fq,
+                                               int m0, int n0, int wm0, int wn0, int split, int Mc, FastDiv dW, FastDiv dH, FastDiv dT,
+                                               int TrS, int HrS, int WrS, int rsT, int rsH, int rsW, int roT, int roH, int roW,
+                                               bf16_t* __restrict__ out, const float* __restrict__ bias,
+                                               const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
+                                               float* __restrict__ stat_sq, int relu, float* __restrict__ partial) {
+  // output position of this lane's rows (class-strided for the parity-split input gradient)
+  long orow[IM];
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int m = m0 + wm0 + i * 16 + fr;
+    if (m < Mc) {
+      const int q1 = fdiv(m, dW), ws_ = m - q1 * WrS;
+      const int q2 = fdiv(q1, dH), hs_ = q1 - q2 * HrS;
+      const int n = fdiv(q2, dT), ts_ = q2 - n * TrS;
+      orow[i] = ((((long)n * g.Tr + ts_ * rsT + roT) * g.Hr + hs_ * rsH + roH) * g.Wr + ws_ * rsW + roW) * g.Cr;
+    } else orow[i] = -1;
+  }
+
+  if (partial != nullptr) {                   // split-K: this split's fp32 slab (plain 16-byte stores); the
+    float* slab = partial + (long)split * ((long)g.N * g.Tr * g.Hr * g.Wr * g.Cr);   // epilogue runs in splitk_finalize_kernel
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      if (orow[i] < 0) continue;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int n = n0 + wn0 + j * 16 + fq * 4;
+        if (n >= g.Cr) continue;
+        *reinterpret_cast<float4*>(slab + orow[i] + n) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
+  if (stat_sum != nullptr) {
+    float* red = reinterpret_cast<float*>(smem);      // [2][BN], tiles are dead after the last barrier
+    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s[r] += __shfl_xor(s[r], o, 64); q[r] += __shfl_xor(q[r], o, 64); }
+      }
+      if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = wn0 + j * 16 + fq * 4 + r;
+          atomicAdd(&red[nl], s[r]);
+          atomicAdd(&red[BN + nl], q[r]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BN; i += 256) {
+      if (n0 + i < g.Cr) { atomicAdd(&stat_sum[n0 + i], red[i]); atomicAdd(&stat_sq[n0 + i], red[BN + i]); }
+    }
+  }
+
+  // ---- epilogue: (+bias) (+addend) (relu) -> bf16, 4 consecutive channels per lane ----
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    if (orow[i] < 0) continue;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int n = n0 + wn0 + j * 16 + fq * 4;
+      if (n >= g.Cr) continue;
+      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      const long o = orow[i] + n;
+      if (bias != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (addend != nullptr) {
+        const uint2 av = *reinterpret_cast<const uint2*>(addend + o);
+        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
+        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
+      }
+      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(out + o) = pv;
+    }
+  }
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
@@ -272,90 +367,154 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     __builtin_amdgcn_s_barrier();             // the epilogue reuses the tile memory
   }
 
-  // output position of this lane's rows (class-strided for the parity-split input gradient)
-  long orow[IM];
+  igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, dW, dH, dT, TrS, HrS, WrS, rsT, rsH, rsW,
+                                 roT, roH, roW, out, bias, addend, stat_sum, stat_sq, relu, partial);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Uniform-tap variant for the layers that carry the FLOPs (source channels a multiple of 64, forward or stride-1
+// input gradient).  One K step = 64 channels of ONE tap, so the tap is wave-uniform: its offset travels in the
+// buffer instruction's SGPR offset and the per-lane VGPR offset of a row never changes.  A K step then costs 3 VALU
+// per A piece (tap-validity test + select of the zero-fill sentinel) and none per B piece, instead of the ~30 the
+// general kernel spends on table lookups and address arithmetic (measured there: 7.8 VALU per MFMA, 22 % MFMA busy).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_fast_kernel(
+    const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
+    const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
+    float* __restrict__ stat_sq, const int relu, float* __restrict__ partial) {
+  constexpr int BK = 64, GPR = 8, RPP = 32;
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int IM = WM / 16, JN = WN / 16;
+  constexpr int A_STAGE = BM * BK * 2, B_STAGE = BN * BK * 2;
+  constexpr unsigned OOB = 0x80000000u;       // >= num_records with or without the SGPR offset added
+  static_assert(WAVES_M * WAVES_N == 4 && IM >= 1 && JN >= 1 && AP >= 1 && BP >= 1 && BN % RPP == 0, "tile config");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const As = smem;                       // [2][BM*BK] bf16
+  unsigned char* const Bs = smem + 2 * A_STAGE;         // [2][BN*BK] bf16
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid % g.ksplit; bid /= g.ksplit;
+  const int nt = bid % g.ntiles; bid /= g.ntiles;
+  const int mt = bid;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int mode = __builtin_amdgcn_readfirstlane(g.mode);      // 0 forward, 1 stride-1 input gradient
+  const int Mc = g.M;
+  const int cs2 = g.Cs * 2;
+  // tap offsets are kept non-negative for the SGPR operand: the descriptor base is moved back by `bias_bytes`
+  const int maxlin = ((g.kT - 1) * g.Hs + (g.kH - 1)) * g.Ws + (g.kW - 1);
+  const int padlin = (g.pT * g.Hs + g.pH) * g.Ws + g.pW;
+  const int bias_bytes = (mode == 0 ? padlin : maxlin) * cs2;
+
+  const int rg = tid & 7, rr = tid >> 3;
+  const int rgl = swz<BK>(rr, rg);
+  int row_voff[AP], row_mask[AP];
 #pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    const int m = m0 + wm0 + i * 16 + fr;
+  for (int p = 0; p < AP; ++p) {
+    const int m = m0 + p * RPP + rr;
+    int mask = 0, base = 0;
     if (m < Mc) {
-      const int q1 = fdiv(m, dW), ws_ = m - q1 * WrS;
-      const int q2 = fdiv(q1, dH), hs_ = q1 - q2 * HrS;
-      const int n = fdiv(q2, dT), ts_ = q2 - n * TrS;
-      orow[i] = ((((long)n * g.Tr + ts_ * rsT + roT) * g.Hr + hs_ * rsH + roH) * g.Wr + ws_ * rsW + roW) * g.Cr;
-    } else orow[i] = -1;
-  }
-
-  if (partial != nullptr) {                   // split-K: this split's fp32 slab (plain 16-byte stores); the
-    float* slab = partial + (long)split * ((long)g.N * g.Tr * g.Hr * g.Wr * g.Cr);   // epilogue runs in splitk_finalize_kernel
-#pragma unroll
-    for (int i = 0; i < IM; ++i) {
-      if (orow[i] < 0) continue;
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const int n = n0 + wn0 + j * 16 + fq * 4;
-        if (n >= g.Cr) continue;
-        *reinterpret_cast<float4*>(slab + orow[i] + n) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-      }
+      const int q1 = fdiv(m, g.dW), wr = m - q1 * g.Wr;
+      const int q2 = fdiv(q1, g.dH), hr = q1 - q2 * g.Hr;
+      const int n = fdiv(q2, g.dT), tr = q2 - n * g.Tr;
+      int t0, h0, w0;
+      if (mode == 0) { t0 = tr * g.sT - g.pT; h0 = hr * g.sH - g.pH; w0 = wr * g.sW - g.pW; }
+      else { t0 = tr + g.pT; h0 = hr + g.pH; w0 = wr + g.pW; }
+      for (int k = 0; k < g.kT; ++k) { const int d = (mode == 0) ? t0 + k : t0 - k; mask |= ((unsigned)d < (unsigned)g.Ts) ? (1 << k) : 0; }
+      for (int k = 0; k < g.kH; ++k) { const int d = (mode == 0) ? h0 + k : h0 - k; mask |= ((unsigned)d < (unsigned)g.Hs) ? (1 << (8 + k)) : 0; }
+      for (int k = 0; k < g.kW; ++k) { const int d = (mode == 0) ? w0 + k : w0 - k; mask |= ((unsigned)d < (unsigned)g.Ws) ? (1 << (16 + k)) : 0; }
+      base = ((n * g.Ts + t0) * g.Hs + h0) * g.Ws + w0;
     }
-    return;
+    row_voff[p] = base * cs2 + (mode == 0 ? bias_bytes : 0) + rgl * 16;      // >= 0 for every row with a valid tap
+    row_mask[p] = mask;
   }
+  unsigned wrow_voff[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int r = p * RPP + rr;
+    wrow_voff[p] = (n0 + r < g.Cr) ? (unsigned)((n0 + r) * g.KG * 16 + rgl * 16) : OOB;
+  }
+  const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src) - bias_bytes;
+  const auto rs_src = make_uniform_rsrc(src_b, 0x7FFFFFFFu);
+  const auto rs_wgt = make_uniform_rsrc(wgt, 0x7FFFFFFFu);
 
-  // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
-  if (stat_sum != nullptr) {
-    float* red = reinterpret_cast<float*>(smem);      // [2][BN], tiles are dead after the last barrier
-    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4_t acc[JN][IM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int sub = g.cgs - 3, submask = (1 << sub) - 1;          // K steps per tap = Cs / 64
+  const int nk_all = g.ntaps << sub;
+  const int k_beg = (int)((long)nk_all * split / g.ksplit), k_end = (int)((long)nk_all * (split + 1) / g.ksplit);
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto issue = [&](int kt, int buf) {
+    const int slot = kt >> sub, cpart = kt & submask;
+    const int q = fdiv(slot, g.dKW), kw = slot - q * g.kW;
+    const int kd = fdiv(q, g.dKH), kh = q - kd * g.kH;
+    const int lin = (kd * g.Hs + kh) * g.Ws + kw;
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((mode == 0 ? lin : maxlin - lin) * cs2 + cpart * 128));
+    const int tb = __builtin_amdgcn_readfirstlane((1 << kd) | (1 << (8 + kh)) | (1 << (16 + kw)));
+    const unsigned woff = __builtin_amdgcn_readfirstlane((unsigned)kt * 128u);
+    unsigned char* a = As + buf * A_STAGE + wave * 1024;
+    unsigned char* b = Bs + buf * B_STAGE + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const unsigned off = ((row_mask[p] & tb) == tb) ? (unsigned)row_voff[p] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(a + p * (RPP * BK * 2)), 16, off, soff, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const unsigned wv = wrow_voff[p];         // (a captured array element passed straight to the builtin loses the host stub)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(b + p * (RPP * BK * 2)), 16, wv, woff, 0, 0);
+    }
+  };
+  // per-lane fragment byte offsets inside a stage (row * 128 + swizzled granule * 16), loop-invariant
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ra = wm0 + fr, rb = wn0 + fr;     // rows of fragment i / j differ by multiples of 16: same swizzle key
+    a_off[ks] = ra * 128 + swz<BK>(ra, ks * 4 + fq) * 16;
+    b_off[ks] = rb * 128 + swz<BK>(rb, ks * 4 + fq) * 16;
+  }
+  auto compute = [&](int buf) {
+    const unsigned char* a = As + buf * A_STAGE;
+    const unsigned char* b = Bs + buf * B_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[IM], fb[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(a + a_off[ks] + i * (16 * 128));
+#pragma unroll
+      for (int j = 0; j < JN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(b + b_off[ks] + j * (16 * 128));
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+    }
+  };
+
+  if (k_beg < k_end) {
+    issue(k_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < JN; ++j) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < IM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s[r] += __shfl_xor(s[r], o, 64); q[r] += __shfl_xor(q[r], o, 64); }
-      }
-      if (fr == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nl = wn0 + j * 16 + fq * 4 + r;
-          atomicAdd(&red[nl], s[r]);
-          atomicAdd(&red[BN + nl], q[r]);
-        }
-      }
-    }
+  }
+  for (int kt = k_beg; kt < k_end; ++kt) {
+    const int cur = (kt - k_beg) & 1;
+    if (kt + 1 < k_end) issue(kt + 1, cur ^ 1);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int i = tid; i < BN; i += 256) {
-      if (n0 + i < g.Cr) { atomicAdd(&stat_sum[n0 + i], red[i]); atomicAdd(&stat_sq[n0 + i], red[BN + i]); }
-    }
   }
-
-  // ---- epilogue: (+bias) (+addend) (relu) -> bf16, 4 consecutive channels per lane ----
-#pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    if (orow[i] < 0) continue;
-#pragma unroll
-    for (int j = 0; j < JN; ++j) {
-      const int n = n0 + wn0 + j * 16 + fq * 4;
-      if (n >= g.Cr) continue;
-      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      const long o = orow[i] + n;
-      if (bias != nullptr) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (addend != nullptr) {
-        const uint2 av = *reinterpret_cast<const uint2*>(addend + o);
-        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
-        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
-      }
-      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(out + o) = pv;
-    }
-  }
+  igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, g.dW, g.dH, g.dT, g.Tr, g.Hr, g.Wr, 1, 1, 1,
+                                 0, 0, 0, out, bias, addend, stat_sum, stat_sq, relu, partial);
 }
 
 // split-K epilogue: out = bf16( relu?( sum of slabs + bias + addend ) ), BN statistics of the sum
@@ -402,6 +561,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------- host side
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
+static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % 32 == 0 && BN % 32 == 0; }
+static bool fast_disabled() { const char* e = getenv("MSCL_IGEMM_FAST"); return e && e[0] == '0'; }
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias,
                       const bf16_t* addend, float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
   int maxM = g.M;
@@ -422,17 +585,38 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
     if (want * out_elems > ws_floats) want = ws_floats / out_elems;
     if (want > 1) g.ksplit = (int)want;
   }
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2 + (size_t)g.ntaps * 12;
-  auto kern = conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, STAGES>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   float* partial = g.ksplit > 1 ? ws : nullptr;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(256), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
-                     relu, partial);
-  MSCL_LAUNCH_CHECK();
+  bool launched = false;
+  if constexpr (fast_tile<BM, BN, BK, WAVES_M, WAVES_N, STAGES>()) {
+    // uniform-tap kernel: whole 64-channel K steps of one tap, no parity classes, offsets below 2^31
+    const long span = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
+    if (g.mode != 2 && g.cgs >= 3 && span < (1L << 31) && !fast_disabled()) {
+      auto kern = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N>;
+      static bool attr_done_f = false;
+      if (!attr_done_f) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done_f = true;
+      }
+      g.dKW = make_fastdiv(g.kW); g.dKH = make_fastdiv(g.kH);
+      const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(256), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
+                         relu, partial);
+      MSCL_LAUNCH_CHECK();
+      launched = true;
+    }
+  }
+  if (!launched) {
+    const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2 + (size_t)g.ntaps * 12;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, STAGES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(256), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
+                       relu, partial);
+    MSCL_LAUNCH_CHECK();
+  }
   if (g.ksplit > 1) {
     const long rows = out_elems / g.Cr;
     const int RP = 256 / (g.Cr / 8);
