@@ -8,8 +8,8 @@
 A step = one pass of the hot path over one synthetic batch of 8 clip-pairs per GPU (16 frames, 112x112,
 RGB q/k + visualised flow q/k as base||rotated), inputs resident in HBM, weights from the closed-form
 fill.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      dominant kernel = the layer-1 3x3x3 64->64 implicit-GEMM conv (MFMA-bound), timed with
-                events on the launch stream during the timed steps
+  roofline      dominant kernel = the layer-1 3x3x3 64->64 conv (halo-resident MFMA kernel, MFMA-bound), timed with
+                event pairs on its launch stream in two eager steps right after the timed region
   cpu_baseline  the oracle/ restatement ("port") timed on this box's host cores on a bounded sample
 """
 import argparse
@@ -157,7 +157,7 @@ def main():
                        'parallelism': f'dp{world}', 'weights': 'closed-form fill, fp32 masters + bf16 shadows',
                        'launch': 'one captured HIP graph per step' if graphed is not None else 'eager'},
             'final_loss': loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,64,64> fwd, 3x3x3 64->64 on (8,16,56,56,64)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64_kernel fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                          'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': None},
         }

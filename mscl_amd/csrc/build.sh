@@ -6,14 +6,16 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in conv_igemm conv_halo conv_wgrad bn_act elementwise contrast optim; do
+SRCS="conv_igemm conv_halo conv_wgrad bn_act elementwise contrast optim"
+for f in $SRCS; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/mscl_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmscl_hip.so build/*.o
+OBJS=""; for f in $SRCS; do OBJS="$OBJS build/$f.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmscl_hip.so $OBJS
 echo "built $(pwd)/libmscl_hip.so"
 # a library with unresolved kernel stubs links fine but cannot be dlopen()ed: check now, not on the GPU box
 python3 -c "import ctypes; ctypes.CDLL('$(pwd)/libmscl_hip.so')" || { echo "error: libmscl_hip.so has unresolved symbols (dlopen failed)"; exit 1; }

@@ -1,25 +1,31 @@
 // Halo-resident 3x3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (R3D-18 layer 1: 44 % of the
 // trunk's FLOPs; forward AND stride-1 input gradient) on bf16 MFMA, gfx950.
 //
-// Why a second conv kernel: the implicit-GEMM kernel (conv_igemm.hip) re-stages every input row once per
-// tap, 27x.  With only 64 output channels a staged byte feeds 64 FLOP, and the measured L2 -> LDS gather rate
-// of a CU (~30 B/clk) then caps the kernel near 45 % of MFMA peak (it reaches ~500 TFLOP/s = 20 %).
-// Here a block owns BM = 256 consecutive output positions of ONE (n, t) plane and stages the input window
-// they can touch ONCE: for each of the 3 source planes the linear range [p0 - W - 1, p0 + BM + W + 1)
-// (BM + 2W + 2 rows of 128 B) = 142 KB of LDS at W = 56.  A tap is then just a constant row offset into that
-// window -- the 27 taps read their MFMA operands straight from it.  Staged bytes per output drop 6x.
-//  * rows outside the plane / planes outside the clip are zero-filled by the DMA's out-of-range rule;
-//  * the only positions the linear window gets wrong are the w = 0 / w = W-1 columns for the kw = 0 / 2 taps
-//    (the neighbour in memory belongs to the adjacent image row): those lanes' fragments are zeroed (v_cndmask);
-//  * weights (8 KB per tap) stream through a double-buffered LDS tile by LDS-DMA, one barrier per tap;
-//  * 4 waves, 64 x 64 outputs each (LDS reads: 8 x ds_read_b128 per 16 MFMAs = 128 B/clk/CU, half the LDS rate);
+// Why a second conv kernel: the implicit-GEMM kernels (conv_igemm.hip) re-stage every input row once per tap, 27x.
+// With only 64 output channels a staged byte feeds 64 FLOP; a CU moves global memory into LDS at <= 64 B/clk, the
+// MFMA pipe wants 4096 FLOP/clk, so re-staging caps those kernels near 40 % of MFMA peak (measured 23 %).
+//
+// Here a block owns BM = 256 consecutive positions of ONE (n, t) plane in PADDED-LINEAR order: the plane is walked
+// as H rows of W + 2 columns (one zero column each side), q = hp * (W + 2) + wp.  In that order every tap is a
+// constant shift of q -- (kh - 1) * (W + 2) + (kw - 1) -- and the zero padding is part of the data, so there is no
+// per-tap masking at all.  The block stages, ONCE, the window [q0 - (W+2) - 1, q0 + BM + (W+2) + 1) of each of the
+// three source planes (384 rows of 128 B each = 144 KB of LDS); rows that fall on padding or outside the clip are
+// zero-filled by the buffer unit's out-of-range rule.  The 2 pad columns cost 3.4 % extra MFMA work at W = 56.
+//  * weights (8 KB per tap) stream through a 2-stage LDS ring by LDS-DMA; one barrier per tap, placed between the
+//    tap's two 32-deep k steps;
+//  * right after that barrier a wave reads BOTH operands of the NEXT tap into registers (A from the resident
+//    window, B from the ring stage that just landed) and only then issues the DMA for the tap after next, so MFMAs
+//    never wait on LDS or on memory in steady state;
+//  * planes 2 and 3 of the window stream in under the first taps (2 pieces per tap), ordered before the weight
+//    pieces so that the per-tap `vmcnt(0)` never waits for anything issued less than a full tap ago;
+//  * 4 waves, 64 positions x 64 channels each: 16 ds_read_b128 per 32 MFMAs (half the LDS read rate);
 //  * epilogue as in conv_igemm.hip: BatchNorm sum / sum-of-squares, optional addend, bf16, 8-byte stores.
 #include "common.h"
 
 struct HaloGeom {
-  int N, T, H, W, HW, NH;          // NH = BM + 2W + 2 window rows per source plane
+  int N, T, H, W, HW, Wp;          // Wp = W + 2 padded row length
   int tiles, mode;                 // tiles per plane; mode 0 forward, 1 input gradient (taps mirrored)
-  FastDiv dW;                      // division by W
+  FastDiv dWp;                     // division by Wp
 };
 
 __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
@@ -29,153 +35,225 @@ __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-constexpr int HBM = 256;           // output positions per block
+constexpr int HBM = 256;           // padded-linear positions per block
 constexpr int HC = 64;             // channels (in = out)
-constexpr int PF = 4;              // weight fragments are prefetched this many taps ahead (registers)
+constexpr int NH = 384;            // window rows per source plane (HBM + 2 * Wp + 2 <= NH, i.e. W <= 61)
+constexpr int NPASS = NH / 32;     // DMA pieces per thread per plane (a pass = 256 threads x 16 B = 32 rows)
+constexpr int PLANE_BYTES = NH * 128;
+constexpr unsigned HOOB = 0x80000000u;
 
-// Wave layout 2 (positions) x 2 (channels): a wave owns 128 positions x 32 output channels.
-//  * A operands (positions) come from the LDS window: 8 fragments per 32-deep k step, read 4 at a time;
-//  * B operands (weights, 32 rows x 64 k per tap = 4 fragments) are loaded from global memory / L2 straight
-//    into registers PF taps ahead -- no weight tile in LDS, hence NO barrier inside the 27-tap loop: the only
-//    barriers are the three "source plane landed" points, so planes 1 and 2 stream in under plane 0's taps.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
                                                              float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Hs = smem;                           // [3][NH][128 B] input window
+  unsigned char* const Hs = smem;                          // [3][NH][128 B] input window, row j <-> q0 - Wp - 1 + j
+  unsigned char* const Ws = smem + 3 * PLANE_BYTES;        // [2][64][128 B] weight ring
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = bid % g.tiles, plane = bid / g.tiles;        // plane = n*T + t
+  const int tile = bid % g.tiles, plane = bid / g.tiles;   // plane = n*T + t
   const int t = plane % g.T;
-  const int p0 = tile * HBM;
+  const int q0 = g.Wp + tile * HBM;                        // first padded-linear position of this tile (hp = 1, wp = 0)
   const int mode = __builtin_amdgcn_readfirstlane(g.mode);
 
-  const unsigned src_bytes = (unsigned)((long)g.N * g.T * g.HW * HC * 2);
-  const auto rs_src = halo_rsrc(src, src_bytes);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifdef HALO_PROBE      // timing-only builds: 1 = weight loads dropped by the range check, 2 = window loads dropped, 3 = both
+  const auto rs_src = halo_rsrc(src, (HALO_PROBE & 2) ? 0u : 0x7FFFFFFFu);
+  const auto rs_wgt = halo_rsrc(wgt, (HALO_PROBE & 1) ? 0u : 0x7FFFFFFFu);
+#else
+  const auto rs_src = halo_rsrc(src, 0x7FFFFFFFu);
+  const auto rs_wgt = halo_rsrc(wgt, 0x7FFFFFFFu);
+#endif
 
-  // ---- weight fragments: rows n = 32*wn + 16*j + fr, k granule = ks*4 + fq ----
-  const int fr = lane & 15, fq = lane >> 4;
-  const bf16_t* wbase[2];
+  // ---- window DMA: per-pass VGPR offsets inside a source plane (same for the 3 planes; the plane goes in the SGPR) ----
+  unsigned win_voff[NPASS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) wbase[j] = wgt + ((long)(32 * wn + 16 * j + fr) * 27) * HC + fq * 8;
-  bf16x8_t bq[PF][2][2];                              // [tap slot][j][ks]
-  auto load_b = [&](int tap, int slot) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bq[slot][j][ks] = *reinterpret_cast<const bf16x8_t*>(wbase[j] + tap * HC + ks * 32);
-  };
-
-  // ---- stage the input window plane by plane, in the order the tap loop visits them.  NH is padded to a
-  // multiple of 32 rows so that every wave issues exactly `npass` DMA instructions per plane: the first wait
-  // below can then be a COUNTED vmcnt that leaves the two later planes in flight under the first taps.
-  // Issue order (vmcnt retires in order): plane A, weight prefetch, plane B, plane C.
-  const int npass = g.NH >> 5;                         // NH*8 granules / 256 per pass
-  auto stage_plane = [&](int k3) {
-    const int hp = mode ? 2 - k3 : k3;                 // window plane used by the k3-th group of taps
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int j = ps * 32 + (tid >> 3), pg = tid & 7;
+    const int lg = pg ^ (j & 7);                           // source-side swizzle keyed on the window row
+    const int q = q0 - g.Wp - 1 + j;
+    const int hp = fdiv(q < 0 ? 0 : q, g.dWp), wp = q - hp * g.Wp;
+    const bool ok = q >= 0 && hp >= 1 && hp <= g.H && wp >= 1 && wp <= g.W;
+    win_voff[ps] = ok ? (unsigned)((((hp - 1) * g.W + (wp - 1)) * HC + lg * 8) * 2) : HOOB;
+  }
+  auto plane_soff = [&](int hp) -> unsigned {              // byte offset of source plane t + hp - 1 (HOOB-safe: invalid -> rows zero)
     const int tt = t + hp - 1;
-    for (int ps = 0; ps < npass; ++ps) {
-      const int G = ps * 256 + tid;
-      const int j = G >> 3, pg = G & 7;
-      const int lg = pg ^ (j & 7);                     // source-side swizzle keyed on the window row (any-offset conflict-free)
-      const int q = p0 - g.W - 1 + j;
-      const bool ok = (unsigned)tt < (unsigned)g.T && (unsigned)q < (unsigned)g.HW;
-      const unsigned off = ok ? (unsigned)((((plane + hp - 1) * g.HW + q) * HC + lg * 8) * 2) : src_bytes;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + hp * g.NH * 128 + (ps * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+    return (unsigned)tt < (unsigned)g.T ? (unsigned)((plane + hp - 1) * g.HW) * (HC * 2) : 0u;
+  };
+  auto plane_ok = [&](int hp) -> bool { return (unsigned)(t + hp - 1) < (unsigned)g.T; };
+  auto issue_plane_piece = [&](int hp, int ps) {
+    const unsigned so = __builtin_amdgcn_readfirstlane(plane_soff(hp));
+    const unsigned vo = plane_ok(hp) ? win_voff[ps] : HOOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + hp * PLANE_BYTES + (ps * 256 + wave * 64) * 16), 16, vo, so, 0, 0);
+  };
+  // ---- weights: tap `tap` -> ring stage tap & 1; rows = output channel n (forward) / input channel (gradient, wT) ----
+  // Default: LDS-DMA, issued one tap ahead.  HALO_WREG=1 stages them through registers instead (16-byte loads two taps
+  // ahead, ds_write_b128 one tap ahead): measured 7 % SLOWER (118 vs 109 us on layer 1), kept for reference.
+#ifndef HALO_WREG
+#define HALO_WREG 0
+#endif
+#ifndef HALO_EXP
+#define HALO_EXP 0       // timing-study switches (wrong results): 1 no barrier, 2 no operand reads, 4 no weight moves, 8 no plane pieces
+#endif
+  const int w_row = tid >> 3, w_lg = tid & 7;
+#if HALO_WREG
+  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + w_lg * 8) * 2);
+  const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
+  const int w_lds = w_row * 128 + ((w_lg ^ (w_row & 7)) * 16);          // + 4096 for the second piece (row + 32: same key)
+  uint4 wreg[3][2];
+  auto load_weights = [&](int tap) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
+    wreg[tap % 3][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, w_voff0, so, 0));
+    wreg[tap % 3][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, w_voff1, so, 0));
+  };
+  auto store_weights = [&](int tap) {
+    unsigned char* dst = Ws + (tap & 1) * (64 * 128) + w_lds;
+    *reinterpret_cast<uint4*>(dst) = wreg[tap % 3][0];
+    *reinterpret_cast<uint4*>(dst + 4096) = wreg[tap % 3][1];
+  };
+#else
+  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);     // source-side swizzle
+  const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
+  auto issue_weights = [&](int tap) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
+    unsigned char* dst = Ws + (tap & 1) * (64 * 128) + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
+  };
+#endif
+
+  // window plane visited by the kt-th group of taps, and the row shift of tap (kh, kw)
+  auto tap_plane = [&](int kt) { return mode ? 2 - kt : kt; };
+  auto tap_shift = [&](int kh, int kw) { return mode ? (2 - kh) * g.Wp + (2 - kw) : kh * g.Wp + kw; };
+
+  // ---- prologue: first plane, weights of taps 0 and 1 ----
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) issue_plane_piece(tap_plane(0), ps);
+#if HALO_WREG
+  load_weights(0);
+  load_weights(1);
+  load_weights(2);
+#else
+  issue_weights(0);
+  issue_weights(1);
+#endif
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int arow0 = wave * 64 + fr;                        // window row of fragment 0 at shift 0
+  const int brow = fr;                                     // weight row of fragment 0 (j adds 16 rows = 2 KB)
+  const int b_addr0 = brow * 128 + ((0 + fq) ^ (brow & 7)) * 16;
+  const int b_addr1 = brow * 128 + ((4 + fq) ^ (brow & 7)) * 16;
+
+  bf16x8_t fa[2][2][4], fb[2][2][4];                       // [buffer][ks][fragment]
+  auto read_operands = [&](int tap, int buf) {
+    const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+    const unsigned char* wb = Ws + (tap & 1) * (64 * 128);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fb[buf][0][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr0 + j * 2048);
+      fb[buf][1][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr1 + j * 2048);
+    }
+    const int row = arow0 + tap_shift(kh, kw);
+    const int key = row & 7;
+    const unsigned char* hb = Hs + tap_plane(kt) * PLANE_BYTES + row * 128;
+    const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[buf][0][i] = *reinterpret_cast<const bf16x8_t*>(hb + g0 + i * 2048);
+      fa[buf][1][i] = *reinterpret_cast<const bf16x8_t*>(hb + g1 + i * 2048);
     }
   };
-  stage_plane(0);
-#pragma unroll
-  for (int s0 = 0; s0 < PF; ++s0) load_b(s0, s0);
-  stage_plane(1);
-  stage_plane(2);
 
-  // ---- per-lane output rows: m = 128*wm + 16*i + fr ----
-  int hq0[8];                       // window row of the CENTRE tap for fragment i
-  unsigned okbits = 0;              // bit i: row valid, bit 8+i: w-1 neighbour exists, bit 16+i: w+1 neighbour exists
+  f32x4_t acc[4][4];                                       // [j: channel tile][i: position tile]
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = 128 * wm + 16 * i + fr;
-    const int p = p0 + m;
-    const int wcol = p - fdiv(p, g.dW) * g.W;
-    hq0[i] = m + g.W + 1;
-    const bool okrow = p < g.HW;
-    okbits |= (okrow ? 1u : 0u) << i;
-    okbits |= ((okrow && wcol >= 1) ? 1u : 0u) << (8 + i);
-    okbits |= ((okrow && wcol <= g.W - 2) ? 1u : 0u) << (16 + i);
-  }
-  f32x4_t acc[2][8];                // [j: channel tile][i: position tile]
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fully unrolled: ring slots and plane bases are compile-time constants (a rolled kt loop with PF = 3 measured
-  // 10 % slower although it needs 428 instead of 512 VGPRs)
+#if HALO_WREG
+  store_weights(0);                                        // (the compiler waits for exactly the loads it needs; the
+  load_weights(3);                                         //  first plane's DMA pieces are older, so they have landed too)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // plane + tap-0 weights landed (tap-1 weights in flight)
+#endif
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_operands(0, 0);
+  if (HALO_EXP & 2) read_operands(0, 1);
+#if HALO_WREG
+  store_weights(1);
+#endif
+
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap) {
-    const int kt = tap / 9, t9 = tap % 9;
-    if (tap == 0) {                 // first plane + weight prefetch landed; 2*npass younger DMA instructions stay in flight
-      switch (2 * npass) {
-        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    const int cur = tap & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][0][j], fa[cur][0][i], acc[j][i], 0, 0, 0);
+    if (tap + 1 < 27) {
+      // The barrier publishes ring stage (tap+1)&1 and says every wave holds its tap-`tap` fragments in registers, so
+      // stage `cur` may be refilled with tap+2.  Raw s_barrier: __syncthreads() would drain vmcnt as well.
+#if HALO_WREG
+      if (tap == 7 || tap == 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next window plane landed (DMA pieces)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       // everything issued a tap ago has landed
+#endif
+      if (!(HALO_EXP & 1)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!(HALO_EXP & 2)) read_operands(tap + 1, cur ^ 1);
+      // window planes 2 and 3: two DMA pieces per tap, ahead of the weight pieces (in-order retirement)
+      if (!(HALO_EXP & 8)) {
+        if (tap < 6) { issue_plane_piece(tap_plane(1), 2 * tap); issue_plane_piece(tap_plane(1), 2 * tap + 1); }
+        else if (tap >= 8 && tap < 14) { issue_plane_piece(tap_plane(2), 2 * (tap - 8)); issue_plane_piece(tap_plane(2), 2 * (tap - 8) + 1); }
       }
-      __builtin_amdgcn_s_barrier();
-    } else if (t9 == 0) {
-      // planes B and C are older than every weight load issued inside the loop, and vmcnt retires in order: the
-      // wait that delivered tap 4's weights already covered them for THIS wave; the barrier publishes that to all
-      __builtin_amdgcn_s_barrier();
-    }
-    const int kw = t9 % 3, kh = t9 / 3;
-    const int hp = mode ? 2 - kt : kt;
-    const int dlt = mode ? (1 - kh) * g.W + (1 - kw) : (kh - 1) * g.W + (kw - 1);
-    const int side = mode ? 2 - kw : kw;        // 0: reads the w-1 neighbour, 2: the w+1 neighbour, 1: centre
-    const unsigned okm = side == 1 ? okbits : (side == 0 ? (okbits >> 8) : (okbits >> 16));
-    const unsigned char* hb = Hs + hp * g.NH * 128;
-    const int slot = tap % PF;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        bf16x8_t fa[4];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int i = half * 4 + ii;
-          const int hq = hq0[i] + dlt;
-          uint4 v = *reinterpret_cast<const uint4*>(hb + hq * 128 + (((ks * 4 + fq) ^ (hq & 7)) * 16));
-          const bool ok = (okm >> i) & 1u;      // (a wave-uniform "skip if no lane is masked" branch was tried: it
-          v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;   // splits the MFMA stream into tiny blocks, 25 % slower)
-          fa[ii] = __builtin_bit_cast(bf16x8_t, v);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int ii = 0; ii < 4; ++ii)
-            acc[j][half * 4 + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[slot][j][ks], fa[ii], acc[j][half * 4 + ii], 0, 0, 0);
+      if (!(HALO_EXP & 4)) {
+#if HALO_WREG
+        if (tap + 2 < 27) store_weights(tap + 2);
+        if (tap + 4 < 27) load_weights(tap + 4);
+#else
+        if (tap + 2 < 27) issue_weights(tap + 2);
+#endif
       }
     }
-    if (tap + PF < 27) load_b(tap + PF, slot);
+    __builtin_amdgcn_sched_barrier(0);          // keep the next tap's operand reads ABOVE this tap's second k step
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                  // the epilogue reuses the window memory
 
-  // ---- epilogue: BatchNorm statistics (rows beyond the plane were zeroed above) ----
+  // ---- output rows of this lane: padded-linear q -> (hp, wp); pad columns and rows past the plane are dropped ----
+  long orow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + wave * 64 + i * 16 + fr;
+    const int hp = fdiv(q, g.dWp), wp = q - hp * g.Wp;
+    const bool ok = hp <= g.H && wp >= 1 && wp <= g.W;
+    orow[i] = ok ? ((long)plane * g.HW + (hp - 1) * g.W + (wp - 1)) * HC : -1;
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // ---- epilogue: BatchNorm statistics ----
   if (stat_sum != nullptr) {
     float* red = reinterpret_cast<float*>(smem);      // [2][64]
     for (int i = tid; i < 2 * HC; i += 256) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
 #pragma unroll
@@ -186,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
       if (fr == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int nl = 32 * wn + j * 16 + fq * 4 + r;
+          const int nl = j * 16 + fq * 4 + r;
           atomicAdd(&red[nl], s[r]);
           atomicAdd(&red[HC + nl], q[r]);
         }
@@ -196,20 +274,19 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
     for (int i = tid; i < HC; i += 256) { atomicAdd(&stat_sum[i], red[i]); atomicAdd(&stat_sq[i], red[HC + i]); }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (!((okbits >> i) & 1u)) continue;
-    const long o0 = ((long)plane * g.HW + p0 + 128 * wm + 16 * i + fr) * HC;
+  for (int i = 0; i < 4; ++i) {
+    if (orow[i] < 0) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = 32 * wn + j * 16 + fq * 4;
+    for (int j = 0; j < 4; ++j) {
+      const int n = j * 16 + fq * 4;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
       if (addend != nullptr) {
-        const uint2 av = *reinterpret_cast<const uint2*>(addend + o0 + n);
+        const uint2 av = *reinterpret_cast<const uint2*>(addend + orow[i] + n);
         v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
         v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
       }
       uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(out + o0 + n) = pv;
+      *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
     }
   }
 }
@@ -221,11 +298,11 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
   if (d->C != HC || d->K != HC || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
       d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
   HaloGeom g{};
-  g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.NH = (HBM + 2 * d->W + 2 + 31) / 32 * 32;
-  const size_t lds = (size_t)3 * g.NH * 128;
-  if (lds > 160 * 1024 || (long)d->N * d->T * g.HW * HC * 2 >= (1L << 31)) return 0;
-  g.tiles = (g.HW + HBM - 1) / HBM; g.mode = mode;
-  g.dW = make_fastdiv(d->W);
+  g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
+  if (HBM + 2 * g.Wp + 2 > NH || (long)d->N * d->T * g.HW * HC * 2 >= (1L << 31)) return 0;
+  g.tiles = (d->H * g.Wp + HBM - 1) / HBM; g.mode = mode;
+  g.dWp = make_fastdiv(g.Wp);
+  const size_t lds = (size_t)3 * PLANE_BYTES + 2 * 64 * 128;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -686,8 +686,14 @@ static int check_desc(const mscl_conv_desc* d) {
 
 extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream);
-// opt-in: the halo-resident kernel ties the implicit-GEMM one on layer 1 (179 vs 177 us), see DESIGN.md
-static bool halo_enabled() { const char* e = getenv("MSCL_HALO"); return e && e[0] == '1'; }
+// layer-1 shape (3x3x3 s1 p1, 64 -> 64): halo-resident kernel, 131 / 109 us vs 156 / 135 us (fwd / dgrad) for the
+// implicit-GEMM kernel; MSCL_HALO=0 switches it off
+static bool halo_enabled(const mscl_conv_desc* d) {
+  const char* e = getenv("MSCL_HALO");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;                        // forced (tests: small planes too)
+  return (long)d->H * (d->W + 2) >= 1024;                   // 256-position tiles: planes of a few hundred positions waste them
+}
 
 extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w, uint16_t* y,
                                const float* bias, const uint16_t* addend, int relu, float* ssum, float* ssq,
@@ -695,7 +701,7 @@ extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const
   int e = check_desc(d); if (e) return e;
   if (!x || !w || !y) return MSCL_E_ARG;
   if ((ssum == nullptr) != (ssq == nullptr)) return MSCL_E_ARG;
-  if (bias == nullptr && !relu && halo_enabled()) {           // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
+  if (bias == nullptr && !relu && halo_enabled(d)) {           // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
     const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
@@ -714,7 +720,7 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
                                  const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!dy || !wT || !dx) return MSCL_E_ARG;
-  if (halo_enabled()) {
+  if (halo_enabled(d)) {
     const int h = mscl_conv_halo64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
     if (h != 0) return h == 1 ? 0 : h;
   }

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmscl_hip.so')
+LIB_PATH = os.environ.get('MSCL_LIB', os.path.join(_HERE, 'csrc', 'libmscl_hip.so'))     # MSCL_LIB: timing-probe builds
 
 
 class MsclError(RuntimeError):
