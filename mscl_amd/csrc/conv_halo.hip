@@ -26,6 +26,7 @@ struct HaloGeom {
   int N, T, H, W, HW, Wp;          // Wp = W + 2 padded row length
   int tiles, mode;                 // tiles per plane; mode 0 forward, 1 input gradient (taps mirrored)
   FastDiv dWp;                     // division by Wp
+  FastDiv dT, dTiles;              // persistent kernel: item -> (chain, t), chain -> (n, tile)
 };
 
 __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
@@ -291,6 +292,223 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
   }
 }
 
+// =====================================================================================================================
+// Persistent plane-walking variant (MSCL_HALO_PERSIST=1).  Timing probes on the kernel above (profiles/r01_pmc_layer1.md) show that
+// with EVERYTHING but the MFMAs removed from its tap loop it still runs at 42 % of MFMA peak: at one 160-KB block per
+// CU every block pays a dispatch gap (17 % of CU time has no wave resident), an exposed 48-KB window prologue and a
+// drained pipeline around its epilogue.  Here the grid is one block per CU and a block walks a contiguous range of
+// (n, tile, t) items with t fastest:
+//  * moving from output plane t to t+1 keeps two of the three source planes in LDS (ring slot = (plane + 1) % 3) and
+//    streams only plane t+2 -- one DMA piece per tap under taps 9..20 -- so window traffic drops 3x and there is no
+//    prologue inside a chain;
+//  * the tap pipeline runs across the item boundary: the last two taps of an item issue the weight tiles of the next
+//    item's first two taps and fetch its first operands, so the MFMA stream only pauses for the epilogue's stores;
+//  * taps are visited in WINDOW order (plane t-1, t, t+1; row shift a*(W+2)+b); the weight tap is idx (forward) or
+//    26 - idx (input gradient), so plane t-1 is always the first one released;
+//  * BatchNorm statistics accumulate in registers over all items of the block: one reduction + 128 atomics per BLOCK.
+// 27 taps per item is odd, so the weight ring parity flips per item (`par`, LDS addresses are runtime anyway) and
+// the operand register double-buffer is re-based by a 32-register copy at the item boundary.
+constexpr int NHP = 376;                     // window rows (374 needed at W = 56); leaves 3 KB of the 160 KB for scratch
+constexpr int PPLANE = NHP * 128;
+constexpr int PNPASS = 12;                   // 32-row DMA passes; the last one covers rows 352..375 (wave 3 sits out)
+
+__global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, const int total_items,
+                                                              const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
+                                                              bf16_t* __restrict__ out, const bf16_t* __restrict__ addend,
+                                                              float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const Hs = smem;                          // [3][NHP][128 B] plane ring
+  unsigned char* const Ws = smem + 3 * PPLANE;             // [2][64][128 B] weight ring
+  float* const red = reinterpret_cast<float*>(smem + 3 * PPLANE + 2 * 64 * 128);      // [2][64] statistics scratch
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mode = __builtin_amdgcn_readfirstlane(g.mode);
+  const int it_beg = (int)((long)total_items * blockIdx.x / gridDim.x);
+  const int it_end = (int)((long)total_items * (blockIdx.x + 1) / gridDim.x);
+  const auto rs_src = halo_rsrc(src, 0x7FFFFFFFu);
+  const auto rs_wgt = halo_rsrc(wgt, 0x7FFFFFFFu);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int arow0 = wave * 64 + fr;
+  const int b_addr0 = fr * 128 + ((0 + fq) ^ (fr & 7)) * 16;
+  const int b_addr1 = fr * 128 + ((4 + fq) ^ (fr & 7)) * 16;
+  const int w_row = tid >> 3, w_lg = tid & 7;
+  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);
+  const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
+
+  unsigned win_voff[PNPASS];                 // per-pass source offsets inside a plane (depend on the tile only)
+  int opos[4];                               // output offset inside a plane (elements), -1 = pad column / beyond the plane
+  float ssum[4][4], ssq[4][4];               // [j][r] running BatchNorm sums of this lane's rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+
+  auto slot_of = [&](int tt) { const int s3 = (tt + 1) % 3; return s3; };          // tt >= -1
+  auto issue_plane_piece = [&](int n_t0, int tt, int ps) {                          // n_t0 = n * T
+    if (ps == PNPASS - 1 && wave == 3) return;                                      // rows 376..383 do not exist
+    const bool pok = (unsigned)tt < (unsigned)g.T;
+    const unsigned so = __builtin_amdgcn_readfirstlane(pok ? (unsigned)((n_t0 + tt) * g.HW) * (HC * 2) : 0u);
+    const unsigned vo = pok ? win_voff[ps] : HOOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + slot_of(tt) * PPLANE + (ps * 256 + wave * 64) * 16), 16, vo, so, 0, 0);
+  };
+  auto issue_weights = [&](int idx, int stage) {                                    // idx = window-order tap
+    const int tapw = mode ? 26 - idx : idx;
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tapw * HC * 2));
+    unsigned char* dst = Ws + stage * (64 * 128) + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
+  };
+  bf16x8_t fa[2][2][4], fb[2][2][4];                       // [buffer][ks][fragment]
+  auto read_operands = [&](int idx, int buf, int stage, int t) {                    // operands of window tap idx of output plane t
+    const int gq = idx / 9, a = (idx % 9) / 3, b = idx % 3;
+    const unsigned char* wb = Ws + stage * (64 * 128);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fb[buf][0][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr0 + j * 2048);
+      fb[buf][1][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr1 + j * 2048);
+    }
+    const int row = arow0 + a * g.Wp + b;
+    const int key = row & 7;
+    const unsigned char* hb = Hs + slot_of(t - 1 + gq) * PPLANE + row * 128;
+    const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[buf][0][i] = *reinterpret_cast<const bf16x8_t*>(hb + g0 + i * 2048);
+      fa[buf][1][i] = *reinterpret_cast<const bf16x8_t*>(hb + g1 + i * 2048);
+    }
+  };
+
+  int par = 0;
+  bool cont = false;                         // this item continues the previous item's chain (operands prefetched)
+  for (int it = it_beg; it < it_end; ++it) {
+    const int chain = fdiv(it, g.dT), t = it - chain * g.T;          // chain = n * tiles + tile
+    const int n = fdiv(chain, g.dTiles), tile = chain - n * g.tiles;
+    const int n_t0 = n * g.T;
+    const int q0 = g.Wp + tile * HBM;
+    const bool next_cont = (it + 1 < it_end) && (t + 1 < g.T);
+    if (!cont) {
+      // ---- chain start: window offsets of this tile, all three planes, first two weight tiles ----
+#pragma unroll
+      for (int ps = 0; ps < PNPASS; ++ps) {
+        const int j = ps * 32 + (tid >> 3), pg = tid & 7;
+        const int lg = pg ^ (j & 7);
+        const int q = q0 - g.Wp - 1 + j;
+        const int hp = fdiv(q < 0 ? 0 : q, g.dWp), wp = q - hp * g.Wp;
+        const bool ok = q >= 0 && hp >= 1 && hp <= g.H && wp >= 1 && wp <= g.W;
+        win_voff[ps] = ok ? (unsigned)((((hp - 1) * g.W + (wp - 1)) * HC + lg * 8) * 2) : HOOB;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = q0 + wave * 64 + i * 16 + fr;
+        const int hp = fdiv(q, g.dWp), wp = q - hp * g.Wp;
+        opos[i] = (hp <= g.H && wp >= 1 && wp <= g.W) ? ((hp - 1) * g.W + (wp - 1)) * HC : -1;
+      }
+      // a slower wave may still be fetching the previous item's last operands (issued after the tap-25 barrier)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t - 1, ps);
+      issue_weights(0, par);
+#pragma unroll
+      for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t, ps);
+#pragma unroll
+      for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t + 1, ps);
+      issue_weights(1, par ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_operands(0, 0, par, t);
+    }
+    f32x4_t acc[4][4];                                     // [j: channel tile][i: position tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int idx = 0; idx < 27; ++idx) {
+      const int cur = idx & 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][0][j], fa[cur][0][i], acc[j][i], 0, 0, 0);
+      if (idx < 26 || next_cont) {
+        // everything issued a tap ago has landed for this wave; the barrier publishes it and says every wave holds its
+        // tap-`idx` fragments, so weight stage (idx & 1) ^ par may be refilled
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (idx < 26) read_operands(idx + 1, cur ^ 1, ((idx + 1) & 1) ^ par, t);
+        else read_operands(0, 1, par ^ 1, t + 1);                                   // next item's first tap
+        if (idx >= 9 && idx < 9 + PNPASS && next_cont) issue_plane_piece(n_t0, t + 2, idx - 9);    // slot of plane t-1: free since tap 8
+        if (idx + 2 < 27) issue_weights(idx + 2, cur ^ par);
+        else if (next_cont) issue_weights(idx + 2 - 27, cur ^ par);
+      }
+      __builtin_amdgcn_sched_barrier(0);        // keep the next tap's operand reads ABOVE this tap's second k step
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- item epilogue: statistics into registers, (+addend) -> bf16, 8-byte stores ----
+    const long pbase = (long)(n_t0 + t) * g.HW * HC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (opos[i] < 0) continue;
+      const long o0 = pbase + opos[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nn = j * 16 + fq * 4;
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[j][r] += v[r]; ssq[j][r] += v[r] * v[r]; }
+        if (addend != nullptr) {
+          const uint2 av = *reinterpret_cast<const uint2*>(addend + o0 + nn);
+          v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
+          v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
+        }
+        uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(out + o0 + nn) = pv;
+      }
+    }
+    if (next_cont) {                         // 27 taps: the prefetched operands sit in buffer 1, the next item starts on buffer 0
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { fa[0][ks][f] = fa[1][ks][f]; fb[0][ks][f] = fb[1][ks][f]; }
+      par ^= 1;
+    }
+    cont = next_cont;
+  }
+
+  // ---- block epilogue: BatchNorm statistics, one reduction and 128 atomics per block ----
+  if (stat_sum != nullptr) {
+    for (int i = tid; i < 2 * HC; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sv = ssum[j][r], qv = ssq[j][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+        if (fr == 0) {
+          const int nl = j * 16 + fq * 4 + r;
+          atomicAdd(&red[nl], sv);
+          atomicAdd(&red[HC + nl], qv);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < HC; i += 256) { atomicAdd(&stat_sum[i], red[i]); atomicAdd(&stat_sq[i], red[HC + i]); }
+  }
+}
+
 // returns 1 if launched, 0 if the shape is not covered (caller falls back to the implicit-GEMM kernel), <0 / >0 on error
 extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream) {
@@ -302,6 +520,29 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
   if (HBM + 2 * g.Wp + 2 > NH || (long)d->N * d->T * g.HW * HC * 2 >= (1L << 31)) return 0;
   g.tiles = (d->H * g.Wp + HBM - 1) / HBM; g.mode = mode;
   g.dWp = make_fastdiv(g.Wp);
+  g.dT = make_fastdiv(d->T); g.dTiles = make_fastdiv(g.tiles);
+  // opt-in: alone it is faster on the forward conv (119 vs 135 us: statistics once per block) and equal on the
+  // gradient (118 vs 114 us), but inside the three-stream step its 256 long-lived 160-KB blocks schedule worse
+  // against the other streams' kernels (725 vs 734 clip-pairs/s)
+  const char* pv = getenv("MSCL_HALO_PERSIST");
+  if (pv && pv[0] == '1' && HBM + 2 * g.Wp + 2 <= NHP) {
+    static int cus = 0;
+    static bool attr_done_p = false;
+    if (!attr_done_p) {
+      int dev = 0; (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (cus <= 0) cus = 256;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done_p = true;
+    }
+    const int items = d->N * d->T * g.tiles;
+    const int grid = items < cus ? items : cus;
+    const size_t ldsp = (size_t)3 * PPLANE + 2 * 64 * 128 + 2 * HC * sizeof(float);
+    hipLaunchKernelGGL(conv_halo64p_kernel, dim3((unsigned)grid), dim3(256), ldsp, (hipStream_t)stream, g, items, src, w, out, addend,
+                       ssum, ssq);
+    MSCL_LAUNCH_CHECK();
+    return 1;
+  }
   const size_t lds = (size_t)3 * PLANE_BYTES + 2 * 64 * 128;
   static bool attr_done = false;
   if (!attr_done) {
