@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
+from . import parallel
 from .lib import MsclError
 
 
@@ -107,14 +108,39 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
                             want_identity_dres=want_dres)
     rt['slot_g'].touched = True
     rt['slot_b'].touched = True
-    conv.wgrad(x, dy)
+    _wgrad(conv, x, dy)
     dx = conv.dgrad(dy, x.shape, addend=dx_addend) if need_dx else None
     return dx, dres
 
 
+# Weight gradients are leaves of the backward dependency chain (only the input gradient feeds the next layer), so
+# the convs whose backward runs on a stream registered here launch their wgrad kernel on the paired side stream:
+# the dgrad / BN-backward chain no longer waits for them.  {stream handle: side torch.cuda.Stream}
+WGRAD_SIDE = {}
+
+
+def _wgrad(conv, x, dy):
+    cur = torch.cuda.current_stream()
+    side = WGRAD_SIDE.get(cur.cuda_stream)
+    if side is None:
+        conv.wgrad(x, dy)
+        return
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        conv.wgrad(x, dy)
+    x.record_stream(side)
+    dy.record_stream(side)
+
+
 def _bucket_done(mod):
     """data-parallel hook: this module's backward completes a gradient bucket -> start its all-reduce now"""
-    for red, i in getattr(mod, '_grad_buckets', ()):
+    buckets = getattr(mod, '_grad_buckets', ())
+    if buckets and parallel.world_size() > 1:
+        cur = torch.cuda.current_stream()
+        side = WGRAD_SIDE.get(cur.cuda_stream)
+        if side is not None:
+            cur.wait_stream(side)               # the bucket's weight gradients were written on the side stream
+    for red, i in buckets:
         red.bucket_done(i)
 
 

@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import kernels as K
+from . import nn as nn_hip
 from . import parallel
 from .arena import ParamArena
 from .lib import MsclError
@@ -235,7 +236,8 @@ class MSCLWithAug(nn.Module):
         self._step = 0
         self._scal_host = self._scal_dev = None
         self._bg = 0
-        self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'     # MSCL_STREAMS=1: everything on the current stream
+        self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
+        self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0') == '1'     # measured 13 % slower: two MFMA-heavy kernels thrash     # MSCL_STREAMS=1: everything on the current stream
         self._side = None
 
     # ------------------------------------------------------------------ device placement
@@ -485,6 +487,9 @@ class MSCLWithAug(nn.Module):
         # rank) on the communicator's own stream, so the same layout holds for world size > 1.
         main = torch.cuda.current_stream()
         multi = self.two_streams
+        nn_hip.WGRAD_SIDE.clear()
+        if multi and self.wgrad_stream:
+            nn_hip.WGRAD_SIDE[main.cuda_stream] = self._side_stream(2)      # RGB backward: wgrad off the dgrad chain
         s_fq = self._side_stream(0) if multi else main       # flow query passes (base, rotated): share BN running stats -> in order
         s_fk = s_fq                                          # flow key passes share the flow stream (a 4th stream measured 3 % slower)
         side = s_fq
