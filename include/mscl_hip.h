@@ -103,9 +103,16 @@ int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y
  * frames [t_off, t_off+T) of (B,Cin<=3,T_total,H,W) fp32 NCTHW -> (B,T,H,W,8) bf16 NDHWC, channels Cin..7
  * zero (the chunk(2, dim=2) of recognizers/mscl.py:230-235 without a copy); optional per-channel
  * (x-mean)/std = the deterministic Normalize of common/ssl_aug_v2.py:66-68.  mean3/std3 are HOST
- * arrays of 3 floats (or NULL). */
+ * arrays of 3 floats (or NULL).  flip_mask (device, B bytes, or NULL): samples with a non-zero byte are mirrored
+ * along W = the horizontal flip of common/ssl_aug_v2.py:107-118 given its Bernoulli draw. */
 int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
-                    const float* mean3, const float* std3, void* stream);
+                    const float* mean3, const float* std3, const uint8_t* flip_mask, void* stream);
+/* optical flow (B,2,T_total,H,W) fp32 uv -> colour-wheel image, frames [t_off, t_off+T), as (B,T,H,W,8) bf16 NDHWC
+ * (channels 3..7 zero): FlowVisualizer / flow_uv_to_colors of common/ssl_aug.py:87-136 with the Middlebury wheel of
+ * tools/RAFT/core/utils/flow_viz.py:19-68, including the uint8 floor; `levels` (optional, (B,T,H,W,3) bytes) receives
+ * the quantised levels themselves.  flip_mask as above (the reference flips the visualised image, not the vectors). */
+int mscl_flow_visualize(const float* uv, uint16_t* out, uint8_t* levels, int B, int T, int H, int W, int T_total, int t_off,
+                        const uint8_t* flip_mask, void* stream);
 /* out = relu?(a + b + c) elementwise bf16 (b, c optional) */
 int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, int relu, void* stream);
 /* din = dout * (out > 0) */

@@ -1,11 +1,12 @@
 """GPU-side input stage.  ref: mmaction/models/common/ssl_aug_v2.py:50-133 (SyncMoCoAugmentV5),
 common/ssl_aug.py:178-183 (IdentityAug).
 
-Scope this round (SURVEY.md §8f#1 is a "next" row): the deterministic part that the measured path
-needs -- ImageNet normalisation of the RGB views (ssl_aug_v2.py:66-68), fused into the NCTHW->NDHWC
-packing kernel; flow views arrive already visualised (3 channels) and pass through un-normalised
-(normalize_flow=False -> Identity, ssl_aug_v2.py:88).  The stochastic kornia ops (flip, colour jitter,
-grayscale, blur) and the uv->colour-wheel visualiser are not implemented; asking for them raises.
+Implemented: the deterministic part -- ImageNet normalisation of the RGB views (ssl_aug_v2.py:66-68), the
+uv -> colour-wheel FlowVisualizer with its uint8 floor (ssl_aug.py:87-136) for 2-channel flow clips, and the
+horizontal flip GIVEN its per-sample Bernoulli mask (ssl_aug_v2.py:107-118: RGB clips and the visualised flow image
+are mirrored along W) -- all fused into the NCTHW -> NDHWC packing kernels.  3-channel flow clips are taken as already
+visualised and pass through un-normalised (normalize_flow=False -> Identity, ssl_aug_v2.py:88).  The stochastic kornia
+ops (drawing the flip mask, colour jitter, grayscale, blur) are not implemented; asking for them raises.
 """
 from . import kernels as K
 from .registry import SSL_AUGS
@@ -24,16 +25,19 @@ class SyncMoCoAugmentV5:
         self.crop_size, self.t, self.flow_suffix = crop_size, t, flow_suffix
         self.visualize, self.normalize_flow = visualize, normalize_flow
 
-    def pack_rgb(self, x):
-        return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD)
+    def pack_rgb(self, x, flip=None):
+        return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, flip=flip)
 
-    def pack_flow(self, x, t_off, T):
-        if x.shape[1] != 3:
-            raise NotImplementedError('2-channel uv flow needs the colour-wheel visualiser (ssl_aug.py:87-136), a "next" row; '
-                                      'feed visualised 3-channel flow clips')
+    def pack_flow(self, x, t_off, T, flip=None):
+        if x.shape[1] == 2:                     # raw (u, v): FlowVisualizer fused into the packing pass
+            if not self.visualize:
+                raise NotImplementedError('visualize=False with 2-channel flow: the flow trunk takes 3 input channels')
+            if self.normalize_flow:
+                raise NotImplementedError('normalize_flow=True on raw uv flow (the shipped config uses False)')
+            return K.flow_visualize(x.contiguous(), t_off=t_off, T=T, flip=flip)
         if self.normalize_flow:
-            return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, t_off=t_off, T=T)
-        return K.pack_input(x.contiguous(), t_off=t_off, T=T)
+            return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, t_off=t_off, T=T, flip=flip)
+        return K.pack_input(x.contiguous(), t_off=t_off, T=T, flip=flip)
 
 
 @SSL_AUGS.register_module()
@@ -44,8 +48,10 @@ class IdentityAug:
     def __call__(self, clips):
         return clips
 
-    def pack_rgb(self, x):
-        return K.pack_input(x.contiguous())
+    def pack_rgb(self, x, flip=None):
+        return K.pack_input(x.contiguous(), flip=flip)
 
-    def pack_flow(self, x, t_off, T):
-        return K.pack_input(x.contiguous(), t_off=t_off, T=T)
+    def pack_flow(self, x, t_off, T, flip=None):
+        if x.shape[1] == 2:
+            return K.flow_visualize(x.contiguous(), t_off=t_off, T=T, flip=flip)
+        return K.pack_input(x.contiguous(), t_off=t_off, T=T, flip=flip)

@@ -7,10 +7,13 @@
 // recognizers/mscl.py:230-235, are packed straight from the concatenated tensor)
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B,
                                                          int Cin, long THW, long THW_total, long off, float m0, float m1,
-                                                         float m2, float i0, float i1, float i2) {
+                                                         float m2, float i0, float i1, float i2,
+                                                         const unsigned char* __restrict__ flip, int W) {
   const long total = (long)B * THW;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long b = e / THW, p = e - b * THW;
+    const long b = e / THW;
+    long p = e - b * THW;
+    if (flip != nullptr && flip[b]) { const long row = p / W; p = row * W + (W - 1 - (p - row * W)); }   // torch.flip(x, [-1])
     const float* xb = x + b * Cin * THW_total + off + p;
     float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     f[0] = (xb[0] - m0) * i0;
@@ -21,7 +24,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 }
 
 extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
-                               const float* mean3, const float* std3, void* stream) {
+                               const float* mean3, const float* std3, const uint8_t* flip_mask, void* stream) {
   if (!x || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t_off < 0 || t_off + T > T_total) return MSCL_E_ARG;
   if (Cin < 1 || Cin > 3) return MSCL_E_SHAPE;
   float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
@@ -29,7 +32,63 @@ extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, in
   const long THW = (long)T * H * W, total = (long)B * THW;
   long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, B, Cin, THW,
-                     (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
+                     (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2], flip_mask, W);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- optical flow (u, v) -> colour wheel image
+// ref: common/ssl_aug.py:87-136 (flow_uv_to_colors / FlowVisualizer), colour wheel tools/RAFT/core/utils/flow_viz.py:19-68.
+// The reference mixes precisions and this kernel follows it operation by operation: radius, angle and the wheel
+// position fk are float32; the colour interpolation runs in float64 (the wheel is a float64 numpy array); the result is
+// floor(255 * col) as a byte, then byte / 255 in float32.  No FMA contraction where the reference rounds twice.
+__device__ const unsigned char kColorWheel[55][3] = {
+  {255,0,0},{255,17,0},{255,34,0},{255,51,0},{255,68,0},{255,85,0},{255,102,0},{255,119,0},{255,136,0},{255,153,0},{255,170,0},
+  {255,187,0},{255,204,0},{255,221,0},{255,238,0},{255,255,0},{213,255,0},{170,255,0},{128,255,0},{85,255,0},{43,255,0},{0,255,0},
+  {0,255,63},{0,255,127},{0,255,191},{0,255,255},{0,232,255},{0,209,255},{0,186,255},{0,163,255},{0,140,255},{0,116,255},{0,93,255},
+  {0,70,255},{0,47,255},{0,24,255},{0,0,255},{19,0,255},{39,0,255},{58,0,255},{78,0,255},{98,0,255},{117,0,255},{137,0,255},
+  {156,0,255},{176,0,255},{196,0,255},{215,0,255},{235,0,255},{255,0,255},{255,0,213},{255,0,170},{255,0,128},{255,0,85},{255,0,43}};
+
+__global__ __launch_bounds__(256) void flow_visualize_kernel(const float* __restrict__ uv, bf16_t* __restrict__ out,
+                                                             unsigned char* __restrict__ levels, int B, long THW, long THW_total,
+                                                             long off, const unsigned char* __restrict__ flip, int W) {
+  const long total = (long)B * THW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / THW;
+    long p = e - b * THW;
+    if (flip != nullptr && flip[b]) { const long row = p / W; p = row * W + (W - 1 - (p - row * W)); }   // flip of the IMAGE (ssl_aug_v2.py:118)
+    const float* ub = uv + b * 2 * THW_total + off + p;
+    const float u = ub[0], v = ub[THW_total];
+    const float rad = __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)));
+    const float a = __fdiv_rn(atan2f(-v, -u), 3.14159265358979323846f);
+    const float fk = __fmul_rn(__fdiv_rn(__fadd_rn(a, 1.0f), 2.0f), 54.0f);
+    const float k0f = floorf(fk);
+    int k0 = (int)k0f, k1 = k0 + 1;
+    if (k1 == 55) k1 = 0;
+    const float f = __fsub_rn(fk, k0f);
+    const double w0 = (double)__fsub_rn(1.0f, f), w1 = (double)f, radd = (double)rad;
+    float c3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double col0 = (double)kColorWheel[k0][i] / 255.0, col1 = (double)kColorWheel[k1][i] / 255.0;
+      double col = __dadd_rn(__dmul_rn(w0, col0), __dmul_rn(w1, col1));
+      if (rad <= 1.0f) col = __dsub_rn(1.0, __dmul_rn(radd, __dsub_rn(1.0, col)));
+      else col = __dmul_rn(col, 0.75);
+      const unsigned char lv = (unsigned char)(int)floor(__dmul_rn(255.0, col));
+      if (levels != nullptr) levels[e * 3 + i] = lv;
+      c3[i] = __fdiv_rn((float)lv, 255.0f);
+    }
+    *reinterpret_cast<uint4*>(out + e * 8) = pack8(c3);
+  }
+}
+
+extern "C" int mscl_flow_visualize(const float* uv, uint16_t* out, uint8_t* levels, int B, int T, int H, int W, int T_total,
+                                   int t_off, const uint8_t* flip_mask, void* stream) {
+  if (!uv || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t_off < 0 || t_off + T > T_total) return MSCL_E_ARG;
+  const long THW = (long)T * H * W, total = (long)B * THW;
+  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(flow_visualize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, uv, out, levels, B, THW,
+                     (long)T_total * H * W, (long)t_off * H * W, flip_mask, W);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

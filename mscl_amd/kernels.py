@@ -145,8 +145,9 @@ def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, r
     return dy, dres
 
 
-def pack_input(x, mean=None, std=None, t_off=0, T=None):
-    """frames [t_off, t_off+T) of (B,C<=3,Ttot,H,W) fp32 -> (B,T,H,W,8) bf16, optional (x-mean)/std."""
+def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None):
+    """frames [t_off, t_off+T) of (B,C<=3,Ttot,H,W) fp32 -> (B,T,H,W,8) bf16, optional (x-mean)/std, optional
+    per-sample horizontal flip (uint8 mask of B entries on the device)."""
     B, C, Ttot, H, W = x.shape
     T = Ttot - t_off if T is None else T
     if not x.is_contiguous():
@@ -154,8 +155,21 @@ def pack_input(x, mean=None, std=None, t_off=0, T=None):
     out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=x.device)
     m = (ctypes.c_float * 3)(*mean) if mean is not None else None
     s = (ctypes.c_float * 3)(*std) if std is not None else None
-    call('mscl_pack_input', ptr(x), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, stream_ptr())
+    call('mscl_pack_input', ptr(x), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, ptr(flip), stream_ptr())
     return out
+
+
+def flow_visualize(uv, t_off=0, T=None, flip=None, want_levels=False):
+    """(B,2,Ttot,H,W) fp32 optical flow -> colour-wheel image (B,T,H,W,8) bf16 (ssl_aug.py:87-136);
+    with want_levels also the quantised bytes (B,T,H,W,3)."""
+    B, C, Ttot, H, W = uv.shape
+    T = Ttot - t_off if T is None else T
+    if C != 2 or not uv.is_contiguous():
+        raise lib.MsclError('flow_visualize needs a contiguous (B,2,T,H,W) tensor')
+    out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=uv.device)
+    lv = torch.empty((B, T, H, W, 3), dtype=torch.uint8, device=uv.device) if want_levels else None
+    call('mscl_flow_visualize', ptr(uv), ptr(out), ptr(lv), B, T, H, W, Ttot, t_off, ptr(flip), stream_ptr())
+    return (out, lv) if want_levels else out
 
 
 def add_relu(a, b=None, c=None, relu=False):

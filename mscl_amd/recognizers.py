@@ -380,6 +380,8 @@ class MSCLWithAug(nn.Module):
         for item in self.aux_info:
             assert item in data_batch
             aux[item] = data_batch[item]
+        if 'flip_mask' in data_batch:           # [mask_q, mask_k], uint8 (B,): the Bernoulli draw of ssl_aug_v2.py:107-110
+            aux['flip_q'], aux['flip_k'] = data_batch['flip_mask'][0], data_batch['flip_mask'][1]
         loss, logs = self.forward_train(im_q, im_k, aux)
         log_vars = self._parse_logs(logs, sync_logs)
         return dict(loss=loss, log_vars=log_vars, num_samples=im_q.shape[0])
@@ -407,7 +409,8 @@ class MSCLWithAug(nn.Module):
             raise MsclError('call model.materialize("cuda") before the first step')
         fk = self.flow_key[0]
         self._pre_step_host(im_q.shape[0])
-        loss, logs = self._device_step(im_q, im_k, aux_info[f'{fk}_q'], aux_info[f'{fk}_k'])
+        loss, logs = self._device_step(im_q, im_k, aux_info[f'{fk}_q'], aux_info[f'{fk}_k'],
+                                       aux_info.get('flip_q'), aux_info.get('flip_k'))
         self._post_step_host()
         return loss, logs
 
@@ -460,12 +463,17 @@ class MSCLWithAug(nn.Module):
             return x          # a within-batch permutation does not change per-GPU BN statistics
         return parallel.all_gather_cat(x).index_select(0, self._idx_dev[slot])
 
+    def _shuffle_mask(self, m, slot):
+        if m is None or parallel.world_size() == 1:
+            return m
+        return self._shuffle(m.view(-1, 1), slot).view(-1).contiguous()
+
     def _unshuffle(self, k, slot):
         if parallel.world_size() == 1:
             return k
         return parallel.all_gather_cat(k).index_select(0, self._idx_dev[3 + slot])
 
-    def _device_step(self, im_q, im_k, flow_q, flow_k):
+    def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None):
         rec, recf = self.recognizer, self.recognizer_flow
         T2 = flow_q.shape[2]
         if T2 % 2:
@@ -497,30 +505,30 @@ class MSCLWithAug(nn.Module):
             if st is not main:
                 st.wait_stream(main)
         with torch.cuda.stream(s_fq):
-            q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th))
-            q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th))
+            q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th, flip_q))
+            q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th, flip_q))
             m_fb, m_fa = maps_fb[ids[1]], maps_fa[ids[1]]
             p_fb = pool(m_fb, m_fb.shape[0] * m_fb.shape[1], hw(m_fb))
             p_fa = pool(m_fa, m_fa.shape[0] * m_fa.shape[1], hw(m_fa))
         with torch.cuda.stream(s_fk):
             # two EMA updates, two BN-statistics passes (App. E-5)
             recf.momentum_update(sc[1:2])
-            k_fb, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 1), 0, Th))
+            k_fb, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 1), 0, Th, self._shuffle_mask(flip_k, 1)))
             k_fb = self._unshuffle(k_fb, 1)
             recf.momentum_update(sc[2:3])
-            k_fa, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 2), Th, Th))
+            k_fa, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 2), Th, Th, self._shuffle_mask(flip_k, 2)))
             k_fa = self._unshuffle(k_fa, 2)
         # -- RGB key branch (no gradient): a third stream, it only meets the query branch in the loss
         side_k = self._side_stream(1) if side is not main else main
         if side_k is not main:
             side_k.wait_stream(main)
         with torch.cuda.stream(side_k):
-            x_k = aug.pack_rgb(self._shuffle(im_k, 0))
+            x_k = aug.pack_rgb(self._shuffle(im_k, 0), self._shuffle_mask(flip_k, 0))
             rec.momentum_update(sc[0:1])
             k_rgb, _ = rec.encode_k(x_k)
             k_rgb = self._unshuffle(k_rgb, 0)
         # -- RGB query branch
-        x_q = aug.pack_rgb(im_q)
+        x_q = aug.pack_rgb(im_q, flip_q)
         q_rgb, maps_rgb = rec.encode_q(x_q)
         if side_k is not main:
             main.wait_stream(side_k)

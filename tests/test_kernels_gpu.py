@@ -322,3 +322,38 @@ def test_ema_sgd(dev):
         K_.sgd_step(pd, g.to(dev), buf, pbf, ss, 40.0, 0.02, 0.9, 1e-4, first=(step == 0))
         close(pd, p.detach(), 2e-6, f'sgd step {step}')
     assert torch.equal(pbf.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def test_flow_visualize_vs_reference_golden(dev):
+    """uv -> colour wheel (ssl_aug.py:87-136).  Byte work: the quantised levels must equal the reference's.  The one
+    tolerated difference: the angle goes through atan2f, whose last bit differs between the host's vector library (the
+    golden was produced on a CPU) and the device's -- as it does between the reference's own CPU and CUDA runs -- and
+    where the interpolated colour sits within ~1e-6 of a quantisation edge that flips floor() by one level.
+    Bound: never more than 1 level, on at most 0.5 % of the elements (observed 0.2 % on the edge-case grid)."""
+    import os
+    import numpy as np
+    from mscl_amd import kernels as K_
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'flowvis_g7.npz'))
+    for a, b in (('uv', 'levels'), ('uv2', 'levels2')):
+        uv = torch.from_numpy(g[a]).to(dev)
+        want = torch.from_numpy(g[b]).permute(0, 2, 3, 4, 1).contiguous()          # (B,3,T,H,W) -> (B,T,H,W,3)
+        out, lv = K_.flow_visualize(uv, want_levels=True)
+        d = (lv.cpu().int() - want.int()).abs()
+        assert int(d.max()) <= 1, int(d.max())
+        assert float((d > 0).float().mean()) <= 5e-3, float((d > 0).float().mean())
+        ref = (lv.float() / 255).to(torch.bfloat16)
+        assert torch.equal(out[..., :3], ref) and float(out[..., 3:].abs().max()) == 0.0
+        # frame window + horizontal flip of the image for sample 1
+        flip = torch.tensor([0, 1], dtype=torch.uint8, device=dev)
+        T = uv.shape[2]
+        out2, lv2 = K_.flow_visualize(uv, t_off=T // 2, T=T // 2, flip=flip, want_levels=True)
+        assert torch.equal(lv2[0], lv[0, T // 2:]) and torch.equal(lv2[1], lv[1, T // 2:].flip(2))
+
+
+def test_pack_input_flip(dev):
+    from mscl_amd import kernels as K_
+    x = torch.rand((3, 3, 4, 6, 10), device=dev)
+    flip = torch.tensor([1, 0, 1], dtype=torch.uint8, device=dev)
+    a = K_.pack_input(x, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), flip=flip)
+    b = K_.pack_input(x, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0].flip(2)) and torch.equal(a[2], b[2].flip(2))

@@ -298,3 +298,35 @@ def test_two_ranks_one_gpu(dev):
         p.join(60)
     for r, msg in res:
         assert msg == 'ok', f'rank {r}:\n{msg}'
+
+
+def test_uv_flow_and_flip_inputs(dev):
+    """SURVEY section 8(f)#1, deterministic part: raw (u, v) flow clips go through the fused FlowVisualizer kernel and give
+    the step that pre-visualised 3-channel clips give; a per-sample flip mask equals flipping the inputs on the host
+    (RGB: torch.flip of the clip; flow: flip of the visualised IMAGE, ssl_aug_v2.py:118)."""
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import flowvis
+    B, T, H, Kq = 2, 8, 32, 64
+    g = torch.Generator().manual_seed(5)
+    uv = [torch.randn((B, 2, 2 * T, H, H), generator=g) * 0.7 for _ in range(2)]
+    vis = flowvis.FlowVisualizer()
+    batch = synthetic_batch(B, T, H, H, 0, 0)
+    flip = [torch.tensor([1, 0], dtype=torch.uint8), torch.tensor([0, 1], dtype=torch.uint8)]
+
+    def flipped(x, m):
+        x = x.clone()
+        x[m.bool()] = torch.flip(x[m.bool()], [-1])
+        return x
+    variants = {
+        'uv+mask': dict(imgs=batch['imgs'], flow_imgs=uv, flip_mask=flip),
+        'host': dict(imgs=[flipped(x, m) for x, m in zip(batch['imgs'], flip)],
+                     flow_imgs=[flipped(vis(x), m) for x, m in zip(uv, flip)]),
+    }
+    losses = {}
+    for name, b in variants.items():
+        model, _ = build(T, Kq, dev)
+        out = model.train_step({k: [t.to(dev) for t in v] for k, v in b.items()})
+        losses[name] = out['log_vars']
+    for k, v in losses['host'].items():
+        if 'loss' in k:
+            assert abs(losses['uv+mask'][k] - v) <= 2e-3 * max(1.0, abs(v)), (k, losses['uv+mask'][k], v)

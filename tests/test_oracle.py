@@ -85,3 +85,17 @@ def test_momentum_schedule_closed_form():
     for it in (0, 1, 10 ** 6, 219136 * 400, 10 ** 9):
         assert momentum_at(it, 219136 * 400, 0.994) == om.momentum_at(it, 219136 * 400, 0.994)
     assert om.momentum_at(0, 100, 0.994) == 0.994 and abs(om.momentum_at(100, 100, 0.994) - 1.0) < 1e-15
+
+
+def test_flow_visualizer_oracle_vs_reference_golden():
+    """G7: oracle/flowvis.py reproduces the levels the reference's FlowVisualizer produced (tools/oracle/make_golden_flowvis.py)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import flowvis
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'flowvis_g7.npz'))
+    assert np.array_equal(flowvis.make_colorwheel(), g['colorwheel'])
+    vis = flowvis.FlowVisualizer()
+    for a, b in (('uv', 'levels'), ('uv2', 'levels2')):
+        out = vis(torch.from_numpy(g[a]))
+        assert np.array_equal(torch.round(out * 255).to(torch.uint8).numpy(), g[b])
