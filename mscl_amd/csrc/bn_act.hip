@@ -108,22 +108,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     rmu[i] = ry ? rmean[c0 + i] : 0.f; riv[i] = ry ? rinv[c0 + i] : 0.f;
   }
   float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long r = (long)blockIdx.x * RP + tr; r < rows; r += (long)gridDim.x * RP) {
-    const long o = r * C + c0;
-    float d[8], a[8], yy[8];
-    unpack8(*reinterpret_cast<const uint4*>(dout + o), d);
-    unpack8(*reinterpret_cast<const uint4*>(y + o), yy);
-    if (relu) {
-      unpack8(*reinterpret_cast<const uint4*>(out + o), a);
+  // UNR rows per trip, every load issued before the first use: the loop is latency-bound (a thread makes only ~12
+  // trips on the largest map), so the trips must overlap their round trips to HBM / Infinity Cache
+  constexpr int UNR = 4;
+  const long stride = (long)gridDim.x * RP;
+  for (long r0 = (long)blockIdx.x * RP + tr; r0 < rows; r0 += stride * UNR) {
+    uint4 vd[UNR], vy[UNR], va[UNR], vr[UNR];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
+    for (int u = 0; u < UNR; ++u) {
+      const long r = r0 + u * stride;
+      const long o = (r < rows ? r : r0) * C + c0;          // clamped: the duplicate is masked out below
+      vd[u] = *reinterpret_cast<const uint4*>(dout + o);
+      vy[u] = *reinterpret_cast<const uint4*>(y + o);
+      if (relu) va[u] = *reinterpret_cast<const uint4*>(out + o);
+      if (ry) vr[u] = *reinterpret_cast<const uint4*>(ry + o);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s0[i] += d[i]; s1[i] += d[i] * (yy[i] - mu[i]) * iv[i]; }
-    if (ry) {
-      float rr[8]; unpack8(*reinterpret_cast<const uint4*>(ry + o), rr);
+    for (int u = 0; u < UNR; ++u) {
+      if (r0 + u * stride >= rows) continue;
+      float d[8], a[8], yy[8];
+      unpack8(vd[u], d);
+      unpack8(vy[u], yy);
+      if (relu) {
+        unpack8(va[u], a);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s2[i] += d[i] * (rr[i] - rmu[i]) * riv[i];
+        for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s0[i] += d[i]; s1[i] += d[i] * (yy[i] - mu[i]) * iv[i]; }
+      if (ry) {
+        float rr[8]; unpack8(vr[u], rr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s2[i] += d[i] * (rr[i] - rmu[i]) * riv[i];
+      }
     }
   }
   // block reduction without LDS atomics: shuffles inside a wave, plain LDS stores across waves
