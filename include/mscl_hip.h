@@ -58,9 +58,11 @@ int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_
 /* dw[Cout][taps][Cin] (fp32) += sum over positions of dy (x) x ; atomically accumulated, so the
  * caller zeroes dw once per step and repeated traversals of a shared trunk simply add up
  * (the flow encoder is traversed twice, recognizers/mscl.py:239-240).  dbias (K floats, optional)
- * += sum over positions of dy.  Replaces autograd's conv3d weight/bias gradient. */
+ * += sum over positions of dy.  Replaces autograd's conv3d weight/bias gradient.  ws (optional, ws_floats fp32):
+ * scratch for the window-resident layer-1 kernel (3x3x3 s1 p1, 64 -> 64), which stores per-block partial slabs and
+ * reduces them in a second pass; 256 * 36864 floats cover every shape; NULL selects the general kernel. */
 int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
-                      float* dbias, void* stream);
+                      float* dbias, float* ws, int64_t ws_floats, void* stream);
 
 /* [Cout][taps][Cin] bf16 -> [Cin][taps][Cout] bf16 */
 int mscl_weight_transpose(const uint16_t* w, uint16_t* wT, int Cout, int taps, int Cin, void* stream);

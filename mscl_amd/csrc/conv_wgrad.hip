@@ -28,6 +28,16 @@ struct WGeom {
 
 __device__ __forceinline__ int wswz(int row) { return (row & 2) | ((row >> 1) & 4); }   // XOR on the 16-byte granule index
 
+// ds_read_b64_tr_b16 as inline asm (see the main loop) + the matching hand-placed wait; the "+v" operands tie the
+// consumers of the two registers to the wait
+__device__ __forceinline__ s16x4_t lds_tr_read(const unsigned char* p) {
+  s16x4_t v;
+  const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)(p);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait2(s16x4_t& x, s16x4_t& y) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y)); }
+
 __device__ __forceinline__ auto wg_rsrc(const void* p, unsigned bytes) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
@@ -168,33 +178,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
     const unsigned char* b = Bt + cur * PB * NCOL * 2;
 #pragma unroll
     for (int ks = 0; ks < PB / 32; ++ks) {
-      bf16x8_t fa[IA], fb[JB];
+      // The transposing reads are inline asm: hipcc guards every LDS read it knows about with s_waitcnt vmcnt(0) while an
+      // LDS-DMA is in flight (it cannot see that the DMA fills the OTHER stage), which used to serialise "stage tile s+1"
+      // and "compute tile s" completely.  The asm reads are invisible to that pass; lgkmcnt is waited for by hand.
+      s16x4_t va[IA][2], vb[JB][2];
 #pragma unroll
       for (int i = 0; i < IA; ++i) {
-        s16x4_t v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r = ks * 32 + 8 * grp + 4 * h + qq;
           const int gq = i * 2 + (pp >> 1);
           const unsigned char* ad = a + r * (CO * 2) + ((SWA ? (gq ^ wswz(r)) : gq) * 16) + (pp & 1) * 8;
-          v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(ad));
+          va[i][h] = lds_tr_read(ad);
         }
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-        s16x8_t w8 = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
-        fa[i] = __builtin_bit_cast(bf16x8_t, w8);
       }
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
-        s16x4_t v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r = ks * 32 + 8 * grp + 4 * h + qq;
           const int gq = (wave * WN) / 8 + j * 2 + (pp >> 1);
           const unsigned char* bd = b + r * (NCOL * 2) + ((SWB ? (gq ^ wswz(r)) : gq) * 16) + (pp & 1) * 8;
-          v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bd));
+          vb[j][h] = lds_tr_read(bd);
         }
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-        s16x8_t w8 = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
+      }
+      bf16x8_t fa[IA], fb[JB];
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        lds_wait2(va[i][0], va[i][1]);
+        s16x8_t w8 = {va[i][0][0], va[i][0][1], va[i][0][2], va[i][0][3], va[i][1][0], va[i][1][1], va[i][1][2], va[i][1][3]};
+        fa[i] = __builtin_bit_cast(bf16x8_t, w8);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        lds_wait2(vb[j][0], vb[j][1]);
+        s16x8_t w8 = {vb[j][0][0], vb[j][0][1], vb[j][0][2], vb[j][0][3], vb[j][1][0], vb[j][1][1], vb[j][1][2], vb[j][1][3]};
         fb[j] = __builtin_bit_cast(bf16x8_t, w8);
       }
 #pragma unroll
@@ -263,8 +282,11 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   return 0;
 }
 
+int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
+                      hipStream_t st);           // conv_wgrad_halo.hip
+
 extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
-                                 float* dbias, void* stream) {
+                                 float* dbias, float* ws, int64_t ws_floats, void* stream) {
   if (!d || !x || !dy || !dw) return MSCL_E_ARG;
   if (d->C % 8 || d->K % 8) return MSCL_E_SHAPE;
   if (ilog2_exact(d->K / 8) < 0 || d->K / 8 > 256 || ilog2_exact(d->C / 8) < 0) return MSCL_E_SHAPE;
@@ -280,9 +302,12 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   g.dWo = make_fastdiv(d->Wo); g.dHo = make_fastdiv(d->Ho); g.dTo = make_fastdiv(d->To);
   hipStream_t st = (hipStream_t)stream;
   int e;
+  const int hres = ws != nullptr ? mscl_wgrad_halo64(d, x, dy, dw, ws, ws_floats, st) : 0;   // layer-1 shape, window-resident
+  if (hres < 0 || hres > 1) return hres;
   bool wide = false;     // NCOL = 192 (three taps share one dy tile) measured slower than 64: fewer blocks per CU
   if (const char* f = getenv("MSCL_WGRAD_NCOL")) wide = atoi(f) == 192;
-  if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st) : launch_w<64, 64>(g, x, dy, dw, st);
+  if (hres == 1) e = 0;
+  else if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st) : launch_w<64, 64>(g, x, dy, dw, st);
   else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st) : launch_w<32, 64>(g, x, dy, dw, st);
   else if (d->K == 16) e = wide ? launch_w<16, 192>(g, x, dy, dw, st) : launch_w<16, 64>(g, x, dy, dw, st);
   else return MSCL_E_SHAPE;

@@ -1,0 +1,275 @@
+// Weight gradient of the layer-1 convolution (3x3x3 / stride 1 / pad 1, 64 -> 64) with the input window resident in
+// LDS:  dW[co][kt][a][b][ci] = sum over positions of dy[pos][co] * x[plane t+kt-1][pos + (a-1, b-1)][ci].
+//
+// Why: the general kernel (conv_wgrad.hip) re-stages the x rows once per tap; at 64 x 64 channels a step stages 16 KB
+// for 32 MFMAs = 128 B per MFMA-clock of a CU, twice what the global -> LDS path delivers: 254 us = 350 TFLOP/s.
+// Here a block walks (plane tile, kt) items of ONE kt: per item it stages the 376-row window of the source plane
+// (padded-linear order, see conv_halo.hip) and the 256-position dy tile ONCE (79 KB) and runs all 9 in-plane taps
+// against them, 1152 MFMAs: 69 B per MFMA.  The 9 x 64 x 64 partial products stay in registers (144 accumulators per
+// lane) over all items of the block; at the end every block stores its slab with plain stores and a small second kernel
+// adds the slabs into dW (float atomics of 147 KB per block would cost more than the GEMM, MI355X_MICROARCH.md).
+//  * both operands are position-major, so fragments are column reads: ds_read_b64_tr_b16 (as conv_wgrad.hip);
+//  * pad columns / rows outside the plane are zero in BOTH tiles (buffer range check), so they add nothing;
+//  * items are double-buffered in LDS (2 x 79 KB): the next item's DMA pieces are issued between the k steps.
+#include "common.h"
+#include <cstdlib>
+
+struct WHGeom {
+  int N, T, H, W, HW, Wp, tiles;   // tiles per plane (256 padded-linear positions each)
+  int total;                        // plane tiles = N * T * tiles
+  int gk;                           // blocks per kt
+  FastDiv dWp, dTiles, dT;
+};
+
+constexpr int WH_XROWS = 376, WH_XBYTES = WH_XROWS * 128, WH_DYBYTES = 256 * 128, WH_STAGE = WH_XBYTES + WH_DYBYTES;
+constexpr int WH_XPASS = 12, WH_DYPASS = 8;
+constexpr unsigned WH_OOB = 0x80000000u;
+constexpr int WH_SLAB = 9 * 64 * 64;
+
+__device__ __forceinline__ int whswz(int row) { return (row & 2) | ((row >> 1) & 4); }
+__device__ __forceinline__ auto wh_rsrc(const void* p) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
+  void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7FFFFFFF, 0x00020000);
+}
+typedef __attribute__((address_space(3))) void* wh_lds_t;
+typedef __attribute__((ext_vector_type(4))) short wh_s16x4;
+typedef __attribute__((ext_vector_type(8))) short wh_s16x8;
+
+__global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, const bf16_t* __restrict__ x,
+                                                              const bf16_t* __restrict__ dy, float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kt = blockIdx.x % 3, slot = blockIdx.x / 3;
+  const auto rs_x = wh_rsrc(x);
+  const auto rs_dy = wh_rsrc(dy);
+  // wave tile: all 64 co x ci [16*wave, +16): one B fragment per step feeds 4 MFMAs (a 32 x 32 tile needs twice the
+  // transposing reads per MFMA, and those, not the MFMAs, then set the pace)
+  const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+
+  // accumulators: [tap 0..8][co tile 0..3]
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t9][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // item = plane tile pt (valid when the source plane t + kt - 1 exists)
+  auto next_valid = [&](int pt) {
+    while (pt < g.total) {
+      const int plane = fdiv(pt, g.dTiles);
+      const int t = plane - fdiv(plane, g.dT) * g.T;
+      if ((unsigned)(t + kt - 1) < (unsigned)g.T) break;
+      pt += g.gk;
+    }
+    return pt;
+  };
+  // Per-item DMA state.  Piece k < 12 stages window rows 32k + (tid >> 3), piece 12 + k' dy rows 32k' + (tid >> 3).
+  // Consecutive pieces advance a row's padded-linear position by 32 (no per-piece offset arrays: they would need dynamic
+  // register indexing); the swizzle key of a row is unchanged by +32 (bits 1 and 3), so the lane's source granule is fixed.
+  const int prow = tid >> 3, pg = tid & 7;
+  const unsigned xg = (unsigned)((pg ^ whswz(prow)) * 16), dg = xg;
+  int x_q = 0, d_q = 0;                                    // padded-linear position of the row of the NEXT piece of each kind
+  unsigned xs = 0, ds = 0;
+  auto prepare = [&](int pt) {
+    const int plane = fdiv(pt, g.dTiles), tile = pt - plane * g.tiles;
+    const int q0 = g.Wp + tile * 256;
+    x_q = q0 - g.Wp - 1 + prow;                            // >= -1
+    d_q = q0 + prow;
+    xs = __builtin_amdgcn_readfirstlane((unsigned)((plane + kt - 1) * g.HW) * 128u);
+    ds = __builtin_amdgcn_readfirstlane((unsigned)(plane * g.HW) * 128u);
+  };
+  auto issue_piece = [&](int k, int stage) {               // k (wave-uniform, runtime) in [0, 20), issued in order
+    unsigned char* base = smem + stage * WH_STAGE;
+    if (k < WH_XPASS) {
+      const int x_hp = fdiv(x_q < 0 ? 0 : x_q, g.dWp), x_wp = x_q - x_hp * g.Wp;
+      const bool ok = x_q >= 0 && x_hp >= 1 && x_hp <= g.H && x_wp >= 1 && x_wp <= g.W;
+      const unsigned vo = ok ? (unsigned)(((x_hp - 1) * g.W + (x_wp - 1)) * 128) + xg : WH_OOB;
+      x_q += 32;
+      if (!(k == WH_XPASS - 1 && wave == 3))               // rows 376..383 do not exist
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (wh_lds_t)(base + (k * 256 + wave * 64) * 16), 16, vo, xs, 0, 0);
+    } else {
+      const int d_hp = fdiv(d_q, g.dWp), d_wp = d_q - d_hp * g.Wp;
+      const bool ok = d_hp <= g.H && d_wp >= 1 && d_wp <= g.W;
+      const unsigned vo = ok ? (unsigned)(((d_hp - 1) * g.W + (d_wp - 1)) * 128) + dg : WH_OOB;
+      d_q += 32;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (wh_lds_t)(base + WH_XBYTES + ((k - WH_XPASS) * 256 + wave * 64) * 16), 16, vo, ds, 0, 0);
+    }
+  };
+
+  int pt = next_valid(slot);
+  int cur = 0;
+  if (pt < g.total) {
+    prepare(pt);
+    for (int k = 0; k < WH_XPASS + WH_DYPASS; ++k) issue_piece(k, 0);
+  }
+  // Per-lane LDS addresses of the transposing reads.  Row r = r_l + 4h + 32*ks + shift(tap); the XOR swizzle key uses
+  // bits 1 and 3 of r, which 32*ks does not touch: one address per (tap, h), the k step goes into the instruction's
+  // immediate offset, and co tile i is tile 0 XOR 32*i (granule bits 1, 2 of the address are otherwise only keyed).
+  const int r_l = 8 * grp + qq;
+  const int sub8 = (pp & 1) * 8;
+  int a_addr[2];                           // dy tile, co tile 0, h = 0 / 1 (relative to the stage base)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { const int r = r_l + 4 * h; a_addr[h] = WH_XBYTES + r * 128 + (((pp >> 1) ^ whswz(r)) * 16) + sub8; }
+  int b_addr[9][2];                        // window, this wave's ci tile, per tap and h (relative to the stage base)
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = r_l + 4 * h + (t9 / 3) * g.Wp + (t9 % 3);
+      b_addr[t9][h] = r * 128 + (((2 * wave + (pp >> 1)) ^ whswz(r)) * 16) + sub8;
+    }
+  // Transposing reads are inline asm with hand-counted lgkmcnt waits: hipcc guards every LDS read it can see with
+  // s_waitcnt vmcnt(0) while an LDS-DMA is in flight (it cannot know the DMA fills the OTHER stage), which would put
+  // each of the next item's 20 DMA pieces' full latency into this item's MFMA stream.
+  const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)(smem);
+#define WH_TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+
+  while (pt < g.total) {
+    const int nxt = next_valid(pt + g.gk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this item's tiles landed
+    __syncthreads();                                       // ... for every wave; the other stage is no longer being read
+    const bool has_next = nxt < g.total;
+    if (has_next) prepare(nxt);
+    // 72 steps (8 k steps x 9 taps) as 4 trips of 18: static register slots (A double buffer by k-step parity, B ring of
+    // 3), the trip's k base lives in the address registers, the k step inside a trip in the immediate offset.
+    // Operands are fetched two steps ahead; the last trip's look-ahead reads fall beyond the tiles (harmless, never
+    // used) so that the hand-counted waits stay the same on every trip.
+    unsigned pa[2], pb[9][2];
+    const unsigned st = lds0 + (unsigned)(cur * WH_STAGE);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pa[h] = st + (unsigned)a_addr[h];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) pb[t9][h] = st + (unsigned)b_addr[t9][h];
+    wh_s16x4 va[2][4][2], vb[3][2];                        // [slot][co tile][h], [slot][h]
+#define WH_READ_A(KSL, SLOT) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { \
+      WH_TR_READ(va[SLOT][i_][0], pa[0] ^ (unsigned)(i_ * 32), (KSL) * 4096); \
+      WH_TR_READ(va[SLOT][i_][1], pa[1] ^ (unsigned)(i_ * 32), (KSL) * 4096); } } while (0)
+#define WH_READ_B(LSTEP, SLOT) do { WH_TR_READ(vb[SLOT][0], pb[(LSTEP) % 9][0], ((LSTEP) / 9) * 4096); \
+                                    WH_TR_READ(vb[SLOT][1], pb[(LSTEP) % 9][1], ((LSTEP) / 9) * 4096); } while (0)
+    WH_READ_A(0, 0);
+    WH_READ_B(0, 0);
+    WH_READ_B(1, 1);
+    int piece = 0;
+    for (int trip = 0; trip < 4; ++trip) {
+#pragma unroll
+      for (int ls = 0; ls < 18; ++ls) {
+        const int ksl = ls / 9, t9 = ls % 9;
+        // look-ahead (A first: it must be older than the B fragments of its k step); local steps 18, 19 = next trip's 0, 1
+        if ((ls + 2) % 9 == 0) {
+          if ((ls + 2) / 9 == 1) WH_READ_A(1, 1); else WH_READ_A(2, 0);
+        }
+        switch (ls + 2) {                  // (the immediate offset must be a literal)
+#define WH_CASE(L) case L: WH_READ_B(L, (L) % 3); break;
+          WH_CASE(2) WH_CASE(3) WH_CASE(4) WH_CASE(5) WH_CASE(6) WH_CASE(7) WH_CASE(8) WH_CASE(9) WH_CASE(10) WH_CASE(11)
+          WH_CASE(12) WH_CASE(13) WH_CASE(14) WH_CASE(15) WH_CASE(16) WH_CASE(17) WH_CASE(18) WH_CASE(19)
+#undef WH_CASE
+          default: break;
+        }
+        // next item's tiles: 20 DMA pieces on the odd steps of the first trips, so the last one is >= 1.5 trips old
+        // when the item ends
+        if (has_next && (ls & 1) && piece < WH_XPASS + WH_DYPASS) { issue_piece(piece, cur ^ 1); ++piece; }
+        // this step's operands were issued two steps ago: everything younger may stay in flight
+        const int y1 = ((ls + 1) % 9 == 0) ? 10 : 2;       // reads issued by the previous step
+        const int y0 = ((ls + 2) % 9 == 0) ? 10 : 2;       // ... and by this one
+        wh_s16x4 &b0 = vb[ls % 3][0], &b1 = vb[ls % 3][1];
+        if (y0 + y1 == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b0), "+v"(b1));
+        else asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(b0), "+v"(b1));
+        if (t9 == 0) {   // first use of this k step's A fragments: older than the B fragment just waited for
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(va[ksl][i][0]), "+v"(va[ksl][i][1]));
+        }
+        wh_s16x8 wb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, wb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const wh_s16x4 v0 = va[ksl][i][0], v1 = va[ksl][i][1];
+          wh_s16x8 w8 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          acc[t9][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w8), fb, acc[t9][i], 0, 0, 0);
+        }
+      }
+      // next trip: two k steps further
+#pragma unroll
+      for (int h = 0; h < 2; ++h) pa[h] += 8192u;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pb[t9][h] += 8192u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // drain the unused look-ahead reads before the stage is reused
+    pt = nxt;
+    cur ^= 1;
+  }
+#undef WH_READ_A
+#undef WH_READ_B
+#undef WH_TR_READ
+
+  // ---- slab store: [block][tap][co][ci], D row = co (16*i + (lane>>4)*4 + r), col = ci (16*wave + (lane & 15)) ----
+  float* slab = slabs + (long)blockIdx.x * WH_SLAB;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = i * 16 + (lane >> 4) * 4 + r;
+        const int ci = wave * 16 + (lane & 15);
+        slab[(t9 * 64 + co) * 64 + ci] = acc[t9][i][r];
+      }
+}
+
+// dw[co][kt*9 + t9][ci] += sum over the gk slabs of kt
+__global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int gk) {
+  const int e = blockIdx.x * 256 + threadIdx.x;            // e = ((kt*9 + t9) * 64 + co) * 64 + ci, 27*4096 elements
+  if (e >= 27 * 4096) return;
+  const int kt = e / (9 * 4096), rem = e - kt * (9 * 4096);
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};        // four independent chains: the loop is a string of dependent-latency loads otherwise
+  int b = 0;
+  for (; b + 4 <= gk; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += slabs[(long)((b + u) * 3 + kt) * WH_SLAB + rem];
+  }
+  for (; b < gk; ++b) s4[0] += slabs[(long)(b * 3 + kt) * WH_SLAB + rem];
+  const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  const int t9 = rem >> 12, co = (rem >> 6) & 63, ci = rem & 63;
+  atomicAdd(&dw[(co * 27 + kt * 9 + t9) * 64 + ci], s);
+}
+
+// returns 1 if launched, 0 if the shape / workspace is not covered, <0 / >0 on error
+int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
+                      hipStream_t st) {
+  if (d->C != 64 || d->K != 64 || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
+      d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
+  const char* e = getenv("MSCL_WGRAD_HALO");
+  if (e && e[0] == '0') return 0;
+  WHGeom g{};
+  g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
+  if (256 + 2 * g.Wp + 2 > WH_XROWS || (long)d->N * d->T * g.HW * 64 * 2 >= (1L << 31)) return 0;
+  if (!(e && e[0] == '1') && (long)d->H * g.Wp < 1024) return 0;          // small planes: the general kernel
+  g.tiles = (d->H * g.Wp + 255) / 256;
+  g.total = d->N * d->T * g.tiles;
+  static int cus = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  int gk = cus / 3;
+  if (gk > g.total) gk = g.total;
+  if (ws == nullptr || (long)gk * 3 * WH_SLAB > ws_floats) gk = (int)(ws ? ws_floats / (3L * WH_SLAB) : 0);
+  if (gk < 1) return 0;
+  g.gk = gk;
+  g.dWp = make_fastdiv(g.Wp); g.dTiles = make_fastdiv(g.tiles); g.dT = make_fastdiv(d->T);
+  hipLaunchKernelGGL(wgrad_halo64_kernel, dim3((unsigned)(3 * gk)), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
+  MSCL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((27 * 4096 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, gk);
+  MSCL_LAUNCH_CHECK();
+  return 1;
+}

@@ -66,9 +66,16 @@ def conv3d_dgrad(dy, wT, d, addend=None):
     return dx
 
 
+WGRAD_HALO_WS = 256 * 9 * 64 * 64       # floats: per-block partial slabs of the window-resident layer-1 weight-gradient kernel
+
+
 def conv3d_wgrad(x, dy, d, dw, dbias=None):
     """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated)."""
-    call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream_ptr())
+    ws = None
+    if (d.C, d.K, d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW) == (64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1):
+        ws = torch.empty((WGRAD_HALO_WS,), dtype=torch.float32, device=x.device)
+    call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
+         ws.numel() if ws is not None else 0, stream_ptr())
 
 
 def weight_transpose(w, wT, Cout, taps, Cin):

@@ -34,7 +34,7 @@ _SIGS = {
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
     'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
-    'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P],
+    'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],
     'mscl_weight_transpose_batched': [P, c_int, c_int, P],
     'mscl_bn_act_fwd': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, P],

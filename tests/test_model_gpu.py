@@ -329,4 +329,4 @@ def test_uv_flow_and_flip_inputs(dev):
         losses[name] = out['log_vars']
     for k, v in losses['host'].items():
         if 'loss' in k:
-            assert abs(losses['uv+mask'][k] - v) <= 2e-3 * max(1.0, abs(v)), (k, losses['uv+mask'][k], v)
+            loss_close(losses['uv+mask'][k], v, k)      # (+-1 colour level on <= 0.5 % of the pixels + fp32-atomic order noise)
