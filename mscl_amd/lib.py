@@ -87,7 +87,14 @@ def load():
     return lib
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
+    """handle of the current HIP stream (raw accessor: torch.cuda.current_stream() costs ~8 us per call on the host,
+    a third of the eager step's Python time at ~900 launches per step)"""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -106,5 +113,13 @@ def check(code, what):
         raise MsclError(f'{what} failed: {kind}')
 
 
+_fns = {}
+
+
 def call(name, *args):
-    check(getattr(load(), name)(*args), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    code = fn(*args)
+    if code != 0:
+        check(code, name)

@@ -120,6 +120,9 @@ WGRAD_SIDE = {}
 
 
 def _wgrad(conv, x, dy):
+    if not WGRAD_SIDE:
+        conv.wgrad(x, dy)
+        return
     cur = torch.cuda.current_stream()
     side = WGRAD_SIDE.get(cur.cuda_stream)
     if side is None:
