@@ -11,6 +11,7 @@ import torch
 class GraphedStep:
     def __init__(self, model, optimizer, example_batch, warmup=2):
         self.model, self.opt = model, optimizer
+        model.shuffle_mode = 'gather'            # all-to-all split sizes change per step and cannot be baked into a graph
         dev = model.arena.device
         self.static = {k: [t.to(dev).clone() for t in v] for k, v in example_batch.items()}
         self.B = self.static[model.im_key][0].shape[0]

@@ -67,6 +67,55 @@ def unshuffle_select(k, step, slot):
     return all_gather_cat(k).index_select(0, idx)
 
 
+class ShufflePlan:
+    """Shuffle-BN as two all-to-alls instead of two all-gathers (moco.py:146-191 gathers the whole W*B batch on every
+    rank and keeps B rows of it: W times the traffic that is needed; over point-to-point xGMI links the key clips are
+    the largest exchange of the step).  Everything is derived on the host from the permutation all ranks share.
+
+    forward:  rank r must encode global rows perm[r] (in that order); every row travels once, owner -> encoder.
+    backward: the encoded keys travel back, encoder -> owner, and land at their local index.
+    """
+
+    def __init__(self, W, B, rank, perm):
+        perm = perm.view(W, B)
+        flat_pos = torch.argsort(perm.flatten())            # flat_pos[g] = r * B + p : who encodes global row g, and where
+        mine = flat_pos[rank * B:(rank + 1) * B]             # ... for the rows this rank owns
+        self.send_order = torch.argsort(mine)                # own rows sorted by (destination, position there)
+        self.send_splits = torch.bincount(mine // B, minlength=W).tolist()
+        src = perm[rank] // B                                # owner of each row this rank encodes
+        self.recv_splits = torch.bincount(src, minlength=W).tolist()
+        arrival = torch.argsort(src, stable=True)            # arrival[j] = position p of the j-th received row
+        self.recv_order = torch.argsort(arrival)             # received buffer -> position order
+        # way back: keys sorted by global id (= by owner, then local index); owners receive, per encoder, ascending ids
+        self.back_send_order = torch.argsort(perm[rank])
+        ids = torch.cat([torch.sort(perm[r][(perm[r] // B) == rank]).values for r in range(W)])
+        self.back_recv_order = torch.argsort(ids)            # ids is a permutation of this rank's own global ids
+
+    def index_rows(self):
+        """the four index vectors, stacked (4, B) int64, for one upload"""
+        return torch.stack([self.send_order, self.recv_order, self.back_send_order, self.back_recv_order])
+
+
+@torch.no_grad()
+def exchange_rows(x, send_order, recv_order, send_splits, recv_splits):
+    """out[p] = the p-th row this rank must hold after the exchange; x rows are this rank's."""
+    xs = x.index_select(0, send_order).contiguous()
+    if dist.get_backend() == 'gloo' and xs.is_cuda:
+        # gloo has no all-to-all for device tensors: same result from all-gathers (test path: two ranks on one GPU)
+        W, r = world_size(), rank()
+        allx = all_gather_cat(xs).view(W, xs.shape[0], *xs.shape[1:])
+        sp = all_gather_cat(torch.tensor([send_splits], device=xs.device)).tolist()
+        parts = []
+        for src in range(W):
+            a = sum(sp[src][:r])
+            parts.append(allx[src, a:a + sp[src][r]])
+        out = torch.cat(parts)
+    else:
+        out = torch.empty_like(xs)
+        dist.all_to_all_single(out, xs, output_split_sizes=recv_splits, input_split_sizes=send_splits)
+    return out.index_select(0, recv_order)
+
+
 def bucket_plan(total, bucket_elems):
     """[(start, end)] covering [0, total) in buckets of at most bucket_elems (last one short)."""
     out, a = [], 0

@@ -236,6 +236,8 @@ class MSCLWithAug(nn.Module):
         self._step = 0
         self._scal_host = self._scal_dev = None
         self._bg = 0
+        self.shuffle_mode = os.environ.get('MSCL_SHUFFLE', 'a2a')      # 'a2a' | 'gather' (shuffle-BN exchange, world size > 1)
+        self._a2a = False
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
         self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0') == '1'     # measured 13 % slower: two MFMA-heavy kernels thrash     # MSCL_STREAMS=1: everything on the current stream
         self._side = None
@@ -424,18 +426,25 @@ class MSCLWithAug(nn.Module):
             dev = self.arena.device
             self._scal_host = torch.zeros(4, dtype=torch.float32).pin_memory()
             self._scal_dev = torch.zeros(4, dtype=torch.float32, device=dev)
-            self._idx_host = torch.zeros((6, B), dtype=torch.long).pin_memory()
-            self._idx_dev = torch.zeros((6, B), dtype=torch.long, device=dev)
+            self._idx_host = torch.zeros((18, B), dtype=torch.long).pin_memory()
+            self._idx_dev = torch.zeros((18, B), dtype=torch.long, device=dev)
+        # all-to-all split sizes change every step, so a captured graph (graph.py) switches to the all-gather formulation
+        self._a2a = W > 1 and self.shuffle_mode == 'a2a'
         rec.m = momentum_at(rec.iters, rec.max_iters, rec.m_base)
         m1 = momentum_at(recf.iters, recf.max_iters, recf.m_base)
         recf.m = momentum_at(recf.iters + (bg if self.training else 0), recf.max_iters, recf.m_base)   # value after the 2nd pass
         self._scal_host[0], self._scal_host[1], self._scal_host[2] = rec.m, m1, recf.m
         if W > 1:
             r = parallel.rank()
+            self._plans = [None] * 3
             for slot in range(3):
                 perm = parallel.shuffle_perm(W * B, self._step, slot)
-                self._idx_host[slot] = perm.view(W, B)[r]
-                self._idx_host[3 + slot] = torch.argsort(perm).view(W, B)[r]
+                if self._a2a:                   # two all-to-alls move B rows per rank instead of gathering W * B
+                    plan = self._plans[slot] = parallel.ShufflePlan(W, B, r, perm)
+                    self._idx_host[6 + 4 * slot:10 + 4 * slot] = plan.index_rows()
+                else:
+                    self._idx_host[slot] = perm.view(W, B)[r]
+                    self._idx_host[3 + slot] = torch.argsort(perm).view(W, B)[r]
         self._bg = bg
 
     def _post_step_host(self):
@@ -461,6 +470,9 @@ class MSCLWithAug(nn.Module):
     def _shuffle(self, x, slot):
         if parallel.world_size() == 1:
             return x          # a within-batch permutation does not change per-GPU BN statistics
+        if self._a2a:
+            p, ix = self._plans[slot], self._idx_dev
+            return parallel.exchange_rows(x, ix[6 + 4 * slot], ix[7 + 4 * slot], p.send_splits, p.recv_splits)
         return parallel.all_gather_cat(x).index_select(0, self._idx_dev[slot])
 
     def _shuffle_mask(self, m, slot):
@@ -471,6 +483,9 @@ class MSCLWithAug(nn.Module):
     def _unshuffle(self, k, slot):
         if parallel.world_size() == 1:
             return k
+        if self._a2a:
+            p, ix = self._plans[slot], self._idx_dev
+            return parallel.exchange_rows(k, ix[8 + 4 * slot], ix[9 + 4 * slot], p.recv_splits, p.send_splits)
         return parallel.all_gather_cat(k).index_select(0, self._idx_dev[3 + slot])
 
     def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None):

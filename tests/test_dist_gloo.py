@@ -42,6 +42,13 @@ def _worker(rank, world, port, q):
         gathered = parallel.all_gather_cat(keys)
         assert torch.equal(rec.queue[:, :world * b], gathered.T) and int(rec.queue_ptr) == world * b
         assert rec.batch_size == world * b and torch.equal(rec.count[:world * b], torch.ones(world * b, dtype=torch.long))
+        # all-to-all shuffle: same rows as the all-gather formulation, and the way back restores the owner's order
+        for step in (0, 3):
+            plan = parallel.ShufflePlan(world, b, rank, parallel.shuffle_perm(world * b, step, 1))
+            got = parallel.exchange_rows(x, plan.send_order, plan.recv_order, plan.send_splits, plan.recv_splits)
+            assert torch.equal(got, parallel.shuffle_select(x, step=step, slot=1))
+            back = parallel.exchange_rows(got * 2.0, plan.back_send_order, plan.back_recv_order, plan.recv_splits, plan.send_splits)
+            assert torch.equal(back, x * 2.0)
         state = torch.cat([rec.queue.flatten(), rec.count.float(), rec.queue_ptr.float()])
         states = parallel.all_gather_cat(state[None])
         assert torch.equal(states[0], states[1])

@@ -123,3 +123,34 @@ def test_shuffle_perm_is_shared_and_invertible():
     assert torch.equal(p1, p2) and sorted(p1.tolist()) == list(range(16))
     assert not torch.equal(p1, shuffle_perm(16, 4, 1))
     assert bucket_plan(10, 4) == [(0, 4), (4, 8), (8, 10)]
+
+
+def test_shuffle_plan_simulated_world4():
+    """ShufflePlan on 4 simulated ranks (no process group): rows land where the all-gather formulation puts them, and
+    the way back restores every owner's order."""
+    import torch
+    from mscl_amd import parallel
+    W, B = 4, 3
+    xs = [torch.arange(B, dtype=torch.float32).view(B, 1) + 100 * r for r in range(W)]
+    for step in range(5):
+        perm = parallel.shuffle_perm(W * B, step, 2)
+        plans = [parallel.ShufflePlan(W, B, r, perm) for r in range(W)]
+
+        def a2a(rows, splits_out, order_out, splits_in, order_in):
+            sent = []
+            for r in range(W):
+                buf = rows[r].index_select(0, getattr(plans[r], order_out))
+                sent.append(list(torch.split(buf, getattr(plans[r], splits_out))))
+            res = []
+            for r in range(W):
+                got = torch.cat([sent[s][r] for s in range(W)])
+                assert [sent[s][r].shape[0] for s in range(W)] == getattr(plans[r], splits_in)
+                res.append(got.index_select(0, getattr(plans[r], order_in)))
+            return res
+        fwd = a2a(xs, 'send_splits', 'send_order', 'recv_splits', 'recv_order')
+        allx = torch.cat(xs)
+        for r in range(W):
+            assert torch.equal(fwd[r], allx.index_select(0, perm.view(W, B)[r]))
+        back = a2a([f * 2 for f in fwd], 'recv_splits', 'back_send_order', 'send_splits', 'back_recv_order')
+        for r in range(W):
+            assert torch.equal(back[r], xs[r] * 2)

@@ -219,6 +219,7 @@ def _two_rank_worker(rank, world, port, q):
         torch.cuda.set_device(dev)
         B, T, H, Kq = 2, 8, 64, 64
         model, cfg = build(T, Kq, dev)
+        assert model.shuffle_mode == 'a2a'          # the all-to-all exchange (emulated over gloo for device tensors)
         opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
         orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
         oopt = om.SGDClip(orc.parameters())
