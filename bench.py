@@ -146,6 +146,10 @@ def main():
         avg_ms = sum(ms) / max(1, len(ms))
         flops = 2.0 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 27 * 64       # 88.8 GFLOP per launch
         achieved = flops / (avg_ms * 1e-3) / 1e12 if ms else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, 'profiles', 'r01_traffic_layer1.json')      # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
         line = {
             'metric': 'clip-pairs/sec/node (R3D-18, 16x112^2, bs8/gpu)',
             'value': world * BATCH * args.steps / dt, 'unit': 'clip-pairs/s',
@@ -159,7 +163,9 @@ def main():
             'final_loss': loss,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64_kernel fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
-                         'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': None},
+                         'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_traffic_layer1.json)',
+                         'algorithmic_bytes': 2 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 2 + 64 * 27 * 64 * 2},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch)
