@@ -331,3 +331,69 @@ def test_uv_flow_and_flip_inputs(dev):
     for k, v in losses['host'].items():
         if 'loss' in k:
             loss_close(losses['uv+mask'][k], v, k)      # (+-1 colour level on <= 0.5 % of the pixels + fp32-atomic order noise)
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE.json's configuration (B=8, T=16, 112x112, K=65536) is too large for the CPU oracle inside a test, so the
+    full-size step is checked through identities that hold at any size:
+      * integer bookkeeping: queue_ptr / count / iters / batch_size after two steps (moco.py:423-440,504-505);
+      * enqueued columns are the L2-normalised keys: unit norm, and the first 8 columns are the keys of step 0;
+      * key encoder = EMA of the query encoder with the scheduled momentum (one update per RGB pass, two per step
+        for the flow recognizer; moco.py:408-421) -- exact in fp32 up to one rounding per fused multiply-add;
+      * clip + SGD identity on the first step: q_after = q - lr * (g * coef + wd * q), coef = min(1, 40 / ||g||)
+        (apis/train.py:111-119 wiring), on every parameter that received a gradient; untouched tensors unchanged;
+      * bf16 shadows equal the rounded masters; the loss is finite and equals the sum of the 8 'loss' entries."""
+    from mscl_amd import ClipSGD
+    from mscl_amd.recognizers import momentum_at
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H, Kq = 8, 16, 112, 65536
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    ar = model.arena
+    rgb_a, rgb_b = ar.ranges['rgb']
+    flw_a, flw_b = ar.ranges['flow']
+    for s in range(2):
+        q0, k0 = ar.Q.clone(), ar.KX.clone()
+        iters_rgb, iters_flow = model.recognizer.iters, model.recognizer_flow.iters
+        batch = synthetic_batch(B, T, H, H, 0, s, device=dev)
+        out = model.train_step(batch)
+        lv = out['log_vars']
+        assert torch.isfinite(out['loss']).item()
+        assert abs(sum(v for k, v in lv.items() if 'loss' in k and k != 'loss') - lv['loss']) <= 1e-3 * abs(lv['loss'])
+        opt.zero_grad(); out['loss'].backward()
+        # EMA identities (the key update uses the query parameters BEFORE this step's SGD)
+        m = momentum_at(iters_rgb, model.recognizer.max_iters, model.recognizer.m_base)
+        want = k0[rgb_a:rgb_b] * m + q0[rgb_a:rgb_b] * (1.0 - m)
+        assert float((ar.KX[rgb_a:rgb_b] - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        m1 = momentum_at(iters_flow, model.recognizer_flow.max_iters, model.recognizer_flow.m_base)
+        m2 = momentum_at(iters_flow + B, model.recognizer_flow.max_iters, model.recognizer_flow.m_base)
+        want = (k0[flw_a:flw_b] * m1 + q0[flw_a:flw_b] * (1.0 - m1)) * m2 + q0[flw_a:flw_b] * (1.0 - m2)
+        assert float((ar.KX[flw_a:flw_b] - want).abs().max()) <= 4e-6 * float(want.abs().max())
+        opt.step()
+        g = ar.G
+        gn = float(opt.grad_norm())
+        assert abs(gn - float(g.double().pow(2).sum().sqrt())) <= 1e-4 * gn
+        if s == 0:                               # momentum buffer starts at zero: buf = d on the first step
+            coef = min(1.0, 40.0 / (gn + 1e-6))
+            lr, wd = cfg.optimizer['lr'], cfg.optimizer['weight_decay']
+            for a, b in ar.active_ranges():
+                want = q0[a:b] - lr * (g[a:b] * coef + wd * q0[a:b])
+                assert float((ar.Q[a:b] - want).abs().max()) <= 1e-6 * float(q0[a:b].abs().max()) + 1e-7
+            act = torch.zeros_like(q0, dtype=torch.bool)
+            for a, b in ar.active_ranges():
+                act[a:b] = True
+            assert torch.equal(ar.Q[~act], q0[~act])
+        assert torch.equal(ar.Qb, ar.Q.to(torch.bfloat16)) and torch.equal(ar.Kb, ar.KX.to(torch.bfloat16))
+        for rec, n_enq in ((model.recognizer, 1), (model.recognizer_flow, 1)):
+            assert int(rec.queue_ptr) == (s + 1) * B and rec.batch_size == B
+            cols = rec.queue[:, :(s + 1) * B].float()
+            assert float((cols.norm(dim=0) - 1).abs().max()) <= 1e-3
+            cnt = rec.count.cpu()
+            want_cnt = torch.full((Kq,), s + 1, dtype=torch.long)      # count += 1 everywhere, fresh slots = 1 (moco.py:426-439)
+            for j in range(s + 1):
+                want_cnt[j * B:(j + 1) * B] = s - j + 1
+            assert torch.equal(cnt, want_cnt)
+        assert model.recognizer.iters == (s + 1) * B and model.recognizer_flow.iters == 2 * (s + 1) * B
+        if s == 0:
+            first_keys = model._dbg['k_rgb'].float().clone()
+            assert float((model.recognizer.queue[:, :B].float().T - first_keys).abs().max()) <= 1e-6
