@@ -397,3 +397,45 @@ def test_full_size_step_properties(dev):
         if s == 0:
             first_keys = model._dbg['k_rgb'].float().clone()
             assert float((model.recognizer.queue[:, :B].float().T - first_keys).abs().max()) <= 1e-6
+
+
+def test_checkpoint_resume_and_lr_schedule(dev, tmp_path):
+    """save after 2 steps, resume into a fresh model: every buffer (551 state-dict entries, bf16
+    shadows, momentum) is bit-identical, the counters continue, and the next step matches the uninterrupted run
+    (integer state exactly; losses within the eager path's run-to-run tolerance).  The epoch-wise cosine schedule
+    reaches the optimizer's device-side lr word."""
+    from mscl_amd import ClipSGD, train as tr
+    from mscl_amd.optim import cosine_lr
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H, Kq = 2, 8, 32, 64
+    batches = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(3)]
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    tr.train(model, opt, lambda e: batches[e:e + 1], total_epochs=2, base_lr=0.02)          # epochs 0, 1: one step each
+    assert abs(opt.param_groups[0]['lr'] - cosine_lr(0.02, 1, 2)) < 1e-12
+    assert abs(float(opt._lr_dev) - cosine_lr(0.02, 1, 2)) < 1e-8
+    path = str(tmp_path / 'ck.pth')
+    meta = tr.save_checkpoint(path, model, opt, epoch=2, it=2)
+    assert meta['mscl_amd']['rgb_iters'] == 2 * B and meta['mscl_amd']['flow_iters'] == 4 * B
+    model2, _ = build(T, Kq, dev)
+    with torch.no_grad():
+        model2.arena.Q.zero_(); model2.arena.KX.zero_()
+    opt2 = ClipSGD.from_cfg(model2, cfg.optimizer, cfg.optimizer_config)
+    tr.resume(path, model2, opt2)
+    for a, b in zip(model.state_dict().values(), model2.state_dict().values()):
+        assert torch.equal(a, b)
+    ar, ar2 = model.arena, model2.arena
+    assert torch.equal(ar.MOM, ar2.MOM) and torch.equal(ar.Qb, ar2.Qb) and torch.equal(ar.Kb, ar2.Kb)
+    assert model2.recognizer.iters == model.recognizer.iters and model2._step == model._step and opt2.steps == opt.steps
+    outs = []
+    for m, o in ((model, opt), (model2, opt2)):
+        o.param_groups[0]['lr'] = 0.01
+        out = m.train_step(batches[2])
+        o.zero_grad(); out['loss'].backward(); o.step()
+        outs.append(out['log_vars'])
+    for k, v in outs[0].items():
+        if 'loss' in k:
+            loss_close(outs[1][k], v, k)
+    assert int(model.recognizer.queue_ptr) == int(model2.recognizer.queue_ptr)
+    assert torch.equal(model.recognizer_flow.count, model2.recognizer_flow.count)
+    assert abs(model.recognizer.m - model2.recognizer.m) < 1e-15
