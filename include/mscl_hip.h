@@ -152,13 +152,15 @@ int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* 
  *   part[blk][r] = {max, sum exp(l-max), #negatives with logit > pos logit}   (pass 1, one K chunk per block)
  *   then mscl_nce_finish: lse, loss_r = lse - pos/T, rank_r, and probabilities' normaliser.
  * Pass 2 (mscl_nce_bwd) re-streams the queue and accumulates dq[r] = (1/T) sum_k softmax_k * W[:,k]
- * (the positive-key term is added by the caller's tiny kernel mscl_nce_pos_bwd). */
+ * (the positive-key term is added by the caller's tiny kernel mscl_nce_pos_bwd); ws = scratch for the per-block
+ * partial sums, at least ceil(K / 128) * roundup(R, 8) * dim floats. */
 int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit,
                  float* part, int R, int dim, int K, float inv_T, void* stream);
 int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank,
                     int R, int nblk, float inv_T, void* stream);
 int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse,
-                 const float* row_scale, float* dq, int R, int dim, int K, float inv_T, void* stream);
+                 const float* row_scale, float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T,
+                 void* stream);
 
 /* pos[r] = <a[r], b[r]> (l_pos, recognizers/moco.py:481) and the positive-key term of the query gradient:
  * dq[r] += row_scale[r] * inv_T * (softmax_pos[r] - 1) * kpos[r] */

@@ -11,8 +11,19 @@
 // Each block owns 64 queue columns; wave w accumulates channels [w*dim/4, (w+1)*dim/4) of the dot products
 // (4x the loads in flight of a column-per-thread loop: the pass is latency-bound otherwise), partials are
 // summed through LDS.  lg[r] = logit of (row r, this lane's column) is returned to wave 0's lanes.
+// query rows staged once per block as qs[c][RT] (channel-major): the rows of one channel are then a few broadcast
+// ds_read_b128; fetching them through the scalar cache (RT s_loads per channel, each waited for) kept the pass at
+// 0.5 TB/s of queue reads
 template <int RT>
-__device__ __forceinline__ void nce_partial(const float* __restrict__ queue, const float* __restrict__ q, int k, int R, int dim,
+__device__ __forceinline__ void nce_stage_q(const float* __restrict__ q, float* __restrict__ qs, int R, int dim) {
+  for (int i = threadIdx.x; i < dim * RT; i += blockDim.x) {
+    const int c = i / RT, r = i - c * RT;
+    qs[i] = r < R ? q[r * dim + c] : 0.f;
+  }
+}
+
+template <int RT>
+__device__ __forceinline__ void nce_partial(const float* __restrict__ queue, const float* __restrict__ qs, int k, int dim,
                                             int K, int wave, float* acc) {
   const int cq = dim / NCE_WAVES, c0 = wave * cq;
 #pragma unroll
@@ -20,8 +31,13 @@ __device__ __forceinline__ void nce_partial(const float* __restrict__ queue, con
 #pragma unroll 8
   for (int c = c0; c < c0 + cq; ++c) {
     const float w = queue[(long)c * K + k];
+    const float4* qv = reinterpret_cast<const float4*>(qs + c * RT);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, acc[r]);
+    for (int r4 = 0; r4 < RT / 4; ++r4) {
+      const float4 v = qv[r4];
+      acc[4 * r4 + 0] = fmaf(v.x, w, acc[4 * r4 + 0]); acc[4 * r4 + 1] = fmaf(v.y, w, acc[4 * r4 + 1]);
+      acc[4 * r4 + 2] = fmaf(v.z, w, acc[4 * r4 + 2]); acc[4 * r4 + 3] = fmaf(v.w, w, acc[4 * r4 + 3]);
+    }
   }
 }
 
@@ -31,11 +47,14 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ q, const float* __restrict__ pos,
                                                       float* __restrict__ part, int R, int dim, int K, float inv_T) {
   __shared__ float red[NCE_WAVES][RT][NCE_COLS];
+  __shared__ __attribute__((aligned(16))) float qs[128 * RT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * NCE_COLS + lane;
   const bool live = k < K;
+  nce_stage_q<RT>(q, qs, R, dim);
+  __syncthreads();
   float acc[RT];
-  nce_partial<RT>(queue, q, live ? k : K - 1, R, dim, K, wave, acc);
+  nce_partial<RT>(queue, qs, live ? k : K - 1, dim, K, wave, acc);
 #pragma unroll
   for (int r = 0; r < RT; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
@@ -70,61 +89,97 @@ __global__ __launch_bounds__(64) void nce_finish_kernel(const float* __restrict_
 }
 
 // dq[r][c] += inv_T * row_scale[r] * sum_k softmax_k * decay_k * queue[c][k]
+// A block walks NCE_BWD_CHUNKS chunks of 64 columns and keeps its dq contribution in registers; the per-block results go
+// to a slab ([block][RT][dim], plain stores) summed by nce_bwd_reduce_kernel.  (One atomicAdd per element per 64-column
+// block meant 3 M float atomics on the same 12 KB: contention-bound at 67 us for a 33.5 MB read.)
+#define NCE_BWD_CHUNKS 2
+#define NCE_WPAD 68          // Wt row pitch in floats: 16-byte aligned rows, conflict-free b128 reads down a column of threads
 template <int RT>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
                                                       const float* __restrict__ q, const float* __restrict__ lse,
-                                                      const float* __restrict__ row_scale, float* __restrict__ dq,
+                                                      const float* __restrict__ row_scale, float* __restrict__ slab,
                                                       int R, int dim, int K, float inv_T) {
-  extern __shared__ float sm[];                 // Wt[dim][NCE_COLS+1], red[4][RT][NCE_COLS] (reused as gcoef[RT][NCE_COLS])
-  float* Wt = sm; float* red = sm + dim * (NCE_COLS + 1);
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // qs[dim][RT], Wt[dim][NCE_WPAD], red[4][RT][NCE_COLS] (reused as gcoef[RT][NCE_COLS])
+  float* qs = sm; float* Wt = qs + dim * RT; float* red = Wt + dim * NCE_WPAD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = blockIdx.x * NCE_COLS + lane;
-  const bool live = k < K;
-  const int kk = live ? k : K - 1;
   const int cq = dim / NCE_WAVES, c0 = wave * cq;
-  float acc[RT];
+  nce_stage_q<RT>(q, qs, R, dim);
+  // phase-2 ownership: thread -> (channel c2, half of the rows)
+  const int c2 = threadIdx.x % 128, half = threadIdx.x / 128;
+  constexpr int RH = RT / 2;
+  float a2[RH];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+  for (int r = 0; r < RH; ++r) a2[r] = 0.f;
+  for (int ch = 0; ch < NCE_BWD_CHUNKS; ++ch) {
+    const int k = (blockIdx.x * NCE_BWD_CHUNKS + ch) * NCE_COLS + lane;
+    const bool live = k < K;
+    const int kk = live ? k : K - 1;
+    __syncthreads();                            // qs staged / previous chunk's Wt, gcoef consumed
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
 #pragma unroll 8
-  for (int c = c0; c < c0 + cq; ++c) {
-    const float w = queue[(long)c * K + kk];
-    Wt[c * (NCE_COLS + 1) + lane] = live ? w : 0.f;
+    for (int c = c0; c < c0 + cq; ++c) {
+      const float w = queue[(long)c * K + kk];
+      Wt[c * NCE_WPAD + lane] = live ? w : 0.f;
+      const float4* qv = reinterpret_cast<const float4*>(qs + c * RT);
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = fmaf(q[(r < R ? r : 0) * dim + c], w, acc[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < RT; ++r) red[(wave * RT + r) * NCE_COLS + lane] = acc[r];
-  __syncthreads();
-  const float decay = powf(0.99999f, (float)count[kk]);
-  float coef[RT / NCE_WAVES + 1];
-  int nc = 0;
-  for (int r = wave; r < RT; r += NCE_WAVES, ++nc) {
-    float dot = 0.f;
-#pragma unroll
-    for (int w = 0; w < NCE_WAVES; ++w) dot += red[(w * RT + r) * NCE_COLS + lane];
-    const float l = dot * decay * inv_T;
-    coef[nc] = (live && r < R) ? __expf(l - lse[r < R ? r : 0]) * decay * inv_T * row_scale[r < R ? r : 0] : 0.f;
-  }
-  __syncthreads();
-  float* gc = red;                              // [RT][NCE_COLS]
-  nc = 0;
-  for (int r = wave; r < RT; r += NCE_WAVES, ++nc) gc[r * NCE_COLS + lane] = coef[nc];
-  __syncthreads();
-  // phase 2: thread -> (channel c, half of the rows)
-  const int c = threadIdx.x % 128, half = threadIdx.x / 128;
-  if (c < dim) {
-    constexpr int RH = RT / 2;
-    float a2[RH];
-#pragma unroll
-    for (int r = 0; r < RH; ++r) a2[r] = 0.f;
-    for (int j = 0; j < NCE_COLS; ++j) {
-      const float w = Wt[c * (NCE_COLS + 1) + j];
-#pragma unroll
-      for (int r = 0; r < RH; ++r) a2[r] = fmaf(gc[(half * RH + r) * NCE_COLS + j], w, a2[r]);
+      for (int r4 = 0; r4 < RT / 4; ++r4) {
+        const float4 v = qv[r4];
+        acc[4 * r4 + 0] = fmaf(v.x, w, acc[4 * r4 + 0]); acc[4 * r4 + 1] = fmaf(v.y, w, acc[4 * r4 + 1]);
+        acc[4 * r4 + 2] = fmaf(v.z, w, acc[4 * r4 + 2]); acc[4 * r4 + 3] = fmaf(v.w, w, acc[4 * r4 + 3]);
+      }
     }
 #pragma unroll
-    for (int r = 0; r < RH; ++r) if (half * RH + r < R) atomicAdd(&dq[(half * RH + r) * dim + c], a2[r]);
+    for (int r = 0; r < RT; ++r) red[(wave * RT + r) * NCE_COLS + lane] = acc[r];
+    __syncthreads();
+    const float decay = powf(0.99999f, (float)count[kk]);
+    float coef[RT / NCE_WAVES + 1];
+    int nc = 0;
+    for (int r = wave; r < RT; r += NCE_WAVES, ++nc) {
+      float dot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NCE_WAVES; ++w) dot += red[(w * RT + r) * NCE_COLS + lane];
+      const float l = dot * decay * inv_T;
+      coef[nc] = (live && r < R) ? __expf(l - lse[r < R ? r : 0]) * decay * inv_T * row_scale[r < R ? r : 0] : 0.f;
+    }
+    __syncthreads();
+    float* gc = red;                              // [RT][NCE_COLS]
+    nc = 0;
+    for (int r = wave; r < RT; r += NCE_WAVES, ++nc) gc[r * NCE_COLS + lane] = coef[nc];
+    __syncthreads();
+    if (c2 < dim) {
+      for (int j = 0; j < NCE_COLS; j += 4) {     // 16-byte LDS reads: 13 per 48 FMAs (gc rows are broadcast reads)
+        const float4 w = *reinterpret_cast<const float4*>(Wt + c2 * NCE_WPAD + j);
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+          const float4 gv = *reinterpret_cast<const float4*>(gc + (half * RH + r) * NCE_COLS + j);
+          a2[r] = fmaf(gv.x, w.x, fmaf(gv.y, w.y, fmaf(gv.z, w.z, fmaf(gv.w, w.w, a2[r]))));
+        }
+      }
+    }
   }
+  if (c2 < dim) {
+    float* o = slab + (long)blockIdx.x * RT * dim;
+#pragma unroll
+    for (int r = 0; r < RH; ++r) o[(half * RH + r) * dim + c2] = a2[r];
+  }
+}
+
+// dq[r][c] += sum over blocks of slab[b][r][c]  (rows r < R); blockIdx.y takes every gridDim.y-th slab
+__global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dq, int nslab,
+                                                             int RT, int R, int dim) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * dim) return;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  const int step = gridDim.y;
+  int b = blockIdx.y;
+  for (; b + 3 * step < nslab; b += 4 * step) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += slab[(long)(b + u * step) * RT * dim + e];
+  }
+  for (; b < nslab; b += step) s4[0] += slab[(long)b * RT * dim + e];
+  atomicAdd(&dq[e], (s4[0] + s4[1]) + (s4[2] + s4[3]));
 }
 
 #define NCE_DISPATCH(RV, CALL8, CALL16, CALL24, CALL32) \
@@ -152,24 +207,28 @@ extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float*
   return 0;
 }
 extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
-                            float* dq, int R, int dim, int K, float inv_T, void* stream) {
-  if (!queue || !count || !q || !lse || !row_scale || !dq || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+                            float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T, void* stream) {
+  if (!queue || !count || !q || !lse || !row_scale || !dq || !ws || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
   if (R > 32 || dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
   const int rt = R <= 8 ? 8 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32));
-  const size_t lds = ((size_t)dim * (NCE_COLS + 1) + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
+  const int nblk = (K + NCE_COLS * NCE_BWD_CHUNKS - 1) / (NCE_COLS * NCE_BWD_CHUNKS);
+  if ((int64_t)nblk * rt * dim > ws_floats) return MSCL_E_ARG;
+  const size_t lds = ((size_t)dim * rt + (size_t)dim * NCE_WPAD + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   NCE_DISPATCH(R,
-    hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, dq, R, dim, K, inv_T))
+    hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T),
+    hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T))
+  MSCL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((R * dim + 255) / 256, 32), dim3(256), 0, st, (const float*)ws, dq, nblk, rt, R, dim);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

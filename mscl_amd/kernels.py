@@ -271,7 +271,10 @@ def nce_backward(queue, count, q, lse, row_scale, inv_T):
     """dq (R, dim) = inv_T * row_scale[r] * sum_k softmax_k * W[:, k] (negatives only)."""
     R, dim = q.shape
     dq = torch.zeros((R, dim), dtype=torch.float32, device=q.device)
-    call('mscl_nce_bwd', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), R, dim, queue.shape[1], inv_T, stream_ptr())
+    Kq = queue.shape[1]
+    ws = torch.empty(((Kq + 127) // 128) * ((R + 7) // 8 * 8) * dim, dtype=torch.float32, device=q.device)
+    call('mscl_nce_bwd', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), ptr(ws), ws.numel(), R, dim, Kq,
+         inv_T, stream_ptr())
     return dq
 
 
