@@ -138,7 +138,7 @@ def _wgrad(conv, x, dy):
 def _bucket_done(mod):
     """data-parallel hook: this module's backward completes a gradient bucket -> start its all-reduce now"""
     buckets = getattr(mod, '_grad_buckets', ())
-    if buckets and parallel.world_size() > 1:
+    if buckets and not parallel.single():
         cur = torch.cuda.current_stream()
         side = WGRAD_SIDE.get(cur.cuda_stream)
         if side is not None:

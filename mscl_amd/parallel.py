@@ -7,6 +7,8 @@
   * the gradient all-reduce of the flat fp32 arena, in a few large buckets sized for the 7-link xGMI mesh.
 All helpers are device-agnostic and are exercised on CPU tensors with 2-rank gloo in tests/.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -23,10 +25,18 @@ def rank():
     return dist.get_rank() if is_dist() else 0
 
 
+def single():
+    """True when no exchange step is needed.  MSCL_FORCE_DIST=1 makes an initialised one-rank group run every collective
+    anyway: the only way to drive the RCCL code paths (all-to-all, all-gather, async AVG all-reduce) on a one-GPU box."""
+    if not is_dist():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get('MSCL_FORCE_DIST') != '1'
+
+
 @torch.no_grad()
 def all_gather_cat(t):
     """ref: recognizers/moco.py:558-568 (concat_all_gather); identity for a single replica."""
-    if world_size() == 1:
+    if single():
         return t
     t = t.contiguous()
     out = torch.empty((world_size() * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -146,7 +156,7 @@ class GradReducer:
         self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)
 
     def bucket_done(self, i, force=False):
-        if world_size() == 1 or i in self.launched:
+        if single() or i in self.launched:
             return
         self.hits[i] += 1
         if self.hits[i] < self.need[i] and not force:
@@ -160,7 +170,7 @@ class GradReducer:
             self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True), None))
 
     def finish(self):
-        if world_size() == 1:
+        if single():
             return
         for i in range(len(self.ranges)):          # anything a trigger missed (e.g. unused branches)
             self.bucket_done(i, force=True)

@@ -395,7 +395,7 @@ class MSCLWithAug(nn.Module):
 
     def _parse_logs(self, logs, sync):
         """ref: base.py:287-306, as ONE packed all-reduce instead of 23 scalar collectives."""
-        if parallel.world_size() > 1:
+        if not parallel.single():
             logs = logs.clone()
             dist.all_reduce(logs)
             logs = logs / parallel.world_size()
@@ -429,12 +429,12 @@ class MSCLWithAug(nn.Module):
             self._idx_host = torch.zeros((18, B), dtype=torch.long).pin_memory()
             self._idx_dev = torch.zeros((18, B), dtype=torch.long, device=dev)
         # all-to-all split sizes change every step, so a captured graph (graph.py) switches to the all-gather formulation
-        self._a2a = W > 1 and self.shuffle_mode == 'a2a'
+        self._a2a = (not parallel.single()) and self.shuffle_mode == 'a2a'
         rec.m = momentum_at(rec.iters, rec.max_iters, rec.m_base)
         m1 = momentum_at(recf.iters, recf.max_iters, recf.m_base)
         recf.m = momentum_at(recf.iters + (bg if self.training else 0), recf.max_iters, recf.m_base)   # value after the 2nd pass
         self._scal_host[0], self._scal_host[1], self._scal_host[2] = rec.m, m1, recf.m
-        if W > 1:
+        if not parallel.single():
             r = parallel.rank()
             self._plans = [None] * 3
             for slot in range(3):
@@ -468,7 +468,7 @@ class MSCLWithAug(nn.Module):
                 torch.cuda.current_stream().wait_stream(st)
 
     def _shuffle(self, x, slot):
-        if parallel.world_size() == 1:
+        if parallel.single():
             return x          # a within-batch permutation does not change per-GPU BN statistics
         if self._a2a:
             p, ix = self._plans[slot], self._idx_dev
@@ -476,12 +476,12 @@ class MSCLWithAug(nn.Module):
         return parallel.all_gather_cat(x).index_select(0, self._idx_dev[slot])
 
     def _shuffle_mask(self, m, slot):
-        if m is None or parallel.world_size() == 1:
+        if m is None or parallel.single():
             return m
         return self._shuffle(m.view(-1, 1), slot).view(-1).contiguous()
 
     def _unshuffle(self, k, slot):
-        if parallel.world_size() == 1:
+        if parallel.single():
             return k
         if self._a2a:
             p, ix = self._plans[slot], self._idx_dev
@@ -497,7 +497,7 @@ class MSCLWithAug(nn.Module):
         aug = self.aug_gpu
         K.ZEROS.reset(im_q.device)
         self._scal_dev.copy_(self._scal_host, non_blocking=True)
-        if parallel.world_size() > 1:
+        if not parallel.single():
             self._idx_dev.copy_(self._idx_host, non_blocking=True)
         sc = self._scal_dev
         ids = self.sup_head.mlvl_ids

@@ -439,3 +439,58 @@ def test_checkpoint_resume_and_lr_schedule(dev, tmp_path):
     assert int(model.recognizer.queue_ptr) == int(model2.recognizer.queue_ptr)
     assert torch.equal(model.recognizer_flow.count, model2.recognizer_flow.count)
     assert abs(model.recognizer.m - model2.recognizer.m) < 1e-15
+
+
+def _rccl_forced_worker(port, q):
+    """one-rank NCCL (= RCCL) group with MSCL_FORCE_DIST=1: all-to-all shuffle, key all-gather, async AVG all-reduce buckets
+    launched from backward, packed log all-reduce -- on the real backend, three streams, eager launches."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MSCL_FORCE_DIST='1')
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        from mscl_amd import ClipSGD, parallel
+        from mscl_amd.synthetic import synthetic_batch
+        assert not parallel.single()
+        B, T, H, Kq = 2, 8, 32, 64
+        model, cfg = build(T, Kq, dev)
+        opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+        res = []
+        for s in range(3):
+            out = model.train_step(synthetic_batch(B, T, H, H, 0, s, device=dev))
+            opt.zero_grad(); out['loss'].backward(); opt.step()
+            res.append({k: v for k, v in out['log_vars'].items() if 'loss' in k})
+        assert model._a2a and model.reducer.launched == set() and int(model.recognizer.queue_ptr) == 3 * B
+        torch.cuda.synchronize()
+        q.put(('ok', res))
+    except Exception:      # noqa
+        import traceback
+        q.put(('err', traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_forced(dev):
+    import socket
+    import torch.multiprocessing as mp
+    from mscl_amd import ClipSGD
+    from mscl_amd.synthetic import synthetic_batch
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_forced_worker, args=(port, q))
+    p.start()
+    status, res = q.get(timeout=600)
+    p.join(60)
+    assert status == 'ok', res
+    B, T, H, Kq = 2, 8, 32, 64
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    for s_ in range(3):
+        out = model.train_step(synthetic_batch(B, T, H, H, 0, s_, device=dev))
+        opt.zero_grad(); out['loss'].backward(); opt.step()
+        if s_ == 0:          # (a within-batch shuffle changes nothing but the summation order; later steps drift chaotically)
+            for k, v in res[0].items():
+                loss_close(out['log_vars'][k], v, k)
+    assert all(v == v for r in res for v in r.values())
