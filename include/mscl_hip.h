@@ -29,6 +29,12 @@ typedef struct {
   int pT, pH, pW;
 } mscl_conv_desc;
 
+/* BatchNorm statistics buffers (the `ssum` / `ssq` outputs of the convolution entry points and the `sum` / `sumsq` inputs
+ * of mscl_bn_params) are MSCL_STAT_SLOTS copies of the [2][C] sums, laid out [slot][2][C] fp32 and zeroed by the caller:
+ * the pointers address slot 0, producers add into slot (block index mod slots), consumers add the slots up.  (Thousands
+ * of blocks adding into one 512-byte row run an order of magnitude below the float-atomic rate.) */
+#define MSCL_STAT_SLOTS 16
+
 int mscl_abi_version(void);
 
 /* ---- Conv3d as implicit GEMM on MFMA (bf16 in, fp32 accumulate) --------------------------------

@@ -11,8 +11,11 @@ struct BnDev {
 __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* shift, int C, float inv_n,
                                            float unbias, float eps, float momentum, bool writer) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float mean = b.sum[c] * inv_n;
-    const float var = fmaxf(b.sumsq[c] * inv_n - mean * mean, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) { s1 += b.sum[sl * 2 * C + c]; s2 += b.sumsq[sl * 2 * C + c]; }
+    const float mean = s1 * inv_n;
+    const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
     const float inv = rsqrtf(var + eps);
     const float sc = b.gamma[c] * inv;
     scale[c] = sc; shift[c] = b.beta[c] - mean * sc;

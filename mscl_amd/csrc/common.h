@@ -70,6 +70,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// BatchNorm statistics are accumulated into MSCL_STAT_SLOTS copies of the [2][C] sums (slot = block index mod slots;
+// consumers add the slots up): thousands of blocks adding into ONE 512-byte row run an order of magnitude below the
+// float-atomic rate (MI355X_MICROARCH.md, Global float atomics, row 'contention').  Slot stride = 2 * C floats.
+#ifndef MSCL_STAT_SLOTS
+#define MSCL_STAT_SLOTS 16
+#endif
+
 // exact floor(n / d) for 0 <= n < 2^31 via one 32x32->64 multiply (Granlund-Montgomery round-up method)
 struct FastDiv { uint32_t magic; int shift; };
 static inline FastDiv make_fastdiv(int d) {

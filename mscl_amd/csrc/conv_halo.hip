@@ -272,7 +272,10 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
       }
     }
     __syncthreads();
-    for (int i = tid; i < HC; i += 256) { atomicAdd(&stat_sum[i], red[i]); atomicAdd(&stat_sq[i], red[HC + i]); }
+    for (int i = tid; i < HC; i += 256) {
+      const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * HC;
+      atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -505,7 +508,10 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
       }
     }
     __syncthreads();
-    for (int i = tid; i < HC; i += 256) { atomicAdd(&stat_sum[i], red[i]); atomicAdd(&stat_sq[i], red[HC + i]); }
+    for (int i = tid; i < HC; i += 256) {
+      const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * HC;
+      atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
+    }
   }
 }
 

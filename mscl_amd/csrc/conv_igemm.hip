@@ -119,7 +119,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
     }
     __syncthreads();
     for (int i = tid; i < BN; i += 256) {
-      if (n0 + i < g.Cr) { atomicAdd(&stat_sum[n0 + i], red[i]); atomicAdd(&stat_sq[n0 + i], red[BN + i]); }
+      if (n0 + i < g.Cr) {
+        const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * g.Cr;
+        atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
+      }
     }
   }
 
@@ -554,8 +557,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
   block_channel_sum(q, red, G, C, 2, 1);
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(&ssum[i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
-    atomicAdd(&ssq[i], red[4 * C + i] + red[5 * C + i] + red[6 * C + i] + red[7 * C + i]);
+    const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * C;
+    atomicAdd(&ssum[so + i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
+    atomicAdd(&ssq[so + i], red[4 * C + i] + red[5 * C + i] + red[6 * C + i] + red[7 * C + i]);
   }
 }
 

@@ -38,6 +38,14 @@ def _splitk_ws(rows, chans, device):
     return torch.empty((nslab * rows * chans,), dtype=torch.float32, device=device)
 
 
+STAT_SLOTS = 16         # = MSCL_STAT_SLOTS (include/mscl_hip.h): BN statistics buffers are [slots][2][C]
+
+
+def new_stats(C, device):
+    """zeroed [slots][2][C] statistics buffer; pass (buf[0, 0], buf[0, 1]) as the conv's stats / to _bnp"""
+    return ZEROS.take(STAT_SLOTS * 2 * C, device).view(STAT_SLOTS, 2, C)
+
+
 PROFILE_CONV = None      # bench.py: dict(sig=(N,T,H,W,C,K,kT), events=[]) -> event pairs around matching launches
 
 

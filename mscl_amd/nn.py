@@ -88,7 +88,7 @@ def cba_fwd(conv, bn, x, residual, relu):
     if not bn.training:
         raise MsclError('BatchNorm3dHip implements training-mode statistics only (both MoCo encoders run in train(), SURVEY App. E-6)')
     C = conv.out_channels
-    stats = K.ZEROS.take(2 * C, x.device).view(2, C)
+    stats = K.new_stats(C, x.device)[0]            # slot 0 of [slots][2][C]
     y = conv.fwd(x, stats=(stats[0], stats[1]))
     save = torch.empty((2, C), dtype=torch.float32, device=x.device)
     rt = bn._rt

@@ -68,8 +68,9 @@ def test_conv_fwd_dgrad_wgrad(case, dev):
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
     xg, wg = x.to(dev), w.to(dev)
     # forward + BN statistics
-    ssum = torch.zeros(K, device=dev); ssq = torch.zeros(K, device=dev)
-    y = K_.conv3d_fwd(xg, wg, d, stats=(ssum, ssq))
+    st = torch.zeros((K_.STAT_SLOTS, 2, K), device=dev)          # [slots][2][C]: producers spread over the slots
+    y = K_.conv3d_fwd(xg, wg, d, stats=(st[0, 0], st[0, 1]))
+    ssum, ssq = st[:, 0].sum(0), st[:, 1].sum(0)
     xr = x.float().requires_grad_(True); wr = w.float().requires_grad_(True)
     yr = _conv_ref(xr, wr, stride, pad)
     close(y, yr, BF16_TOL, 'conv fwd')
@@ -128,9 +129,14 @@ def test_bn_act_fwd_bwd(C, relu, resmode, dev):
         rr = res.float().requires_grad_(True); m2, z2 = bn_ref(rr, rgamma, rbeta); z = z + z2
     out_ref = F.relu(z) if relu else z
     # device
-    def stats_of(t):
+    def stats_of(t):                       # [slots][2][C], the sums split unevenly over two slots
+        from mscl_amd.kernels import STAT_SLOTS
         f = t.float().to(dev).reshape(-1, C)
-        return f.sum(0).contiguous(), (f * f).sum(0).contiguous()
+        st = torch.zeros((STAT_SLOTS, 2, C), device=dev)
+        h = f.shape[0] // 3
+        st[0, 0], st[0, 1] = f[:h].sum(0), (f[:h] * f[:h]).sum(0)
+        st[5, 0], st[5, 1] = f[h:].sum(0), (f[h:] * f[h:]).sum(0)
+        return st[0, 0], st[0, 1], st
     mk = lambda: dict(rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev),
                       nbt=torch.zeros((), dtype=torch.long, device=dev), sm=torch.empty(C, device=dev), si=torch.empty(C, device=dev))
     s1 = mk(); g1, b1 = gamma.to(dev), beta.to(dev)

@@ -60,7 +60,7 @@ def main():
         wT = w.permute(4, 1, 2, 3, 0).contiguous()
         dy = torch.randn(K.out_shape(d), device=dev).to(torch.bfloat16)
         dw = torch.zeros((Kc, *kern, C), device=dev)
-        stats = torch.zeros((2, Kc), device=dev)
+        stats = torch.zeros((K.STAT_SLOTS, 2, Kc), device=dev)[0]
         flops = 2.0 * d.N * d.To * d.Ho * d.Wo * Kc * kern[0] * kern[1] * kern[2] * C
         out = [f'{name:16s} {flops/1e9:7.2f} GF']
         if 'fwd' in modes:
