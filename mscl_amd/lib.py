@@ -94,8 +94,8 @@ def stream_ptr():
     """handle of the current HIP stream (raw accessor: torch.cuda.current_stream() costs ~8 us per call on the host,
     a third of the eager step's Python time at ~900 launches per step)"""
     if _raw_stream is not None:
-        return c_void_p(_raw_stream(torch.cuda.current_device()))
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(torch.cuda.current_device())          # plain int: ctypes converts it for a c_void_p parameter
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
@@ -104,7 +104,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise MsclError('mscl_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback')
-    return c_void_p(t.data_ptr())
+    return t.data_ptr()                           # plain int (see stream_ptr): +3 % on the host-bound eager step
 
 
 def check(code, what):
