@@ -121,6 +121,15 @@ int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H,
  * the quantised levels themselves.  flip_mask as above (the reference flips the visualised image, not the vectors). */
 int mscl_flow_visualize(const float* uv, uint16_t* out, uint8_t* levels, int B, int T, int H, int W, int T_total, int t_off,
                         const uint8_t* flip_mask, void* stream);
+/* Flow Rotation Augmentation + visualiser in one pass over raw flow: NormFlowWithStidedAug of
+ * datasets/pipelines/transforms_motion.py:7-29,103-142 (per-frame division by max radius + 1e-5; a second copy rotated
+ * by (ratio_lo + (ratio_hi - ratio_lo) / num_chunks * cid[b]) * pi first) followed by FlowVisualizer.  uv (B,2,T,H,W)
+ * fp32, cid (B) int32 on the device -> out (B,2T,H,W,8) bf16: frames [0,T) base, [T,2T) rotated (merge_aug=True).
+ * Optional outputs: levels (B,2T,H,W,3) bytes, normed (B,2T,H,W,2) fp32 = the normalised vectors.  scratch: 2*B*T
+ * doubles. */
+int mscl_flow_fra_visualize(const float* uv, const int32_t* cid, float ratio_lo, float ratio_hi, int num_chunks,
+                            uint16_t* out, uint8_t* levels, float* normed, double* scratch, int B, int T, int H, int W,
+                            const uint8_t* flip_mask, void* stream);
 /* out = relu?(a + b + c) elementwise bf16 (b, c optional) */
 int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, int relu, void* stream);
 /* din = dout * (out > 0) */

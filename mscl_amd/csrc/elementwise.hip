@@ -49,6 +49,26 @@ __device__ const unsigned char kColorWheel[55][3] = {
   {0,70,255},{0,47,255},{0,24,255},{0,0,255},{19,0,255},{39,0,255},{58,0,255},{78,0,255},{98,0,255},{117,0,255},{137,0,255},
   {156,0,255},{176,0,255},{196,0,255},{215,0,255},{235,0,255},{255,0,255},{255,0,213},{255,0,170},{255,0,128},{255,0,85},{255,0,43}};
 
+// colour-wheel levels of one flow vector, operation by operation as the reference computes them (see above)
+__device__ __forceinline__ void flow_uv_to_levels(float u, float v, unsigned char* lv) {
+  const float rad = __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)));
+  const float a = __fdiv_rn(atan2f(-v, -u), 3.14159265358979323846f);
+  const float fk = __fmul_rn(__fdiv_rn(__fadd_rn(a, 1.0f), 2.0f), 54.0f);
+  const float k0f = floorf(fk);
+  int k0 = (int)k0f, k1 = k0 + 1;
+  if (k1 == 55) k1 = 0;
+  const float f = __fsub_rn(fk, k0f);
+  const double w0 = (double)__fsub_rn(1.0f, f), w1 = (double)f, radd = (double)rad;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double col0 = (double)kColorWheel[k0][i] / 255.0, col1 = (double)kColorWheel[k1][i] / 255.0;
+    double col = __dadd_rn(__dmul_rn(w0, col0), __dmul_rn(w1, col1));
+    if (rad <= 1.0f) col = __dsub_rn(1.0, __dmul_rn(radd, __dsub_rn(1.0, col)));
+    else col = __dmul_rn(col, 0.75);
+    lv[i] = (unsigned char)(int)floor(__dmul_rn(255.0, col));
+  }
+}
+
 __global__ __launch_bounds__(256) void flow_visualize_kernel(const float* __restrict__ uv, bf16_t* __restrict__ out,
                                                              unsigned char* __restrict__ levels, int B, long THW, long THW_total,
                                                              long off, const unsigned char* __restrict__ flip, int W) {
@@ -58,25 +78,13 @@ __global__ __launch_bounds__(256) void flow_visualize_kernel(const float* __rest
     long p = e - b * THW;
     if (flip != nullptr && flip[b]) { const long row = p / W; p = row * W + (W - 1 - (p - row * W)); }   // flip of the IMAGE (ssl_aug_v2.py:118)
     const float* ub = uv + b * 2 * THW_total + off + p;
-    const float u = ub[0], v = ub[THW_total];
-    const float rad = __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)));
-    const float a = __fdiv_rn(atan2f(-v, -u), 3.14159265358979323846f);
-    const float fk = __fmul_rn(__fdiv_rn(__fadd_rn(a, 1.0f), 2.0f), 54.0f);
-    const float k0f = floorf(fk);
-    int k0 = (int)k0f, k1 = k0 + 1;
-    if (k1 == 55) k1 = 0;
-    const float f = __fsub_rn(fk, k0f);
-    const double w0 = (double)__fsub_rn(1.0f, f), w1 = (double)f, radd = (double)rad;
+    unsigned char lv[3];
+    flow_uv_to_levels(ub[0], ub[THW_total], lv);
     float c3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const double col0 = (double)kColorWheel[k0][i] / 255.0, col1 = (double)kColorWheel[k1][i] / 255.0;
-      double col = __dadd_rn(__dmul_rn(w0, col0), __dmul_rn(w1, col1));
-      if (rad <= 1.0f) col = __dsub_rn(1.0, __dmul_rn(radd, __dsub_rn(1.0, col)));
-      else col = __dmul_rn(col, 0.75);
-      const unsigned char lv = (unsigned char)(int)floor(__dmul_rn(255.0, col));
-      if (levels != nullptr) levels[e * 3 + i] = lv;
-      c3[i] = __fdiv_rn((float)lv, 255.0f);
+      if (levels != nullptr) levels[e * 3 + i] = lv[i];
+      c3[i] = __fdiv_rn((float)lv[i], 255.0f);
     }
     *reinterpret_cast<uint4*>(out + e * 8) = pack8(c3);
   }
@@ -89,6 +97,93 @@ extern "C" int mscl_flow_visualize(const float* uv, uint16_t* out, uint8_t* leve
   long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(flow_visualize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, uv, out, levels, B, THW,
                      (long)T_total * H * W, (long)t_off * H * W, flip_mask, W);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- Flow Rotation Augmentation + visualiser, fused
+// ref: datasets/pipelines/transforms_motion.py:7-29,103-142 (NormFlowWithStidedAug as configured at
+// mscl_r18_cosm_lr2e-2.py:70,82) followed by FlowVisualizer: every frame is divided by (its max radius + 1e-5); a second
+// copy is first rotated by beta = (start + stride * cid) * pi.  The reference mixes precisions (NumPy 2 rules: the base
+// copy stays float32, the rotated copy is float64 because sin/cos are float64 scalars); both are followed here.
+// Output: frames [0, T) = base, [T, 2T) = rotated (merge_aug=True), as the colour image the flow trunk consumes.
+__global__ __launch_bounds__(256) void fra_maxrad_kernel(const float* __restrict__ uv, const int* __restrict__ cid, double start,
+                                                         double stride, double* __restrict__ maxrad, int T, long HW) {
+  const int bt = blockIdx.x, b = bt / T, t = bt - b * T;
+  const float* u = uv + ((long)b * 2 * T + t) * HW;
+  const float* v = u + (long)T * HW;
+  const double beta = (start + stride * (double)cid[b]) * 3.141592653589793;
+  const double sb = sin(beta), cb = cos(beta);
+  float m0 = 0.f; double m1 = 0.0;
+  for (long p = threadIdx.x; p < HW; p += 256) {
+    const float uu = u[p], vv = v[p];
+    m0 = fmaxf(m0, __fsqrt_rn(__fadd_rn(__fmul_rn(uu, uu), __fmul_rn(vv, vv))));
+    const double nu = __dsub_rn(__dmul_rn(cb, (double)uu), __dmul_rn(sb, (double)vv));
+    const double nv = __dadd_rn(__dmul_rn(sb, (double)uu), __dmul_rn(cb, (double)vv));
+    m1 = fmax(m1, __dsqrt_rn(__dadd_rn(__dmul_rn(nu, nu), __dmul_rn(nv, nv))));
+  }
+  __shared__ double red0[256], red1[256];
+  red0[threadIdx.x] = (double)m0; red1[threadIdx.x] = m1;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { red0[threadIdx.x] = fmax(red0[threadIdx.x], red0[threadIdx.x + w]); red1[threadIdx.x] = fmax(red1[threadIdx.x], red1[threadIdx.x + w]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { maxrad[bt * 2] = red0[0]; maxrad[bt * 2 + 1] = red1[0]; }
+}
+
+__global__ __launch_bounds__(256) void fra_visualize_kernel(const float* __restrict__ uv, const int* __restrict__ cid, double start,
+                                                            double stride, const double* __restrict__ maxrad,
+                                                            bf16_t* __restrict__ out, unsigned char* __restrict__ levels,
+                                                            float* __restrict__ normed, int B, int T, long HW,
+                                                            const unsigned char* __restrict__ flip, int W) {
+  const long total = (long)B * 2 * T * HW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / (2 * T * HW);
+    const long r = e - b * 2 * T * HW;
+    const int t2 = (int)(r / HW);
+    long p = r - (long)t2 * HW;
+    if (flip != nullptr && flip[b]) { const long row = p / W; p = row * W + (W - 1 - (p - row * W)); }
+    const int t = t2 < T ? t2 : t2 - T;
+    const float uu = uv[((long)b * 2 * T + t) * HW + p], vv = uv[((long)b * 2 * T + T + t) * HW + p];
+    float un, vn;
+    if (t2 < T) {
+      const float den = __fadd_rn((float)maxrad[(b * T + t) * 2], 1e-5f);
+      un = __fdiv_rn(uu, den); vn = __fdiv_rn(vv, den);
+    } else {
+      const double beta = (start + stride * (double)cid[b]) * 3.141592653589793;
+      const double sb = sin(beta), cb = cos(beta);
+      const double nu = __dsub_rn(__dmul_rn(cb, (double)uu), __dmul_rn(sb, (double)vv));
+      const double nv = __dadd_rn(__dmul_rn(sb, (double)uu), __dmul_rn(cb, (double)vv));
+      const double den = __dadd_rn(maxrad[(b * T + t) * 2 + 1], 1e-5);
+      un = (float)__ddiv_rn(nu, den); vn = (float)__ddiv_rn(nv, den);
+    }
+    if (normed != nullptr) { normed[((long)b * 2 * T + t2) * HW * 2 + (r - (long)t2 * HW) * 2] = un; normed[((long)b * 2 * T + t2) * HW * 2 + (r - (long)t2 * HW) * 2 + 1] = vn; }
+    unsigned char lv[3];
+    flow_uv_to_levels(un, vn, lv);
+    float c3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (levels != nullptr) levels[e * 3 + i] = lv[i];
+      c3[i] = __fdiv_rn((float)lv[i], 255.0f);
+    }
+    *reinterpret_cast<uint4*>(out + e * 8) = pack8(c3);
+  }
+}
+
+extern "C" int mscl_flow_fra_visualize(const float* uv, const int32_t* cid, float ratio_lo, float ratio_hi, int num_chunks,
+                                       uint16_t* out, uint8_t* levels, float* normed, double* scratch, int B, int T, int H, int W,
+                                       const uint8_t* flip_mask, void* stream) {
+  if (!uv || !cid || !out || !scratch || B <= 0 || T <= 0 || H <= 0 || W <= 0 || num_chunks <= 0) return MSCL_E_ARG;
+  const double start = (double)ratio_lo, stride = ((double)ratio_hi - (double)ratio_lo) / num_chunks;
+  const long HW = (long)H * W;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fra_maxrad_kernel, dim3((unsigned)(B * T)), dim3(256), 0, st, uv, cid, start, stride, scratch, T, HW);
+  MSCL_LAUNCH_CHECK();
+  const long total = (long)B * 2 * T * HW;
+  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fra_visualize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, uv, cid, start, stride,
+                     (const double*)scratch, out, levels, normed, B, T, HW, flip_mask, W);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

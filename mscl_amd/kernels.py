@@ -187,6 +187,22 @@ def flow_visualize(uv, t_off=0, T=None, flip=None, want_levels=False):
     return (out, lv) if want_levels else out
 
 
+def flow_fra_visualize(uv, cid, ratios=(0.2, 1.8), num_chunks=8, flip=None, want_debug=False):
+    """raw flow (B,2,T,H,W) fp32 + chunk ids (B,) int32 -> colour images of the base and the rotated copy, (B,2T,H,W,8) bf16
+    (Flow Rotation Augmentation, transforms_motion.py:103-142, + FlowVisualizer).  want_debug also returns
+    (levels (B,2T,H,W,3) uint8, normed (B,2T,H,W,2) fp32)."""
+    B, C, T, H, W = uv.shape
+    if C != 2 or not uv.is_contiguous() or cid.dtype != torch.int32:
+        raise lib.MsclError('flow_fra_visualize needs a contiguous (B,2,T,H,W) tensor and int32 chunk ids')
+    out = torch.empty((B, 2 * T, H, W, 8), dtype=torch.bfloat16, device=uv.device)
+    lv = torch.empty((B, 2 * T, H, W, 3), dtype=torch.uint8, device=uv.device) if want_debug else None
+    nm = torch.empty((B, 2 * T, H, W, 2), dtype=torch.float32, device=uv.device) if want_debug else None
+    scratch = torch.empty((2 * B * T,), dtype=torch.float64, device=uv.device)
+    call('mscl_flow_fra_visualize', ptr(uv), ptr(cid), float(ratios[0]), float(ratios[1]), int(num_chunks), ptr(out), ptr(lv),
+         ptr(nm), ptr(scratch), B, T, H, W, ptr(flip), stream_ptr())
+    return (out, lv, nm) if want_debug else out
+
+
 def add_relu(a, b=None, c=None, relu=False):
     out = torch.empty_like(a)
     call('mscl_add_relu', ptr(a), ptr(b), ptr(c), ptr(out), a.numel(), int(relu), stream_ptr())

@@ -6,10 +6,13 @@ arithmetic on activations, parameters and gradients is done by libmscl_hip.so.  
 never travel through autograd: kernels accumulate them straight into the flat gradient arena
 (mscl_amd/arena.py), so a fused block is one graph node.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
 from . import kernels as K
+from . import lib
 from . import parallel
 from .lib import MsclError
 
@@ -36,6 +39,7 @@ class Conv3dHip(nn.Module):
         self.cin_eff = cin if cin % 8 == 0 else 8
         self.taps = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         self._rt = None           # runtime views, set by materialize()
+        self._plans = {}          # per input shape: cached descriptor / workspace size (cba_fwd)
         self._descs = {}
 
     def extra_repr(self):
@@ -77,6 +81,7 @@ class BatchNorm3dHip(nn.Module):
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
         self._rt = None
+        self._bnp = None          # cached parameter block of the fused forward (cba_fwd)
 
     def extra_repr(self):
         return f'{self.num_features}, eps={self.eps}, momentum={self.momentum}'
@@ -84,17 +89,53 @@ class BatchNorm3dHip(nn.Module):
 
 def cba_fwd(conv, bn, x, residual, relu):
     """conv -> BN(batch stats fused into the conv epilogue) -> (+residual) -> (ReLU).
-    Returns (y raw conv output, out, save[2,C] = mean/invstd)."""
+    Returns (y raw conv output, out, save[2,C] = mean/invstd).
+
+    The eager step is host-bound (~900 launches), so this path avoids per-call Python work: descriptor, split-K
+    workspace size and the constant half of the BatchNorm parameter block are cached per (module, input shape)."""
     if not bn.training:
         raise MsclError('BatchNorm3dHip implements training-mode statistics only (both MoCo encoders run in train(), SURVEY App. E-6)')
+    rt = conv._rt
+    if rt is None:
+        raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
+    shape = tuple(x.shape)
+    plan = conv._plans.get(shape)
+    if plan is None:
+        d = conv.desc(shape)
+        ws = K._splitk_ws(d.N * d.To * d.Ho * d.Wo, d.K, x.device)
+        plan = conv._plans[shape] = (d, ctypes.byref(d), K.out_shape(d), ws.numel() if ws is not None else 0,
+                                     (d.N, d.T, d.H, d.W, d.C, d.K, d.kT))
+    d, dref, oshape, ws_n, sig = plan
     C = conv.out_channels
-    stats = K.new_stats(C, x.device)[0]            # slot 0 of [slots][2][C]
-    y = conv.fwd(x, stats=(stats[0], stats[1]))
-    save = torch.empty((2, C), dtype=torch.float32, device=x.device)
-    rt = bn._rt
-    bnp = K._bnp((stats[0], stats[1]), rt['gamma'], rt['beta'], bn.running_mean, bn.running_var,
-                 bn.num_batches_tracked, save[0], save[1])
-    out = K.bn_act_fwd(y, bnp, residual=residual, relu=relu, eps=bn.eps, momentum=bn.momentum)
+    dev = x.device
+    stats = K.new_stats(C, dev)[0]                 # slot 0 of [slots][2][C]
+    buf = torch.empty((2,) + oshape, dtype=torch.bfloat16, device=dev)
+    y, out = buf[0], buf[1]
+    save = torch.empty((2, C), dtype=torch.float32, device=dev)
+    ws = torch.empty((ws_n,), dtype=torch.float32, device=dev) if ws_n else None
+    st = lib.stream_ptr()
+    prof = K.PROFILE_CONV
+    timed = prof is not None and prof['sig'] == sig
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    s_ptr = stats.data_ptr()
+    lib.call('mscl_conv3d_fwd', dref, x.data_ptr(), rt['w'].data_ptr(), y.data_ptr(),
+             rt['bias'].data_ptr() if rt['bias'] is not None else None, None, 0, s_ptr, s_ptr + 4 * C,
+             ws.data_ptr() if ws is not None else None, ws_n, st)
+    if timed:
+        e1.record()
+        prof['events'].append((e0, e1))
+    bp = bn._bnp
+    if bp is None:
+        brt = bn._rt
+        bp = bn._bnp = lib.BnParams(None, None, brt['gamma'].data_ptr(), brt['beta'].data_ptr(), bn.running_mean.data_ptr(),
+                                    bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), None, None)
+        bn._bnp_ref = ctypes.byref(bp)
+    sv = save.data_ptr()
+    bp.sum, bp.sumsq, bp.save_mean, bp.save_invstd = s_ptr, s_ptr + 4 * C, sv, sv + 4 * C
+    lib.call('mscl_bn_act_fwd', y.data_ptr(), bn._bnp_ref, residual.data_ptr() if residual is not None else None, None,
+             out.data_ptr(), y.numel() // C, C, bn.eps, bn.momentum, int(relu), st)
     return y, out, save
 
 

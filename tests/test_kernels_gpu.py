@@ -363,3 +363,24 @@ def test_pack_input_flip(dev):
     a = K_.pack_input(x, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), flip=flip)
     b = K_.pack_input(x, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
     assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0].flip(2)) and torch.equal(a[2], b[2].flip(2))
+
+
+def test_flow_fra_visualize_vs_reference_golden(dev):
+    """Flow Rotation Augmentation + visualiser fused (transforms_motion.py:103-142 + ssl_aug.py:87-136) against the
+    reference pipeline class.  Normalised vectors: float32 results of the reference's mixed float32 / float64 arithmetic,
+    compared at 2 ulp (sin / cos / sqrt in double on the device vs the host, then one rounding to float32); colour levels: +-1 level on <= 0.5 % of the elements
+    (see test_flow_visualize_vs_reference_golden)."""
+    import os
+    import numpy as np
+    from mscl_amd import kernels as K_
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fra_g8.npz'))
+    uv = torch.from_numpy(g['uv']).permute(0, 4, 1, 2, 3).contiguous().to(dev)            # (B,T,H,W,2) -> (B,2,T,H,W)
+    cid = torch.from_numpy(g['cid']).to(torch.int32).to(dev)
+    out, lv, nm = K_.flow_fra_visualize(uv, cid, want_debug=True)
+    want = torch.from_numpy(g['normed']).float()                                           # what ToTensor hands to the GPU
+    err = (nm.cpu() - want).abs()
+    assert float(err.max()) <= 2.4e-7, float(err.max())          # values lie in [-1, 1]: two float32 ulps at 1.0
+    wl = torch.from_numpy(g['levels']).permute(0, 2, 3, 4, 1).contiguous()               # (B,3,2T,H,W) -> (B,2T,H,W,3)
+    d = (lv.cpu().int() - wl.int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 5e-3, (int(d.max()), float((d > 0).float().mean()))
+    assert torch.equal(out[..., :3], (lv.float() / 255).to(torch.bfloat16)) and float(out[..., 3:].abs().max()) == 0.0

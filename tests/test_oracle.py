@@ -99,3 +99,14 @@ def test_flow_visualizer_oracle_vs_reference_golden():
     for a, b in (('uv', 'levels'), ('uv2', 'levels2')):
         out = vis(torch.from_numpy(g[a]))
         assert np.array_equal(torch.round(out * 255).to(torch.uint8).numpy(), g[b])
+
+
+def test_fra_oracle_vs_reference_golden():
+    """G8: oracle/flowaug.py reproduces the reference's NormFlowWithStidedAug outputs (tools/oracle/make_golden_fra.py)."""
+    import os
+    import numpy as np
+    from oracle import flowaug
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fra_g8.npz'))
+    for b in range(g['uv'].shape[0]):
+        out = flowaug.fra([g['uv'][b, t] for t in range(g['uv'].shape[1])], int(g['cid'][b]))
+        assert np.array_equal(np.stack(out).astype(np.float64), g['normed'][b])

@@ -1,0 +1,32 @@
+"""Host-side duration of the three phases of an eager step (no device sync inside): where the launch overhead sits."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mscl_amd import ClipSGD, Config, build_model          # noqa: E402
+from mscl_amd.fill import fill_module                       # noqa: E402
+from mscl_amd.synthetic import synthetic_batch              # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dev = torch.device('cuda', 0)
+cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+cfg.model.sup_head.t = 8
+model = build_model(cfg.model); fill_module(model); model.materialize(dev).train()
+opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+batch = synthetic_batch(8, 16, 112, 112, 0, 0, device=dev)
+acc = [0.0, 0.0, 0.0]
+for it in range(25):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.train_step(batch, sync_logs=False)
+    t1 = time.perf_counter()
+    opt.zero_grad(); out['loss'].backward()
+    t2 = time.perf_counter()
+    opt.step()
+    t3 = time.perf_counter()
+    if it >= 5:
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2
+print('host ms/step: forward %.2f  backward %.2f  optimizer %.2f' % tuple(1e3 * a / 20 for a in acc))
