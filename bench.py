@@ -9,7 +9,7 @@ A step = one pass of the hot path over one synthetic batch of 8 clip-pairs per G
 RGB q/k + visualised flow q/k as base||rotated), inputs resident in HBM, weights from the closed-form
 fill.  Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      dominant kernel = the layer-1 3x3x3 64->64 conv (halo-resident MFMA kernel, MFMA-bound), timed with
-                event pairs on its launch stream in two eager steps right after the timed region
+                event pairs on its launch stream in two single-stream eager steps right after the timed region
   cpu_baseline  the oracle/ restatement ("port") timed on this box's host cores on a bounded sample
 """
 import argparse
@@ -127,10 +127,15 @@ def main():
     dt = time.perf_counter() - t0
     # dominant-kernel timing: event pairs around the layer-1 conv launches of 2 eager steps issued right after the
     # timed region (same kernels, same data; the timed region itself is one graph launch per step)
+    # (one stream for these two steps: an event pair on one stream would otherwise also time the other streams' kernels
+    #  sharing the CUs -- 154 us instead of 131 us for this launch; the in-graph average is in profiles/*kernel_stats*)
     kernels.PROFILE_CONV = dict(sig=(BATCH, T_FRAMES, SIDE // 2, SIDE // 2, 64, 64, 3), events=[])
+    streams_were = model.two_streams
+    model.two_streams = False
     for i in range(2):
         eager_step(i)
     torch.cuda.synchronize()
+    model.two_streams = streams_were
     prof = kernels.PROFILE_CONV
     kernels.PROFILE_CONV = None
     tmax = torch.tensor([dt], device=dev)
