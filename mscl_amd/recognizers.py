@@ -457,7 +457,8 @@ class MSCLWithAug(nn.Module):
 
     def _side_stream(self, i=0):
         if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.arena.device) for _ in range(3)]
+            prio = int(os.environ.get('MSCL_SIDE_PRIORITY', '0'))      # HIP: larger = lower priority than the main chain
+            self._side = [torch.cuda.Stream(device=self.arena.device, priority=prio) for _ in range(3)]
         return self._side[i]
 
     def sync_streams(self):

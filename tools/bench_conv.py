@@ -21,6 +21,12 @@ SHAPES = [
     ('stem_rgb', (8, 16, 112, 112, 8), 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
     ('sepc_128', (8, 8, 28, 28, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('fpn_133', (8, 8, 28, 28, 128), 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('neck_lat_l3', (8, 4, 14, 14, 256), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('neck_lat_l4', (8, 2, 7, 7, 512), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('neck_lat_l2', (8, 8, 28, 28, 128), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('neck_333_p1', (8, 4, 14, 14, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('neck_333_p2', (8, 2, 7, 7, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('neck_133_p1', (8, 4, 14, 14, 128), 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('flow_stem', (8, 16, 112, 112, 8), 16, (1, 7, 7), (2, 2, 2), (0, 3, 3)),
     ('flow_l1', (8, 8, 56, 56, 16), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('flow_l2', (8, 8, 28, 28, 32), 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
