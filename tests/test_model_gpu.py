@@ -494,3 +494,45 @@ def test_rccl_backend_single_rank_forced(dev):
             for k, v in res[0].items():
                 loss_close(out['log_vars'][k], v, k)
     assert all(v == v for r in res for v in r.values())
+
+
+def test_r3d18_single_stream_full_size(dev):
+    """BASELINE.json configs[1]: the R3D-18 trunk alone, forward + backward on one (8, 3, 16, 112, 112) batch, loss = mean
+    of the layer-4 map, against the oracle trunk on the host (fp32).  bf16 storage tolerances as in the step test:
+    layer maps cosine >= 0.995; gradient norm within 8 %; per-tensor gradient cosine >= 0.90 on tensors carrying >= 1 % of
+    the norm (bf16 activations ahead of BatchNorm-backward cost ~0.92 in ANY bf16 pipeline, see the module docstring)."""
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    B, T, H = 8, 16, 112
+    model, _ = build(T, 64, dev)
+    orc = om.MSCLWithAug(num_frames=T, K=64); ofill.fill_module(orc); orc.train()
+    x = synthetic_batch(B, T, H, H, 0, 0)['imgs'][0]
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1, 1); std = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1, 1)
+    # device
+    model.zero_grad()
+    maps = model.recognizer.encoder_q(model.aug_gpu.pack_rgb(x.to(dev)))
+    loss = maps[-1].float().mean()
+    loss.backward()
+    # oracle
+    omaps = orc.recognizer.encoder_q((x - mean) / std)
+    oloss = omaps[-1].mean()
+    oloss.backward()
+    cos = torch.nn.functional.cosine_similarity
+    for li, (a, b) in enumerate(zip(maps, omaps)):
+        a = a.detach().float().cpu().permute(0, 4, 1, 2, 3)          # NDHWC -> NCDHW
+        c = float(cos(a.flatten(), b.detach().flatten(), dim=0))
+        assert c >= 0.995, f'layer{li + 1} map cosine {c}'
+    assert abs(float(loss) - float(oloss)) <= 0.02 * abs(float(oloss)) + 1e-3
+    gp = dict(model.recognizer.encoder_q.named_parameters())
+    go = dict(orc.recognizer.encoder_q.named_parameters())
+    tot_h = sum(float(p.grad.double().pow(2).sum()) for p in gp.values()) ** 0.5
+    tot_o = sum(float(p.grad.double().pow(2).sum()) for p in go.values() if p.grad is not None) ** 0.5
+    assert abs(tot_h - tot_o) <= 0.08 * tot_o, (tot_h, tot_o)
+    bad = []
+    for n, p in go.items():
+        if p.grad is None or float(p.grad.norm()) < 0.01 * tot_o:
+            continue
+        c = float(cos(gp[n].grad.float().cpu().flatten(), p.grad.flatten(), dim=0))
+        if c < 0.90:
+            bad.append((n, c))
+    assert not bad, bad
