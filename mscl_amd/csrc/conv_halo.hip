@@ -45,13 +45,21 @@ constexpr unsigned HOOB = 0x80000000u;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
+// NW = waves per block.  4: one wave per SIMD, 64 positions x 64 channels each.  8: two waves per SIMD, 32 positions each,
+// so one wave's barrier / LDS waits are covered by its neighbour's MFMAs (at 12 instead of 8 LDS reads per 16 MFMAs).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
                                                              float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Hs = smem;                          // [3][NH][128 B] input window, row j <-> q0 - Wp - 1 + j
   unsigned char* const Ws = smem + 3 * PLANE_BYTES;        // [2][64][128 B] weight ring
+  constexpr int RPP = 8 * NW;                              // window rows per DMA pass (64 * NW threads x 16 B)
+  constexpr int NPS = NH / RPP;                            // DMA pieces per thread per plane
+  constexpr int PPT = NPS / 6;                             // ... issued per tap while a plane streams in (6 taps)
+  constexpr int WPOS = HBM / NW, IM = WPOS / 16;           // positions per wave, position tiles per wave
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -69,10 +77,10 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
 #endif
 
   // ---- window DMA: per-pass VGPR offsets inside a source plane (same for the 3 planes; the plane goes in the SGPR) ----
-  unsigned win_voff[NPASS];
+  unsigned win_voff[NPS];
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int j = ps * 32 + (tid >> 3), pg = tid & 7;
+  for (int ps = 0; ps < NPS; ++ps) {
+    const int j = ps * RPP + (tid >> 3), pg = tid & 7;
     const int lg = pg ^ (j & 7);                           // source-side swizzle keyed on the window row
     const int q = q0 - g.Wp - 1 + j;
     const int hp = fdiv(q < 0 ? 0 : q, g.dWp), wp = q - hp * g.Wp;
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
   auto issue_plane_piece = [&](int hp, int ps) {
     const unsigned so = __builtin_amdgcn_readfirstlane(plane_soff(hp));
     const unsigned vo = plane_ok(hp) ? win_voff[ps] : HOOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + hp * PLANE_BYTES + (ps * 256 + wave * 64) * 16), 16, vo, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + hp * PLANE_BYTES + (ps * 64 * NW + wave * 64) * 16), 16, vo, so, 0, 0);
   };
   // ---- weights: tap `tap` -> ring stage tap & 1; rows = output channel n (forward) / input channel (gradient, wT) ----
   // Default: LDS-DMA, issued one tap ahead.  HALO_WREG=1 stages them through registers instead (16-byte loads two taps
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
     unsigned char* dst = Ws + (tap & 1) * (64 * 128) + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
+    if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
   };
 #endif
 
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
 
   // ---- prologue: first plane, weights of taps 0 and 1 ----
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) issue_plane_piece(tap_plane(0), ps);
+  for (int ps = 0; ps < NPS; ++ps) issue_plane_piece(tap_plane(0), ps);
 #if HALO_WREG
   load_weights(0);
   load_weights(1);
@@ -142,12 +150,12 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
 #endif
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int arow0 = wave * 64 + fr;                        // window row of fragment 0 at shift 0
+  const int arow0 = wave * WPOS + fr;                      // window row of fragment 0 at shift 0
   const int brow = fr;                                     // weight row of fragment 0 (j adds 16 rows = 2 KB)
   const int b_addr0 = brow * 128 + ((0 + fq) ^ (brow & 7)) * 16;
   const int b_addr1 = brow * 128 + ((4 + fq) ^ (brow & 7)) * 16;
 
-  bf16x8_t fa[2][2][4], fb[2][2][4];                       // [buffer][ks][fragment]
+  bf16x8_t fa[2][2][IM], fb[2][2][4];                      // [buffer][ks][fragment]
   auto read_operands = [&](int tap, int buf) {
     const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
     const unsigned char* wb = Ws + (tap & 1) * (64 * 128);
@@ -161,24 +169,25 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
     const unsigned char* hb = Hs + tap_plane(kt) * PLANE_BYTES + row * 128;
     const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IM; ++i) {
       fa[buf][0][i] = *reinterpret_cast<const bf16x8_t*>(hb + g0 + i * 2048);
       fa[buf][1][i] = *reinterpret_cast<const bf16x8_t*>(hb + g1 + i * 2048);
     }
   };
 
-  f32x4_t acc[4][4];                                       // [j: channel tile][i: position tile]
+  f32x4_t acc[4][IM];                                      // [j: channel tile][i: position tile]
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #if HALO_WREG
   store_weights(0);                                        // (the compiler waits for exactly the loads it needs; the
   load_weights(3);                                         //  first plane's DMA pieces are older, so they have landed too)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // plane + tap-0 weights landed (tap-1 weights in flight)
+  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // plane + tap-0 weights landed (tap-1 weights in flight)
+  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #endif
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < IM; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][0][j], fa[cur][0][i], acc[j][i], 0, 0, 0);
     if (tap + 1 < 27) {
       // The barrier publishes ring stage (tap+1)&1 and says every wave holds its tap-`tap` fragments in registers, so
@@ -210,8 +219,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
       if (!(HALO_EXP & 2)) read_operands(tap + 1, cur ^ 1);
       // window planes 2 and 3: two DMA pieces per tap, ahead of the weight pieces (in-order retirement)
       if (!(HALO_EXP & 8)) {
-        if (tap < 6) { issue_plane_piece(tap_plane(1), 2 * tap); issue_plane_piece(tap_plane(1), 2 * tap + 1); }
-        else if (tap >= 8 && tap < 14) { issue_plane_piece(tap_plane(2), 2 * (tap - 8)); issue_plane_piece(tap_plane(2), 2 * (tap - 8) + 1); }
+        if (tap < 6) {
+#pragma unroll
+          for (int u = 0; u < PPT; ++u) issue_plane_piece(tap_plane(1), PPT * tap + u);
+        } else if (tap >= 8 && tap < 14) {
+#pragma unroll
+          for (int u = 0; u < PPT; ++u) issue_plane_piece(tap_plane(2), PPT * (tap - 8) + u);
+        }
       }
       if (!(HALO_EXP & 4)) {
 #if HALO_WREG
@@ -226,17 +240,17 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < IM; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                  // the epilogue reuses the window memory
 
   // ---- output rows of this lane: padded-linear q -> (hp, wp); pad columns and rows past the plane are dropped ----
-  long orow[4];
+  long orow[IM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = q0 + wave * 64 + i * 16 + fr;
+  for (int i = 0; i < IM; ++i) {
+    const int q = q0 + wave * WPOS + i * 16 + fr;
     const int hp = fdiv(q, g.dWp), wp = q - hp * g.Wp;
     const bool ok = hp <= g.H && wp >= 1 && wp <= g.W;
     orow[i] = ok ? ((long)plane * g.HW + (hp - 1) * g.W + (wp - 1)) * HC : -1;
@@ -248,13 +262,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
   // ---- epilogue: BatchNorm statistics ----
   if (stat_sum != nullptr) {
     float* red = reinterpret_cast<float*>(smem);      // [2][64]
-    for (int i = tid; i < 2 * HC; i += 256) red[i] = 0.f;
+    for (int i = tid; i < 2 * HC; i += 64 * NW) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
 #pragma unroll
@@ -272,13 +286,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo64_kernel(const HaloGeom g, c
       }
     }
     __syncthreads();
-    for (int i = tid; i < HC; i += 256) {
+    for (int i = tid; i < HC; i += 64 * NW) {
       const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * HC;
       atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < IM; ++i) {
     if (orow[i] < 0) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -552,11 +566,17 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
   const size_t lds = (size_t)3 * PLANE_BYTES + 2 * 64 * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_halo64_kernel, dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, (hipStream_t)stream, g, src, w, out,
-                     addend, ssum, ssq);
+  const char* w8 = getenv("MSCL_HALO_WAVES");
+  if (w8 && w8[0] == '8')
+    hipLaunchKernelGGL(conv_halo64_kernel<8>, dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, (hipStream_t)stream, g, src, w,
+                       out, addend, ssum, ssq);
+  else
+    hipLaunchKernelGGL(conv_halo64_kernel<4>, dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, (hipStream_t)stream, g, src, w,
+                       out, addend, ssum, ssq);
   MSCL_LAUNCH_CHECK();
   return 1;
 }
