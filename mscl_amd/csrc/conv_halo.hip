@@ -36,6 +36,21 @@ __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+#ifdef HALO_CLOCK        // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz per block (MI355X_MICROARCH.md, DVFS item 6)
+__device__ unsigned long long halo_clock_dbg[2 * 4096];
+__device__ unsigned long long halo_seg_dbg[5 * 256];
+extern "C" int mscl_halo_seg_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(halo_seg_dbg), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mscl_halo_clock_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(halo_clock_dbg), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+#ifndef HALO_CLOCK
+#define HSTAMP(I) do {} while (0)
+#endif
+
 constexpr int HBM = 256;           // padded-linear positions per block
 constexpr int HC = 64;             // channels (in = out)
 constexpr int NH = 384;            // window rows per source plane (HBM + 2 * Wp + 2 <= NH, i.e. W <= 61)
@@ -53,8 +68,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
                                                              float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const Hs = smem;                          // [3][NH][128 B] input window, row j <-> q0 - Wp - 1 + j
-  unsigned char* const Ws = smem + 3 * PLANE_BYTES;        // [2][64][128 B] weight ring
+  // The three source planes are visited one after the other, so TWO window slots suffice: the third plane streams into
+  // the first one's slot while the second is in use.  That frees LDS for a 4-stage weight ring: a weight tile is issued
+  // three taps before it is needed (its L2 latency under load is ~1.5 taps; with a 2-stage ring, one tap ahead, every
+  // tap waited for it: 915 instead of 512 cycles per tap by in-kernel s_memtime stamps).
+  unsigned char* const Hs = smem;                          // [2][NH][128 B] input window slots, row j <-> q0 - Wp - 1 + j
+  unsigned char* const Ws = smem + 2 * PLANE_BYTES;        // [4][64][128 B] weight ring
   constexpr int RPP = 8 * NW;                              // window rows per DMA pass (64 * NW threads x 16 B)
   constexpr int NPS = NH / RPP;                            // DMA pieces per thread per plane
   constexpr int PPT = NPS / 6;                             // ... issued per tap while a plane streams in (6 taps)
@@ -67,6 +86,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   const int t = plane % g.T;
   const int q0 = g.Wp + tile * HBM;                        // first padded-linear position of this tile (hp = 1, wp = 0)
   const int mode = __builtin_amdgcn_readfirstlane(g.mode);
+#ifdef HALO_CLOCK
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0;   // HALO_CLOCK=2: where a tap's cycles go (wave 0)
+#define HSTAMP(I) do { if (HALO_CLOCK == 2) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); seg[I] += tn - tprev; tprev = tn; } } while (0)
+#endif
 
 #ifdef HALO_PROBE      // timing-only builds: 1 = weight loads dropped by the range check, 2 = window loads dropped, 3 = both
   const auto rs_src = halo_rsrc(src, (HALO_PROBE & 2) ? 0u : 0x7FFFFFFFu);
@@ -95,43 +119,23 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   auto issue_plane_piece = [&](int hp, int ps) {
     const unsigned so = __builtin_amdgcn_readfirstlane(plane_soff(hp));
     const unsigned vo = plane_ok(hp) ? win_voff[ps] : HOOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + hp * PLANE_BYTES + (ps * 64 * NW + wave * 64) * 16), 16, vo, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + (hp == 1 ? PLANE_BYTES : 0) + (ps * 64 * NW + wave * 64) * 16), 16, vo, so, 0, 0);
   };
-  // ---- weights: tap `tap` -> ring stage tap & 1; rows = output channel n (forward) / input channel (gradient, wT) ----
-  // Default: LDS-DMA, issued one tap ahead.  HALO_WREG=1 stages them through registers instead (16-byte loads two taps
-  // ahead, ds_write_b128 one tap ahead): measured 7 % SLOWER (118 vs 109 us on layer 1), kept for reference.
-#ifndef HALO_WREG
-#define HALO_WREG 0
-#endif
+  // ---- weights: tap `tap` -> ring stage tap & 3; rows = output channel n (forward) / input channel (gradient, wT) ----
+  // LDS-DMA into a 4-stage ring, issued three taps ahead.  (Staging them through registers instead -- 16-byte loads plus
+  // ds_write_b128 -- measured 7 % slower.)
 #ifndef HALO_EXP
 #define HALO_EXP 0       // timing-study switches (wrong results): 1 no barrier, 2 no operand reads, 4 no weight moves, 8 no plane pieces
 #endif
   const int w_row = tid >> 3, w_lg = tid & 7;
-#if HALO_WREG
-  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + w_lg * 8) * 2);
-  const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
-  const int w_lds = w_row * 128 + ((w_lg ^ (w_row & 7)) * 16);          // + 4096 for the second piece (row + 32: same key)
-  uint4 wreg[3][2];
-  auto load_weights = [&](int tap) {
-    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
-    wreg[tap % 3][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, w_voff0, so, 0));
-    wreg[tap % 3][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, w_voff1, so, 0));
-  };
-  auto store_weights = [&](int tap) {
-    unsigned char* dst = Ws + (tap & 1) * (64 * 128) + w_lds;
-    *reinterpret_cast<uint4*>(dst) = wreg[tap % 3][0];
-    *reinterpret_cast<uint4*>(dst + 4096) = wreg[tap % 3][1];
-  };
-#else
   const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);     // source-side swizzle
   const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
   auto issue_weights = [&](int tap) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
-    unsigned char* dst = Ws + (tap & 1) * (64 * 128) + wave * 1024;
+    unsigned char* dst = Ws + (tap & 3) * (64 * 128) + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
     if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
   };
-#endif
 
   // window plane visited by the kt-th group of taps, and the row shift of tap (kh, kw)
   auto tap_plane = [&](int kt) { return mode ? 2 - kt : kt; };
@@ -140,14 +144,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   // ---- prologue: first plane, weights of taps 0 and 1 ----
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) issue_plane_piece(tap_plane(0), ps);
-#if HALO_WREG
-  load_weights(0);
-  load_weights(1);
-  load_weights(2);
-#else
   issue_weights(0);
   issue_weights(1);
-#endif
+  issue_weights(2);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int arow0 = wave * WPOS + fr;                      // window row of fragment 0 at shift 0
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   bf16x8_t fa[2][2][IM], fb[2][2][4];                      // [buffer][ks][fragment]
   auto read_operands = [&](int tap, int buf) {
     const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
-    const unsigned char* wb = Ws + (tap & 1) * (64 * 128);
+    const unsigned char* wb = Ws + (tap & 3) * (64 * 128);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       fb[buf][0][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr0 + j * 2048);
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
     }
     const int row = arow0 + tap_shift(kh, kw);
     const int key = row & 7;
-    const unsigned char* hb = Hs + tap_plane(kt) * PLANE_BYTES + row * 128;
+    const unsigned char* hb = Hs + (kt == 1 ? PLANE_BYTES : 0) + row * 128;
     const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
@@ -181,25 +180,19 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
 #pragma unroll
     for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-#if HALO_WREG
-  store_weights(0);                                        // (the compiler waits for exactly the loads it needs; the
-  load_weights(3);                                         //  first plane's DMA pieces are older, so they have landed too)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // plane + tap-0 weights landed (tap-1 weights in flight)
-  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#endif
+  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // plane + tap-0 weights landed (taps 1, 2 in flight)
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   read_operands(0, 0);
   if (HALO_EXP & 2) read_operands(0, 1);
-#if HALO_WREG
-  store_weights(1);
-#endif
 
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap) {
     const int cur = tap & 1;
+#ifdef HALO_CLOCK
+    if (HALO_CLOCK == 2 && tap == 0) tprev = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -208,16 +201,35 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
     if (tap + 1 < 27) {
       // The barrier publishes ring stage (tap+1)&1 and says every wave holds its tap-`tap` fragments in registers, so
       // stage `cur` may be refilled with tap+2.  Raw s_barrier: __syncthreads() would drain vmcnt as well.
-#if HALO_WREG
-      if (tap == 7 || tap == 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next window plane landed (DMA pieces)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       // everything issued a tap ago has landed
-#endif
+      // Wait for the weight tile of tap + 1 (issued two taps ago, or in the prologue).  Everything issued after it may stay
+      // in flight: the window pieces of the two previous taps and the weight tile of tap + 2 -- the count is a
+      // compile-time constant per tap (the loop is fully unrolled).  In-order retirement also guarantees that a window
+      // plane has landed two taps after its last piece was issued.
+      HSTAMP(0);
+      {
+        auto pieces_at = [](int tp) { return ((tp >= 0 && tp < 6) || (tp >= 8 && tp < 14)) ? PPT : 0; };
+        constexpr int WP = NW == 4 ? 2 : 1;                      // DMA instructions per weight tile per wave
+        const int younger = pieces_at(tap - 2) + (tap >= 1 && tap + 2 < 27 ? WP : 0) + pieces_at(tap - 1) + (tap == 0 ? 2 * WP - WP : 0);
+        switch (younger) {
+          case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+      }
+      HSTAMP(1);
       if (!(HALO_EXP & 1)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      HSTAMP(2);
       if (!(HALO_EXP & 2)) read_operands(tap + 1, cur ^ 1);
-      // window planes 2 and 3: two DMA pieces per tap, ahead of the weight pieces (in-order retirement)
+      // weight tile of tap + 2 first, then this tap's share of window planes 2 and 3 (in-order retirement: see the wait above)
+      if (!(HALO_EXP & 4)) {
+        if (tap + 3 < 27) issue_weights(tap + 3);
+      }
       if (!(HALO_EXP & 8)) {
         if (tap < 6) {
 #pragma unroll
@@ -227,15 +239,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
           for (int u = 0; u < PPT; ++u) issue_plane_piece(tap_plane(2), PPT * (tap - 8) + u);
         }
       }
-      if (!(HALO_EXP & 4)) {
-#if HALO_WREG
-        if (tap + 2 < 27) store_weights(tap + 2);
-        if (tap + 4 < 27) load_weights(tap + 4);
-#else
-        if (tap + 2 < 27) issue_weights(tap + 2);
-#endif
-      }
     }
+    HSTAMP(3);
     __builtin_amdgcn_sched_barrier(0);          // keep the next tap's operand reads ABOVE this tap's second k step
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
       for (int i = 0; i < IM; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    HSTAMP(4);
   }
   __syncthreads();                  // the epilogue reuses the window memory
 
@@ -307,27 +313,40 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
       *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
     }
   }
+#ifdef HALO_CLOCK
+  if (tid == 0 && blockIdx.x < 4096) {
+    halo_clock_dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+    halo_clock_dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    if (HALO_CLOCK == 2 && blockIdx.x < 256) { for (int q_ = 0; q_ < 5; ++q_) halo_seg_dbg[5 * blockIdx.x + q_] = seg[q_]; }
+  }
+#endif
 }
 
 // =====================================================================================================================
-// Persistent plane-walking variant (MSCL_HALO_PERSIST=1).  Timing probes on the kernel above (profiles/r01_pmc_layer1.md) show that
-// with EVERYTHING but the MFMAs removed from its tap loop it still runs at 42 % of MFMA peak: at one 160-KB block per
-// CU every block pays a dispatch gap (17 % of CU time has no wave resident), an exposed 48-KB window prologue and a
-// drained pipeline around its epilogue.  Here the grid is one block per CU and a block walks a contiguous range of
-// (n, tile, t) items with t fastest:
+// Persistent plane-walking variant (MSCL_HALO_PERSIST=1).  In-kernel s_memtime stamps on the kernel above
+// (profiles/r01_pmc_layer1.md): of the 42 k cycles a block slot costs, 13.8 k are MFMAs, 9 k tap-loop overhead, 9 k the
+// exposed window prologue + epilogue and 10 k the dispatch gap of a 160-KB block.  Here the grid is one block per CU and
+// a block walks a contiguous range of (n, tile, t) items with t fastest:
 //  * moving from output plane t to t+1 keeps two of the three source planes in LDS (ring slot = (plane + 1) % 3) and
-//    streams only plane t+2 -- one DMA piece per tap under taps 9..20 -- so window traffic drops 3x and there is no
-//    prologue inside a chain;
-//  * the tap pipeline runs across the item boundary: the last two taps of an item issue the weight tiles of the next
-//    item's first two taps and fetch its first operands, so the MFMA stream only pauses for the epilogue's stores;
+//    streams only plane t+2, one DMA piece per tap, so there is neither a prologue nor a dispatch gap inside a chain;
+//  * a tile is 192 positions (3 position tiles per wave): three 320-row planes leave room for a FOUR-stage weight ring,
+//    so a weight tile is issued three taps before use (with two stages every tap waited ~200 cycles for it) -- and 17
+//    tiles of 192 cover a 56 x 58 plane with 0.5 % waste (13 x 256: 2.4 %);
+//  * the tap pipeline runs across the item boundary: the last taps of an item issue the next item's first weight tiles
+//    and fetch its first operands, so the MFMA stream only pauses for the epilogue's stores;
+//  * right after the per-tap barrier the next tap's 14 operand reads are interleaved one-to-one with this tap's first 12
+//    MFMAs (sched_group_barrier): issued as one burst by all four waves they saturate the LDS for ~250 cycles with the
+//    MFMA pipes idle, which is what the first version of this kernel did (560 instead of 360 cycles for that segment);
 //  * taps are visited in WINDOW order (plane t-1, t, t+1; row shift a*(W+2)+b); the weight tap is idx (forward) or
 //    26 - idx (input gradient), so plane t-1 is always the first one released;
 //  * BatchNorm statistics accumulate in registers over all items of the block: one reduction + 128 atomics per BLOCK.
-// 27 taps per item is odd, so the weight ring parity flips per item (`par`, LDS addresses are runtime anyway) and
-// the operand register double-buffer is re-based by a 32-register copy at the item boundary.
-constexpr int NHP = 376;                     // window rows (374 needed at W = 56); leaves 3 KB of the 160 KB for scratch
+// 27 taps per item: the ring stage of a tap is (taps done so far + idx) & 3 (runtime base, LDS addresses are runtime
+// anyway); the operand register double-buffer is re-based by a 28-register copy at the item boundary.
+constexpr int PBM = 192;                     // padded-linear positions per item
+constexpr int NHP = 320;                     // window rows: PBM + 2 * (W + 2) + 2 = 310 at W = 56, in 32-row DMA passes
 constexpr int PPLANE = NHP * 128;
-constexpr int PNPASS = 12;                   // 32-row DMA passes; the last one covers rows 352..375 (wave 3 sits out)
+constexpr int PNPASS = NHP / 32;             // 10
+constexpr int PIM = PBM / 64;                // position tiles per wave (3)
 
 __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, const int total_items,
                                                               const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
@@ -335,17 +354,21 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
                                                               float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Hs = smem;                          // [3][NHP][128 B] plane ring
-  unsigned char* const Ws = smem + 3 * PPLANE;             // [2][64][128 B] weight ring
-  float* const red = reinterpret_cast<float*>(smem + 3 * PPLANE + 2 * 64 * 128);      // [2][64] statistics scratch
+  unsigned char* const Ws = smem + 3 * PPLANE;             // [4][64][128 B] weight ring
+  float* const red = reinterpret_cast<float*>(smem + 3 * PPLANE + 4 * 64 * 128);      // [2][64] statistics scratch
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mode = __builtin_amdgcn_readfirstlane(g.mode);
+#ifdef HALO_CLOCK
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#endif
   const int it_beg = (int)((long)total_items * blockIdx.x / gridDim.x);
   const int it_end = (int)((long)total_items * (blockIdx.x + 1) / gridDim.x);
   const auto rs_src = halo_rsrc(src, 0x7FFFFFFFu);
   const auto rs_wgt = halo_rsrc(wgt, 0x7FFFFFFFu);
   const int fr = lane & 15, fq = lane >> 4;
-  const int arow0 = wave * 64 + fr;
+  const int arow0 = wave * (PBM / 4) + fr;
   const int b_addr0 = fr * 128 + ((0 + fq) ^ (fr & 7)) * 16;
   const int b_addr1 = fr * 128 + ((4 + fq) ^ (fr & 7)) * 16;
   const int w_row = tid >> 3, w_lg = tid & 7;
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
   const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
 
   unsigned win_voff[PNPASS];                 // per-pass source offsets inside a plane (depend on the tile only)
-  int opos[4];                               // output offset inside a plane (elements), -1 = pad column / beyond the plane
+  int opos[PIM];                             // output offset inside a plane (elements), -1 = pad column / beyond the plane
   float ssum[4][4], ssq[4][4];               // [j][r] running BatchNorm sums of this lane's rows
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -362,7 +385,6 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
 
   auto slot_of = [&](int tt) { const int s3 = (tt + 1) % 3; return s3; };          // tt >= -1
   auto issue_plane_piece = [&](int n_t0, int tt, int ps) {                          // n_t0 = n * T
-    if (ps == PNPASS - 1 && wave == 3) return;                                      // rows 376..383 do not exist
     const bool pok = (unsigned)tt < (unsigned)g.T;
     const unsigned so = __builtin_amdgcn_readfirstlane(pok ? (unsigned)((n_t0 + tt) * g.HW) * (HC * 2) : 0u);
     const unsigned vo = pok ? win_voff[ps] : HOOB;
@@ -375,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
   };
-  bf16x8_t fa[2][2][4], fb[2][2][4];                       // [buffer][ks][fragment]
+  bf16x8_t fa[2][2][PIM], fb[2][2][4];                     // [buffer][ks][fragment]
   auto read_operands = [&](int idx, int buf, int stage, int t) {                    // operands of window tap idx of output plane t
     const int gq = idx / 9, a = (idx % 9) / 3, b = idx % 3;
     const unsigned char* wb = Ws + stage * (64 * 128);
@@ -389,22 +411,22 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
     const unsigned char* hb = Hs + slot_of(t - 1 + gq) * PPLANE + row * 128;
     const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PIM; ++i) {
       fa[buf][0][i] = *reinterpret_cast<const bf16x8_t*>(hb + g0 + i * 2048);
       fa[buf][1][i] = *reinterpret_cast<const bf16x8_t*>(hb + g1 + i * 2048);
     }
   };
 
-  int par = 0;
+  int sbase = 0;                             // ring stage of the current item's tap 0  (= taps done so far, mod 4)
   bool cont = false;                         // this item continues the previous item's chain (operands prefetched)
   for (int it = it_beg; it < it_end; ++it) {
     const int chain = fdiv(it, g.dT), t = it - chain * g.T;          // chain = n * tiles + tile
     const int n = fdiv(chain, g.dTiles), tile = chain - n * g.tiles;
     const int n_t0 = n * g.T;
-    const int q0 = g.Wp + tile * HBM;
+    const int q0 = g.Wp + tile * PBM;
     const bool next_cont = (it + 1 < it_end) && (t + 1 < g.T);
     if (!cont) {
-      // ---- chain start: window offsets of this tile, all three planes, first two weight tiles ----
+      // ---- chain start: window offsets of this tile, all three planes, first three weight tiles ----
 #pragma unroll
       for (int ps = 0; ps < PNPASS; ++ps) {
         const int j = ps * 32 + (tid >> 3), pg = tid & 7;
@@ -415,8 +437,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
         win_voff[ps] = ok ? (unsigned)((((hp - 1) * g.W + (wp - 1)) * HC + lg * 8) * 2) : HOOB;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = q0 + wave * 64 + i * 16 + fr;
+      for (int i = 0; i < PIM; ++i) {
+        const int q = q0 + wave * (PBM / 4) + i * 16 + fr;
         const int hp = fdiv(q, g.dWp), wp = q - hp * g.Wp;
         opos[i] = (hp <= g.H && wp >= 1 && wp <= g.W) ? ((hp - 1) * g.W + (wp - 1)) * HC : -1;
       }
@@ -426,56 +448,90 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t - 1, ps);
-      issue_weights(0, par);
+      issue_weights(0, sbase & 3);
 #pragma unroll
       for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t, ps);
 #pragma unroll
       for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t + 1, ps);
-      issue_weights(1, par ^ 1);
+      issue_weights(1, (sbase + 1) & 3);
+      issue_weights(2, (sbase + 2) & 3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      read_operands(0, 0, par, t);
+      read_operands(0, 0, sbase & 3, t);
+      if (HALO_EXP & 2) read_operands(0, 1, sbase & 3, t);
     }
-    f32x4_t acc[4][4];                                     // [j: channel tile][i: position tile]
+    f32x4_t acc[4][PIM];                                   // [j: channel tile][i: position tile]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
+      for (int i = 0; i < PIM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifdef HALO_CLOCK
+    tprev = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int idx = 0; idx < 27; ++idx) {
       const int cur = idx & 1;
+      const bool more = idx < 26 || next_cont;             // another tap follows in this chain
+      if (more) {
+        // The weight tile of the next tap was issued two taps ago (or at the chain start); everything younger may stay in
+        // flight: the window pieces of the two previous taps and the weight tile issued a tap ago.  The barrier then
+        // publishes it and says every wave holds this tap's fragments, so the stage three taps ahead may be refilled.
+        HSTAMP(0);
+        {
+          const int p2 = (idx - 2 >= 9 && idx - 2 < 9 + PNPASS && next_cont) ? 1 : 0;
+          const int p1 = (idx - 1 >= 9 && idx - 1 < 9 + PNPASS && next_cont) ? 1 : 0;
+          const int w1 = (idx + 2 < 27 || next_cont) ? 2 : 0;       // the tile issued a tap ago (or, at tap 0, by the previous item / the chain start) is W(idx + 2)
+          const int younger = p2 + w1 + p1;
+          if (younger == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          else if (younger == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+          else if (younger == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+          else if (younger == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        }
+        HSTAMP(1);
+        if (!(HALO_EXP & 1)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        HSTAMP(2);
+        if (!(HALO_EXP & 2)) {
+          if (idx < 26) read_operands(idx + 1, cur ^ 1, (sbase + idx + 1) & 3, t);
+          else read_operands(0, 1, (sbase + 27) & 3, t + 1);                          // next item's first tap
+        }
+        if (!(HALO_EXP & 4)) {
+          if (idx + 3 < 27) issue_weights(idx + 3, (sbase + idx + 3) & 3);
+          else if (next_cont) issue_weights(idx + 3 - 27, (sbase + idx + 3) & 3);
+        }
+        if (!(HALO_EXP & 8) && idx >= 9 && idx < 9 + PNPASS && next_cont) issue_plane_piece(n_t0, t + 2, idx - 9);    // slot of plane t-1: free since tap 8
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PIM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][0][j], fa[cur][0][i], acc[j][i], 0, 0, 0);
-      if (idx < 26 || next_cont) {
-        // everything issued a tap ago has landed for this wave; the barrier publishes it and says every wave holds its
-        // tap-`idx` fragments, so weight stage (idx & 1) ^ par may be refilled
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (idx < 26) read_operands(idx + 1, cur ^ 1, ((idx + 1) & 1) ^ par, t);
-        else read_operands(0, 1, par ^ 1, t + 1);                                   // next item's first tap
-        if (idx >= 9 && idx < 9 + PNPASS && next_cont) issue_plane_piece(n_t0, t + 2, idx - 9);    // slot of plane t-1: free since tap 8
-        if (idx + 2 < 27) issue_weights(idx + 2, cur ^ par);
-        else if (next_cont) issue_weights(idx + 2 - 27, cur ^ par);
+      // one LDS read after each of the first MFMAs, the DMA instructions after them
+#pragma unroll
+      for (int u = 0; u < 4 * PIM; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (4 + PIM) - 4 * PIM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+      HSTAMP(3);
       __builtin_amdgcn_sched_barrier(0);        // keep the next tap's operand reads ABOVE this tap's second k step
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PIM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      HSTAMP(4);
     }
 
     // ---- item epilogue: statistics into registers, (+addend) -> bf16, 8-byte stores ----
+    if ((HALO_EXP & 16) && it + 1 < it_end) { if (next_cont) {} sbase = (sbase + 27) & 3; cont = next_cont; continue; }
     const long pbase = (long)(n_t0 + t) * g.HW * HC;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PIM; ++i) {
       if (opos[i] < 0) continue;
       const long o0 = pbase + opos[i];
 #pragma unroll
@@ -495,14 +551,24 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
     }
     if (next_cont) {                         // 27 taps: the prefetched operands sit in buffer 1, the next item starts on buffer 0
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { fa[0][ks][f] = fa[1][ks][f]; fb[0][ks][f] = fb[1][ks][f]; }
-      par ^= 1;
+        for (int f = 0; f < PIM; ++f) fa[0][ks][f] = fa[1][ks][f];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fb[0][ks][f] = fb[1][ks][f];
+      }
     }
+    sbase = (sbase + 27) & 3;
     cont = next_cont;
   }
 
+#ifdef HALO_CLOCK
+  if (tid == 0 && blockIdx.x < 4096) {
+    halo_clock_dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+    halo_clock_dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    if (HALO_CLOCK == 2 && blockIdx.x < 256) { for (int q_ = 0; q_ < 5; ++q_) halo_seg_dbg[5 * blockIdx.x + q_] = seg[q_] / (unsigned long long)(it_end - it_beg); }
+  }
+#endif
   // ---- block epilogue: BatchNorm statistics, one reduction and 128 atomics per block ----
   if (stat_sum != nullptr) {
     for (int i = tid; i < 2 * HC; i += 256) red[i] = 0.f;
@@ -541,11 +607,12 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
   g.tiles = (d->H * g.Wp + HBM - 1) / HBM; g.mode = mode;
   g.dWp = make_fastdiv(g.Wp);
   g.dT = make_fastdiv(d->T); g.dTiles = make_fastdiv(g.tiles);
-  // opt-in: alone it is faster on the forward conv (119 vs 135 us: statistics once per block) and equal on the
-  // gradient (118 vs 114 us), but inside the three-stream step its 256 long-lived 160-KB blocks schedule worse
-  // against the other streams' kernels (725 vs 734 clip-pairs/s)
+  // opt-in: alone it is faster on the forward conv (112 vs 125-134 us: statistics once per block) and about equal on
+  // the gradient (106-113 vs 112-114 us), but inside the three-stream step its 256 long-lived blocks schedule worse
+  // against the other streams' kernels (785-793 vs 804-808 clip-pairs/s)
   const char* pv = getenv("MSCL_HALO_PERSIST");
-  if (pv && pv[0] == '1' && HBM + 2 * g.Wp + 2 <= NHP) {
+  if (pv && pv[0] == '1' && PBM + 2 * g.Wp + 2 <= NHP) {
+    g.tiles = (d->H * g.Wp + PBM - 1) / PBM; g.dTiles = make_fastdiv(g.tiles);
     static int cus = 0;
     static bool attr_done_p = false;
     if (!attr_done_p) {
@@ -557,13 +624,13 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
     }
     const int items = d->N * d->T * g.tiles;
     const int grid = items < cus ? items : cus;
-    const size_t ldsp = (size_t)3 * PPLANE + 2 * 64 * 128 + 2 * HC * sizeof(float);
+    const size_t ldsp = (size_t)3 * PPLANE + 4 * 64 * 128 + 2 * HC * sizeof(float);
     hipLaunchKernelGGL(conv_halo64p_kernel, dim3((unsigned)grid), dim3(256), ldsp, (hipStream_t)stream, g, items, src, w, out, addend,
                        ssum, ssq);
     MSCL_LAUNCH_CHECK();
     return 1;
   }
-  const size_t lds = (size_t)3 * PLANE_BYTES + 2 * 64 * 128;
+  const size_t lds = (size_t)2 * PLANE_BYTES + 4 * 64 * 128;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
