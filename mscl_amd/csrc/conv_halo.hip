@@ -21,6 +21,7 @@
 //  * 4 waves, 64 positions x 64 channels each: 16 ds_read_b128 per 32 MFMAs (half the LDS read rate);
 //  * epilogue as in conv_igemm.hip: BatchNorm sum / sum-of-squares, optional addend, bf16, 8-byte stores.
 #include "common.h"
+#include <cstdlib>
 
 struct HaloGeom {
   int N, T, H, W, HW, Wp;          // Wp = W + 2 padded row length
@@ -62,29 +63,35 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // NW = waves per block.  4: one wave per SIMD, 64 positions x 64 channels each.  8: two waves per SIMD, 32 positions each,
 // so one wave's barrier / LDS waits are covered by its neighbour's MFMAs (at 12 instead of 8 LDS reads per 16 MFMAs).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
+// BM = positions per block, RING = weight-ring stages.  <4, 256, 4>: one 128-KB block per CU.  <4, 128, 2>: 80 KB, TWO
+// blocks per CU -- the second block computes through the first one's dispatch gap, window prologue, barriers and epilogue
+// (those cost 45 % of a block slot at one block per CU), at the price of twice the weight traffic per position.
+template <int NW, int BM, int RING>
+__global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
                                                              float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // The three source planes are visited one after the other, so TWO window slots suffice: the third plane streams into
-  // the first one's slot while the second is in use.  That frees LDS for a 4-stage weight ring: a weight tile is issued
-  // three taps before it is needed (its L2 latency under load is ~1.5 taps; with a 2-stage ring, one tap ahead, every
-  // tap waited for it: 915 instead of 512 cycles per tap by in-kernel s_memtime stamps).
-  unsigned char* const Hs = smem;                          // [2][NH][128 B] input window slots, row j <-> q0 - Wp - 1 + j
-  unsigned char* const Ws = smem + 2 * PLANE_BYTES;        // [4][64][128 B] weight ring
+  // the first one's slot while the second is in use.  The freed LDS holds a deeper weight ring (tiles issued RING taps
+  // before use) or, with 128-position tiles, a second block per CU.
   constexpr int RPP = 8 * NW;                              // window rows per DMA pass (64 * NW threads x 16 B)
-  constexpr int NPS = NH / RPP;                            // DMA pieces per thread per plane
-  constexpr int PPT = NPS / 6;                             // ... issued per tap while a plane streams in (6 taps)
-  constexpr int WPOS = HBM / NW, IM = WPOS / 16;           // positions per wave, position tiles per wave
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int NHK = (BM + 128 + RPP - 1) / RPP * RPP;    // window rows per plane (BM + 2 * (W + 2) + 2, W <= 61)
+  constexpr int PLANE = NHK * 128;
+  constexpr int NPS = NHK / RPP;                           // DMA pieces per thread per plane
+  constexpr int PPT1 = (NPS + 4) / 5;                      // plane 2 streams in under taps 0..4 (landed before tap 9's operands are read)
+  constexpr int PPT2 = (NPS + 5) / 6;                      // plane 3 under taps 8..13, into plane 1's slot
+  constexpr int WPOS = BM / NW, IM = WPOS / 16;            // positions per wave, position tiles per wave
+  constexpr int WP = NW == 4 ? 2 : 1;                      // DMA instructions per weight tile per wave
+  static_assert((NW == 4 || NW == 8) && (RING == 2 || RING == 4) && WPOS % 16 == 0, "configuration");
+  unsigned char* const Hs = smem;                          // [2][NHK][128 B] input window slots, row j <-> q0 - Wp - 1 + j
+  unsigned char* const Ws = smem + 2 * PLANE;              // [RING][64][128 B] weight ring
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = bid % g.tiles, plane = bid / g.tiles;   // plane = n*T + t
   const int t = plane % g.T;
-  const int q0 = g.Wp + tile * HBM;                        // first padded-linear position of this tile (hp = 1, wp = 0)
+  const int q0 = g.Wp + tile * BM;                         // first padded-linear position of this tile (hp = 1, wp = 0)
   const int mode = __builtin_amdgcn_readfirstlane(g.mode);
 #ifdef HALO_CLOCK
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   auto issue_plane_piece = [&](int hp, int ps) {
     const unsigned so = __builtin_amdgcn_readfirstlane(plane_soff(hp));
     const unsigned vo = plane_ok(hp) ? win_voff[ps] : HOOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + (hp == 1 ? PLANE_BYTES : 0) + (ps * 64 * NW + wave * 64) * 16), 16, vo, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + (hp == 1 ? PLANE : 0) + (ps * 64 * NW + wave * 64) * 16), 16, vo, so, 0, 0);
   };
   // ---- weights: tap `tap` -> ring stage tap & 3; rows = output channel n (forward) / input channel (gradient, wT) ----
   // LDS-DMA into a 4-stage ring, issued three taps ahead.  (Staging them through registers instead -- 16-byte loads plus
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
   auto issue_weights = [&](int tap) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
-    unsigned char* dst = Ws + (tap & 3) * (64 * 128) + wave * 1024;
+    unsigned char* dst = Ws + (tap % RING) * (64 * 128) + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
     if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
   };
@@ -144,9 +151,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   // ---- prologue: first plane, weights of taps 0 and 1 ----
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) issue_plane_piece(tap_plane(0), ps);
-  issue_weights(0);
-  issue_weights(1);
-  issue_weights(2);
+#pragma unroll
+  for (int w0 = 0; w0 < RING; ++w0) issue_weights(w0);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int arow0 = wave * WPOS + fr;                      // window row of fragment 0 at shift 0
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
   bf16x8_t fa[2][2][IM], fb[2][2][4];                      // [buffer][ks][fragment]
   auto read_operands = [&](int tap, int buf) {
     const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
-    const unsigned char* wb = Ws + (tap & 3) * (64 * 128);
+    const unsigned char* wb = Ws + (tap % RING) * (64 * 128);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       fb[buf][0][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr0 + j * 2048);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
     }
     const int row = arow0 + tap_shift(kh, kw);
     const int key = row & 7;
-    const unsigned char* hb = Hs + (kt == 1 ? PLANE_BYTES : 0) + row * 128;
+    const unsigned char* hb = Hs + (kt == 1 ? PLANE : 0) + row * 128;
     const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
@@ -180,8 +186,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
 #pragma unroll
     for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // plane + tap-0 weights landed (taps 1, 2 in flight)
-  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  // plane + tap-0 weights landed; the other RING - 1 weight tiles stay in flight
+  if constexpr (WP * (RING - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (WP * (RING - 1) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (WP * (RING - 1) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   read_operands(0, 0);
@@ -199,25 +208,29 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
       for (int i = 0; i < IM; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][0][j], fa[cur][0][i], acc[j][i], 0, 0, 0);
     if (tap + 1 < 27) {
-      // The barrier publishes ring stage (tap+1)&1 and says every wave holds its tap-`tap` fragments in registers, so
-      // stage `cur` may be refilled with tap+2.  Raw s_barrier: __syncthreads() would drain vmcnt as well.
-      // Wait for the weight tile of tap + 1 (issued two taps ago, or in the prologue).  Everything issued after it may stay
-      // in flight: the window pieces of the two previous taps and the weight tile of tap + 2 -- the count is a
-      // compile-time constant per tap (the loop is fully unrolled).  In-order retirement also guarantees that a window
-      // plane has landed two taps after its last piece was issued.
+      // Wait for the weight tile of tap + 1, then barrier: it publishes that tile and says every wave holds its tap-`tap`
+      // fragments in registers, so their ring stage may be refilled with tap + RING.  (Raw s_barrier: __syncthreads()
+      // would drain vmcnt as well.)  Everything issued AFTER the awaited tile may stay in flight -- later weight tiles
+      // and the window pieces of the last RING - 1 taps; the count is a compile-time constant per tap (fully unrolled
+      // loop).  The piece schedule ends three taps before a plane's first use, so in-order retirement has it landed.
       HSTAMP(0);
       {
-        auto pieces_at = [](int tp) { return ((tp >= 0 && tp < 6) || (tp >= 8 && tp < 14)) ? PPT : 0; };
-        constexpr int WP = NW == 4 ? 2 : 1;                      // DMA instructions per weight tile per wave
-        const int younger = pieces_at(tap - 2) + (tap >= 1 && tap + 2 < 27 ? WP : 0) + pieces_at(tap - 1) + (tap == 0 ? 2 * WP - WP : 0);
+        auto pieces_at = [](int tp) {
+          if (tp >= 0 && tp < 5) { const int lo = PPT1 * tp, hi = PPT1 * (tp + 1) < NPS ? PPT1 * (tp + 1) : NPS; return hi > lo ? hi - lo : 0; }
+          if (tp >= 8 && tp < 14) { const int lo = PPT2 * (tp - 8), hi = PPT2 * (tp - 7) < NPS ? PPT2 * (tp - 7) : NPS; return hi > lo ? hi - lo : 0; }
+          return 0;
+        };
+        int younger = 0;
+        {
+          const int wy = RING - 2 < 25 - tap ? RING - 2 : 25 - tap;         // weight tiles tap+2 .. issued so far
+          younger = WP * (wy > 0 ? wy : 0);
+          for (int sp = (tap + 1 - RING > 0 ? tap + 1 - RING : 0); sp <= tap - 1; ++sp) younger += pieces_at(sp);
+        }
         switch (younger) {
-          case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-          case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
-          case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
-          case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
-          case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-          case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
-          case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+#define HW_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+          HW_CASE(0) HW_CASE(1) HW_CASE(2) HW_CASE(3) HW_CASE(4) HW_CASE(5) HW_CASE(6) HW_CASE(7) HW_CASE(8) HW_CASE(9) HW_CASE(10)
+          HW_CASE(11) HW_CASE(12) HW_CASE(13) HW_CASE(14)
+#undef HW_CASE
           default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
         }
       }
@@ -226,17 +239,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_halo64_kernel(const HaloGeom 
       asm volatile("" ::: "memory");
       HSTAMP(2);
       if (!(HALO_EXP & 2)) read_operands(tap + 1, cur ^ 1);
-      // weight tile of tap + 2 first, then this tap's share of window planes 2 and 3 (in-order retirement: see the wait above)
+      // weight tile of tap + RING first, then this tap's share of window planes 2 and 3 (in-order retirement: see the wait)
       if (!(HALO_EXP & 4)) {
-        if (tap + 3 < 27) issue_weights(tap + 3);
+        if (tap + RING < 27) issue_weights(tap + RING);
       }
       if (!(HALO_EXP & 8)) {
-        if (tap < 6) {
+        if (tap < 5) {
 #pragma unroll
-          for (int u = 0; u < PPT; ++u) issue_plane_piece(tap_plane(1), PPT * tap + u);
+          for (int u = 0; u < PPT1; ++u) if (PPT1 * tap + u < NPS) issue_plane_piece(tap_plane(1), PPT1 * tap + u);
         } else if (tap >= 8 && tap < 14) {
 #pragma unroll
-          for (int u = 0; u < PPT; ++u) issue_plane_piece(tap_plane(2), PPT * (tap - 8) + u);
+          for (int u = 0; u < PPT2; ++u) if (PPT2 * (tap - 8) + u < NPS) issue_plane_piece(tap_plane(2), PPT2 * (tap - 8) + u);
         }
       }
     }
@@ -630,20 +643,30 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
     MSCL_LAUNCH_CHECK();
     return 1;
   }
-  const size_t lds = (size_t)2 * PLANE_BYTES + 4 * 64 * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4, 256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<8, 256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const char* w8 = getenv("MSCL_HALO_WAVES");
-  if (w8 && w8[0] == '8')
-    hipLaunchKernelGGL(conv_halo64_kernel<8>, dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, (hipStream_t)stream, g, src, w,
-                       out, addend, ssum, ssq);
-  else
-    hipLaunchKernelGGL(conv_halo64_kernel<4>, dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, (hipStream_t)stream, g, src, w,
-                       out, addend, ssum, ssq);
+  const char* bm = getenv("MSCL_HALO_BM");
+  hipStream_t st = (hipStream_t)stream;
+  if (bm && atoi(bm) == 128) {
+    g.tiles = (d->H * g.Wp + 127) / 128;
+    const size_t lds = (size_t)2 * 256 * 128 + 2 * 64 * 128;          // 80 KB: two blocks per CU
+    hipLaunchKernelGGL((conv_halo64_kernel<4, 128, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
+                       addend, ssum, ssq);
+  } else if (w8 && w8[0] == '8') {
+    const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
+    hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, st, g, src, w, out,
+                       addend, ssum, ssq);
+  } else {
+    const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
+    hipLaunchKernelGGL((conv_halo64_kernel<4, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
+                       addend, ssum, ssq);
+  }
   MSCL_LAUNCH_CHECK();
   return 1;
 }
