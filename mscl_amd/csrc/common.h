@@ -32,6 +32,17 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane of the row.  VALU + DPP only:
+// __shfl_xor compiles to ds_bpermute_b32 (an LDS crossbar instruction with LDS latency), 128 of them per wave in a conv
+// epilogue that reduces BatchNorm statistics over the 16 positions a row of lanes holds.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -292,8 +292,7 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
         for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s[r] += __shfl_xor(s[r], o, 64); q[r] += __shfl_xor(q[r], o, 64); }
+        s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
       }
       if (fr == 0) {
 #pragma unroll
@@ -591,8 +590,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float sv = ssum[j][r], qv = ssq[j][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+        sv = row16_sum(sv); qv = row16_sum(qv);
         if (fr == 0) {
           const int nl = j * 16 + fq * 4 + r;
           atomicAdd(&red[nl], sv);

@@ -105,8 +105,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
         for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s[r] += __shfl_xor(s[r], o, 64); q[r] += __shfl_xor(q[r], o, 64); }
+        s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
       }
       if (fr == 0) {
 #pragma unroll
