@@ -43,15 +43,23 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)));
   return v;
 }
+// whole-wave reductions, result wave-uniform: DPP inside the four rows, then one v_readlane per row
+__device__ __forceinline__ float wave_sum(float v) {
+  const int r = __builtin_bit_cast(int, row16_sum(v));
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48)));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const int r = __builtin_bit_cast(int, row16_max(v));
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48))));
 }
 
 // Block-wide per-channel sum for the "G = C/8 threads per row, 256/G rows per pass" thread layout used by the
