@@ -9,11 +9,13 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
                                                          int Cin, long THW, long THW_total, long off, float m0, float m1,
                                                          float m2, float i0, float i1, float i2,
                                                          const unsigned char* __restrict__ flip, int W) {
-  const long total = (long)B * THW;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long b = e / THW;
-    long p = e - b * THW;
-    if (flip != nullptr && flip[b]) { const long row = p / W; p = row * W + (W - 1 - (p - row * W)); }   // torch.flip(x, [-1])
+  // blockIdx.y = sample: no per-element division
+  const long b = blockIdx.y;
+  const bool fl = flip != nullptr && flip[b];
+  for (long p0 = (long)blockIdx.x * blockDim.x + threadIdx.x; p0 < THW; p0 += (long)gridDim.x * blockDim.x) {
+    const long e = b * THW + p0;
+    long p = p0;
+    if (fl) { const long row = p / W; p = row * W + (W - 1 - (p - row * W)); }   // torch.flip(x, [-1])
     const float* xb = x + b * Cin * THW_total + off + p;
     float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     f[0] = (xb[0] - m0) * i0;
@@ -29,9 +31,9 @@ extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, in
   if (Cin < 1 || Cin > 3) return MSCL_E_SHAPE;
   float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
   if (mean3 && std3) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; iv[i] = 1.f / std3[i]; }   // host arrays
-  const long THW = (long)T * H * W, total = (long)B * THW;
-  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, B, Cin, THW,
+  const long THW = (long)T * H * W;
+  long blocks = (THW + 255) / 256; if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out, B, Cin, THW,
                      (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2], flip_mask, W);
   MSCL_LAUNCH_CHECK();
   return 0;
@@ -245,18 +247,21 @@ __device__ __forceinline__ void lin_coord(int d, int in, int outn, int& i0, int&
   i0 = (int)s; if (i0 > in - 1) i0 = in - 1;
   i1 = i0 + 1 > in - 1 ? in - 1 : i0 + 1; w1 = s - (float)i0;
 }
+// index decode by multiply-shift (FastDiv): 64-bit / and % by runtime values cost ~100 instructions each, five per element
+struct UpDiv { FastDiv G, Wd, Hd, Td, Ws, Hs, Ts; };
 __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N,
                                                            int Ts, int Hs, int Ws, int Td, int Hd, int Wd, int C,
-                                                           int trilinear, int accumulate) {
+                                                           int trilinear, int accumulate, UpDiv dv) {
   const int G = C >> 3;
-  const long total = (long)N * Td * Hd * Wd * G;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int gq = (int)(e % G); long r = e / G;
-    const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd;
-    const int t = (int)(r % Td); const int n = (int)(r / Td);
+  const int total = N * Td * Hd * Wd * G;            // < 2^31 (checked by the launcher)
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int r = fdiv(e, dv.G); const int gq = e - r * G;
+    int q = fdiv(r, dv.Wd); const int w = r - q * Wd; r = q;
+    q = fdiv(r, dv.Hd); const int h = r - q * Hd; r = q;
+    const int n = fdiv(r, dv.Td), t = r - n * Td;
     float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!trilinear) {
-      const int ts = (int)((long)t * Ts / Td), hs = (int)((long)h * Hs / Hd), ws = (int)((long)w * Ws / Wd);
+      const int ts = fdiv(t * Ts, dv.Td), hs = fdiv(h * Hs, dv.Hd), ws = fdiv(w * Ws, dv.Wd);
       unpack8(*reinterpret_cast<const uint4*>(src + ((((long)n * Ts + ts) * Hs + hs) * Ws + ws) * C + gq * 8), f);
     } else {
       int t0, t1, h0, h1, w0, w1; float a, b, c;
@@ -272,21 +277,27 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
       }
     }
     if (accumulate) {
-      float d8[8]; unpack8(*reinterpret_cast<const uint4*>(dst + e * 8), d8);
+      float d8[8]; unpack8(*reinterpret_cast<const uint4*>(dst + (long)e * 8), d8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] += d8[i];
     }
-    *reinterpret_cast<uint4*>(dst + e * 8) = pack8(f);
+    *reinterpret_cast<uint4*>(dst + (long)e * 8) = pack8(f);
   }
+}
+static UpDiv make_updiv(int G, int Ts, int Hs, int Ws, int Td, int Hd, int Wd) {
+  UpDiv d; d.G = make_fastdiv(G); d.Wd = make_fastdiv(Wd); d.Hd = make_fastdiv(Hd); d.Td = make_fastdiv(Td);
+  d.Ws = make_fastdiv(Ws); d.Hs = make_fastdiv(Hs); d.Ts = make_fastdiv(Ts);
+  return d;
 }
 extern "C" int mscl_upsample_add(const uint16_t* src, uint16_t* dst, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
                                  int C, int trilinear, int accumulate, void* stream) {
   if (!src || !dst || N <= 0 || Ts <= 0 || Hs <= 0 || Ws <= 0 || Td <= 0 || Hd <= 0 || Wd <= 0) return MSCL_E_ARG;
   if (C % 8) return MSCL_E_SHAPE;
   const long total = (long)N * Td * Hd * Wd * (C / 8);
+  if (total >= (1L << 31) || (long)Td * Ts >= (1L << 31)) return MSCL_E_SHAPE;
   long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, Ts, Hs, Ws,
-                     Td, Hd, Wd, C, trilinear, accumulate);
+                     Td, Hd, Wd, C, trilinear, accumulate, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -295,30 +306,31 @@ extern "C" int mscl_upsample_add(const uint16_t* src, uint16_t* dst, int N, int 
 // Per axis a coarse index i receives from fine d in a window; we scan the (small) fine extent per axis.
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restrict__ dd, bf16_t* __restrict__ ds, int N,
                                                            int Ts, int Hs, int Ws, int Td, int Hd, int Wd, int C,
-                                                           int trilinear) {
+                                                           int trilinear, UpDiv dv) {
   const int G = C >> 3;
-  const long total = (long)N * Ts * Hs * Ws * G;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int gq = (int)(e % G); long r = e / G;
-    const int ws = (int)(r % Ws); r /= Ws; const int hs = (int)(r % Hs); r /= Hs;
-    const int ts = (int)(r % Ts); const int n = (int)(r / Ts);
+  const int total = N * Ts * Hs * Ws * G;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int r = fdiv(e, dv.G); const int gq = e - r * G;
+    int q = fdiv(r, dv.Ws); const int ws = r - q * Ws; r = q;
+    q = fdiv(r, dv.Hs); const int hs = r - q * Hs; r = q;
+    const int n = fdiv(r, dv.Ts), ts = r - n * Ts;
     float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // candidate fine ranges: a coarse index influences fine indices within +-ceil(out/in)+1 of its centre
     const int rt = Td / Ts + 2, rh = Hd / Hs + 2, rw = Wd / Ws + 2;
-    const int ct = (int)(((long)ts * Td) / Ts), ch = (int)(((long)hs * Hd) / Hs), cw = (int)(((long)ws * Wd) / Ws);
+    const int ct = fdiv(ts * Td, dv.Ts), ch = fdiv(hs * Hd, dv.Hs), cw = fdiv(ws * Wd, dv.Ws);
     for (int t = max(0, ct - rt); t <= min(Td - 1, ct + rt); ++t) {
       float wt_t;
-      if (!trilinear) { wt_t = ((int)((long)t * Ts / Td) == ts) ? 1.f : 0.f; }
+      if (!trilinear) { wt_t = (fdiv(t * Ts, dv.Td) == ts) ? 1.f : 0.f; }
       else { int i0, i1; float a; lin_coord(t, Ts, Td, i0, i1, a); wt_t = (i0 == ts ? 1.f - a : 0.f) + (i1 == ts ? a : 0.f); }
       if (wt_t == 0.f) continue;
       for (int h = max(0, ch - rh); h <= min(Hd - 1, ch + rh); ++h) {
         float wt_h;
-        if (!trilinear) { wt_h = ((int)((long)h * Hs / Hd) == hs) ? 1.f : 0.f; }
+        if (!trilinear) { wt_h = (fdiv(h * Hs, dv.Hd) == hs) ? 1.f : 0.f; }
         else { int i0, i1; float a; lin_coord(h, Hs, Hd, i0, i1, a); wt_h = (i0 == hs ? 1.f - a : 0.f) + (i1 == hs ? a : 0.f); }
         if (wt_h == 0.f) continue;
         for (int w = max(0, cw - rw); w <= min(Wd - 1, cw + rw); ++w) {
           float wt_w;
-          if (!trilinear) { wt_w = ((int)((long)w * Ws / Wd) == ws) ? 1.f : 0.f; }
+          if (!trilinear) { wt_w = (fdiv(w * Ws, dv.Wd) == ws) ? 1.f : 0.f; }
           else { int i0, i1; float a; lin_coord(w, Ws, Wd, i0, i1, a); wt_w = (i0 == ws ? 1.f - a : 0.f) + (i1 == ws ? a : 0.f); }
           if (wt_w == 0.f) continue;
           float g8[8];
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restr
         }
       }
     }
-    *reinterpret_cast<uint4*>(ds + e * 8) = pack8(f);
+    *reinterpret_cast<uint4*>(ds + (long)e * 8) = pack8(f);
   }
 }
 extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
@@ -337,9 +349,10 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
   if (!ddst || !dsrc || N <= 0 || Ts <= 0 || Hs <= 0 || Ws <= 0 || Td <= 0 || Hd <= 0 || Wd <= 0) return MSCL_E_ARG;
   if (C % 8) return MSCL_E_SHAPE;
   const long total = (long)N * Ts * Hs * Ws * (C / 8);
+  if ((long)N * Td * Hd * Wd * (C / 8) >= (1L << 31) || (long)Td * Ts >= (1L << 31)) return MSCL_E_SHAPE;
   long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, N, Ts, Hs, Ws,
-                     Td, Hd, Wd, C, trilinear);
+                     Td, Hd, Wd, C, trilinear, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
   MSCL_LAUNCH_CHECK();
   return 0;
 }
