@@ -2,6 +2,7 @@
 // HBM-bound passes: 16-byte (8-channel) accesses, lanes run along the channel axis so every wave
 // touches whole contiguous rows; per-channel constants live in LDS.
 #include "common.h"
+#include <cstdlib>
 
 struct BnDev {
   const float* sum; const float* sumsq; const float* gamma; const float* beta;
