@@ -177,6 +177,14 @@ int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const
                  const float* row_scale, float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T,
                  void* stream);
 
+/* The step's log vector (17 or 23 floats, MSCLWithAug's key order, last entry = sum of the loss entries) from the per-row
+ * results of the three queue passes and the LMCL kernel: mean loss / top-1 / top-5 per InfoNCE group
+ * (heads/moco_head.py:60-77, core/evaluation/accuracy.py:130-149 as a rank count) and recognizers/base.py:287-298.
+ * rank/loss arrays hold nA (A), 1 (B), nC (C) groups of B rows; nA == nC in {2, 3}. */
+int mscl_step_logs(const int32_t* rankA, const float* lossA, const int32_t* rankB, const float* lossB,
+                   const int32_t* rankC, const float* lossC, const float* lmcl_sum, const int32_t* lmcl_hits, int B,
+                   int nA, int nC, float w_intra, float n_rows, float* logs, void* stream);
+
 /* pos[r] = <a[r], b[r]> (l_pos, recognizers/moco.py:481) and the positive-key term of the query gradient:
  * dq[r] += row_scale[r] * inv_T * (softmax_pos[r] - 1) * kpos[r] */
 int mscl_rowdot(const float* a, const float* b, float* out, int rows, int dim, void* stream);

@@ -233,6 +233,61 @@ extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const floa
   return 0;
 }
 
+// ---------------------------------------------------------------- the step's log vector in one launch
+// mean loss / top-1 / top-5 per InfoNCE group (heads/moco_head.py:60-77: accuracy = share of rows whose positive is
+// ranked < k), the LMCL entries, and their sum (recognizers/base.py:297-298), in MSCLWithAug's key order.  Replaces ~50
+// compare / cast / mean / stack micro-kernels per step.
+// groups: A = RGB queue pass (rows [q_rgb | q_flow | q_flow_rot]), B = flow queue pass, C = flow queue pass after the
+// base-flow enqueue (rows [q_flow_rot | q_rgb | q_rgb]); nA, nC in {2, 3} (3 = cross-modal terms of the rotated flow).
+__global__ __launch_bounds__(64) void mscl_logs_kernel(const int32_t* __restrict__ rankA, const float* __restrict__ lossA,
+                                                       const int32_t* __restrict__ rankB, const float* __restrict__ lossB,
+                                                       const int32_t* __restrict__ rankC, const float* __restrict__ lossC,
+                                                       const float* __restrict__ lmcl_sum, const int32_t* __restrict__ lmcl_hits,
+                                                       int B, int nA, int nC, float w_intra, float n_rows, float* __restrict__ logs) {
+  __shared__ float g3[7][3];                       // [group][top1, top5, loss]: A0 A1 A2 B C0 C1 C2
+  const int lane = threadIdx.x;
+  for (int grp = 0; grp < 7; ++grp) {
+    const int32_t* rk; const float* ls; int idx;
+    if (grp < 3) { rk = rankA; ls = lossA; idx = grp; if (idx >= nA) continue; }
+    else if (grp == 3) { rk = rankB; ls = lossB; idx = 0; }
+    else { rk = rankC; ls = lossC; idx = grp - 4; if (idx >= nC) continue; }
+    float t1 = 0.f, t5 = 0.f, l = 0.f;
+    for (int r = lane; r < B; r += 64) {
+      const int rr = rk[idx * B + r];
+      t1 += rr < 1 ? 1.f : 0.f; t5 += rr < 5 ? 1.f : 0.f; l += ls[idx * B + r];
+    }
+    t1 = wave_sum(t1); t5 = wave_sum(t5); l = wave_sum(l);
+    if (lane == 0) { g3[grp][0] = t1 / (float)B; g3[grp][1] = t5 / (float)B; g3[grp][2] = l / (float)B; }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int o = 0;
+    float total = 0.f;
+    auto put3 = [&](int grp) { logs[o++] = g3[grp][0]; logs[o++] = g3[grp][1]; logs[o++] = g3[grp][2]; total += g3[grp][2]; };
+    put3(0);                                              // top1_acc, top5_acc, loss_cls
+    put3(3);                                              // *_flow
+    { const float v = g3[4][2] * w_intra; logs[o++] = v; total += v; }      // loss_cls_flow_aug
+    put3(5);                                              // *_mx        (q_rgb vs flow queue)
+    put3(1);                                              // *_mx_r      (q_flow vs rgb queue)
+    if (nA == 3 && nC == 3) { put3(6); put3(2); }         // *_mx_aug, *_mx_r_aug
+    const float lp = lmcl_sum[0] / n_rows;
+    logs[o++] = lp; total += lp;                          // loss_pos
+    logs[o++] = (float)lmcl_hits[0] / n_rows;             // top1_acc_pos
+    logs[o++] = (float)lmcl_hits[1] / n_rows;             // top5_acc_pos
+    logs[o++] = total;                                    // loss
+  }
+}
+extern "C" int mscl_step_logs(const int32_t* rankA, const float* lossA, const int32_t* rankB, const float* lossB,
+                              const int32_t* rankC, const float* lossC, const float* lmcl_sum, const int32_t* lmcl_hits, int B,
+                              int nA, int nC, float w_intra, float n_rows, float* logs, void* stream) {
+  if (!rankA || !lossA || !rankB || !lossB || !rankC || !lossC || !lmcl_sum || !lmcl_hits || !logs || B <= 0) return MSCL_E_ARG;
+  if (nA < 2 || nA > 3 || nC < 2 || nC > 3 || nA != nC) return MSCL_E_SHAPE;
+  hipLaunchKernelGGL(mscl_logs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rankA, lossA, rankB, lossB, rankC, lossC, lmcl_sum,
+                     lmcl_hits, B, nA, nC, w_intra, n_rows, logs);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- queue bookkeeping (int64, bit-exact)
 __global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue, int64_t* __restrict__ count,
                                                       const int64_t* __restrict__ ptr, const float* __restrict__ keys, int n,

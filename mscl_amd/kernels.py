@@ -328,6 +328,14 @@ def lmcl(rgb, flow, inv_T):
     return loss_sum, hits, drgb, dflow
 
 
+def step_logs(rankA, lossA, rankB, lossB, rankC, lossC, lmcl_sum, lmcl_hits, B, n_groups, w_intra, n_rows):
+    """the step's log vector (MSCLWithAug key order, last = total loss) in one launch"""
+    logs = torch.empty((23 if n_groups == 3 else 17,), dtype=torch.float32, device=lossA.device)
+    call('mscl_step_logs', ptr(rankA), ptr(lossA), ptr(rankB), ptr(lossB), ptr(rankC), ptr(lossC), ptr(lmcl_sum), ptr(lmcl_hits),
+         B, n_groups, n_groups, float(w_intra), float(n_rows), ptr(logs), stream_ptr())
+    return logs
+
+
 def ema_update(pk, pq, pk_bf16, m):
     call('mscl_ema_update', ptr(pk), ptr(pq), ptr(pk_bf16), pk.numel(), float(m), stream_ptr())
 

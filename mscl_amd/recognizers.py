@@ -36,6 +36,7 @@ LOG_KEYS = ('top1_acc', 'top5_acc', 'loss_cls', 'top1_acc_flow', 'top5_acc_flow'
             'top1_acc_mx', 'top5_acc_mx', 'loss_cls_mx', 'top1_acc_mx_r', 'top5_acc_mx_r', 'loss_cls_mx_r',
             'top1_acc_mx_aug', 'top5_acc_mx_aug', 'loss_cls_mx_aug', 'top1_acc_mx_r_aug', 'top5_acc_mx_r_aug',
             'loss_cls_mx_r_aug', 'loss_pos', 'top1_acc_pos', 'top5_acc_pos', 'loss')
+LOG_KEYS_NO_AUG_MX = tuple(k for k in LOG_KEYS if not k.endswith('_mx_aug') and not k.endswith('_mx_r_aug'))
 
 
 def momentum_at(iters, max_iters, m_base):
@@ -178,24 +179,10 @@ class _MSCLLossFn(torch.autograd.Function):
 
         def grp(v, i):
             return v[i * B:(i + 1) * B]
-        mean = lambda v: v.mean()
-        acc = lambda r, k: (r < k).float().mean()
-        e = OrderedDict()
-        e['top1_acc'], e['top5_acc'], e['loss_cls'] = acc(grp(rankA, 0), 1), acc(grp(rankA, 0), 5), mean(grp(lossA, 0))
-        e['top1_acc_flow'], e['top5_acc_flow'], e['loss_cls_flow'] = acc(rankB, 1), acc(rankB, 5), mean(lossB)
-        e['loss_cls_flow_aug'] = mean(grp(lossC, 0)) * w_intra
-        e['top1_acc_mx'], e['top5_acc_mx'], e['loss_cls_mx'] = acc(grp(rankC, 1), 1), acc(grp(rankC, 1), 5), mean(grp(lossC, 1))
-        e['top1_acc_mx_r'], e['top5_acc_mx_r'], e['loss_cls_mx_r'] = acc(grp(rankA, 1), 1), acc(grp(rankA, 1), 5), mean(grp(lossA, 1))
-        if use_aug_mx:
-            e['top1_acc_mx_aug'], e['top5_acc_mx_aug'], e['loss_cls_mx_aug'] = acc(grp(rankC, 2), 1), acc(grp(rankC, 2), 5), mean(grp(lossC, 2))
-            e['top1_acc_mx_r_aug'], e['top5_acc_mx_r_aug'], e['loss_cls_mx_r_aug'] = acc(grp(rankA, 2), 1), acc(grp(rankA, 2), 5), mean(grp(lossA, 2))
-        n_rows = float(B * t)
-        e['loss_pos'] = lsum[0] / n_rows
-        e['top1_acc_pos'], e['top5_acc_pos'] = hits[0].float() / n_rows, hits[1].float() / n_rows
-        total = sum(v for k_, v in e.items() if 'loss' in k_)            # base.py:297-298
-        e['loss'] = total
-        ctx.log_keys = tuple(e.keys())
-        logs = torch.stack([v.float() for v in e.values()])
+        # the 17 / 23 log entries (heads/moco_head.py:60-77 per group, base.py:297-298 total) in one launch
+        logs = K.step_logs(rankA, lossA, rankB, lossB, rankC, lossC, lsum, hits, B, 3 if use_aug_mx else 2, w_intra, float(B * t))
+        ctx.log_keys = LOG_KEYS if use_aug_mx else LOG_KEYS_NO_AUG_MX
+        total = logs[-1]
         # gradients w.r.t. the differentiable inputs (loss weights folded in by the row scales)
         dq_rgb = grp(dA, 0) + grp(dC, 1) + (grp(dC, 2) if use_aug_mx else 0)
         dq_fb = grp(dA, 1) + dB
