@@ -384,3 +384,41 @@ def test_flow_fra_visualize_vs_reference_golden(dev):
     d = (lv.cpu().int() - wl.int()).abs()
     assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 5e-3, (int(d.max()), float((d > 0).float().mean()))
     assert torch.equal(out[..., :3], (lv.float() / 255).to(torch.bfloat16)) and float(out[..., 3:].abs().max()) == 0.0
+
+
+def test_edge_cases_and_error_codes(dev):
+    """Edge cases the reference guards or that sit on kernel boundaries:
+      * enqueue exactly up to the end of the queue wraps the pointer to 0 (moco.py:423-440), and a batch that does not
+        divide K is refused like the reference's `assert self.K % batch_size == 0` (moco.py:432);
+      * a convolution whose position count is not a multiple of any tile (ragged M) and a 1-position map;
+      * argument errors come back as negative codes -> MsclError, never as a launch."""
+    from mscl_amd import kernels as K_, lib
+    from mscl_amd.recognizers import MoCoV2
+    Kq, dim, n = 32, 128, 8
+    queue = torch.zeros((dim, Kq), device=dev); count = torch.zeros(Kq, dtype=torch.long, device=dev)
+    ptr_ = torch.tensor([Kq - n], dtype=torch.long, device=dev)
+    keys = torch.nn.functional.normalize(torch.randn(n, dim, device=dev), dim=1)
+    K_.queue_enqueue(queue, count, ptr_, keys)
+    assert int(ptr_) == 0 and torch.equal(queue[:, Kq - n:], keys.T)
+    assert torch.equal(count.cpu(), torch.cat([torch.ones(Kq - n, dtype=torch.long), torch.ones(n, dtype=torch.long)]))
+    rec = MoCoV2(backbone=dict(type='resnet_flow.r2d_18'), neck=dict(type='BaseMoCo'), moco_head=dict(type='MoCoHead', basename='_flow',
+                 loss_cls=dict(type='CrossEntropyLoss_torch', ignore_index=-1)), dim_in=128, K=20, max_iters=10, mlp=True)
+    rec.queue, rec.count, rec.queue_ptr = torch.zeros((128, 20), device=dev), torch.zeros(20, dtype=torch.long, device=dev), \
+        torch.zeros(1, dtype=torch.long, device=dev)
+    with pytest.raises(AssertionError):
+        rec.dequeue_and_enqueue(keys)                        # 20 % 8 != 0
+    # ragged / tiny convolutions against the fp32 reference
+    for shape, Kc in (((1, 1, 5, 7, 64), 64), ((1, 1, 1, 1, 64), 64), ((3, 2, 9, 5, 16), 32)):
+        x = bf(rnd(shape, 21)); w = bf(rnd((Kc, 3, 3, 3, shape[-1]), 22, scale=0.05))
+        d = K_.conv_desc(shape, Kc, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        y = K_.conv3d_fwd(x.to(dev), w.to(dev), d)
+        close(y, _conv_ref(x.float(), w.float(), (1, 1, 1), (1, 1, 1)), BF16_TOL, f'ragged conv {shape}')
+    # error paths
+    with pytest.raises(lib.MsclError):
+        K_.conv3d_fwd(torch.zeros((1, 1, 4, 4, 12), dtype=torch.bfloat16, device=dev),
+                      torch.zeros((8, 3, 3, 3, 12), dtype=torch.bfloat16, device=dev),
+                      K_.conv_desc((1, 1, 4, 4, 12), 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)))          # C % 8 != 0
+    with pytest.raises(lib.MsclError):
+        K_.pack_input(torch.zeros((1, 3, 4, 4, 4)), None, None)                                     # CPU tensor
+    with pytest.raises(lib.MsclError):
+        lib.call('mscl_sumsq', None, None, 0, None, 0, None)
