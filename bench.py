@@ -36,6 +36,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=4)
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of one captured HIP graph per step')
+    p.add_argument('--stochastic-aug', action='store_true',
+                   help='variant (not the BASELINE.json workload): random flip / colour jitter / grayscale / blur per step')
     return p.parse_args()
 
 
@@ -84,6 +86,9 @@ def main():
     model = build_model(cfg.model)
     fill_module(model)
     model.materialize(dev).train()
+    if args.stochastic_aug:
+        model.aug_gpu.stochastic = True
+        model.aug_gpu.seed(1234 + rank)
     opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
     nbatch = 4
     batches = [synthetic_batch(BATCH, T_FRAMES, SIDE, SIDE, rank, s, device=dev) for s in range(nbatch)]
@@ -164,7 +169,9 @@ def main():
                                    'cross-modal InfoNCE, LMCL, backward, clip+SGD), mscl_r18 config with T=16',
                        'clip': f'{T_FRAMES}x{SIDE}x{SIDE}', 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
                        'parallelism': f'dp{world}', 'weights': 'closed-form fill, fp32 masters + bf16 shadows',
-                       'launch': 'one captured HIP graph per step' if graphed is not None else 'eager'},
+                       'launch': 'one captured HIP graph per step' if graphed is not None else 'eager',
+                       'aug': 'stochastic flip+jitter+grayscale+blur (variant)' if args.stochastic_aug
+                              else 'normalise only (BASELINE.json workload)'},
             'final_loss': loss,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64_kernel fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,

@@ -130,6 +130,19 @@ int mscl_flow_visualize(const float* uv, uint16_t* out, uint8_t* levels, int B, 
 int mscl_flow_fra_visualize(const float* uv, const int32_t* cid, float ratio_lo, float ratio_hi, int num_chunks,
                             uint16_t* out, uint8_t* levels, float* normed, double* scratch, int B, int T, int H, int W,
                             const uint8_t* flip_mask, void* stream);
+/* Colour augmentation of an RGB clip GIVEN its sampled parameters (the arithmetic of the kornia ops chained in
+ * common/ssl_aug_v2.py:31-43: ColorJitter(0.4,0.4,0.4,0.1) then RandomGrayscale; parameter sampling is the host's job).
+ * x, out (B,3,T,H,W) fp32 in [0,1]; params (B,16) fp32 on the device, per sample: [0] jitter on/off, [1..4] order of the
+ * four ops (0 brightness, 1 contrast, 2 saturation, 3 hue), [5] brightness factor f (x + f - 1, clamped), [6] contrast
+ * factor (x * f, clamped), [7] saturation factor (HSV s * f, clamped), [8] hue shift in radians, [9] grayscale on/off
+ * (0.299 R + 0.587 G + 0.114 B in all three channels), [10] Gaussian sigma for mscl_gauss_blur (0 = none). */
+int mscl_color_aug(const float* x, float* out, const float* params, int B, int T, int H, int W, void* stream);
+/* Separable ksize x ksize Gaussian blur with reflect border of every (H,W) frame of the samples whose params[b][10]
+ * (sigma) is > 0, a copy for the others: GaussianBlur of common/ssl_aug.py:163-171 (kornia GaussianBlur2d, taps
+ * exp(-d^2 / 2 sigma^2) normalised to sum 1).  x, tmp, out (B,frames,H,W) fp32; out may alias x, tmp may not.
+ * ksize odd, <= 33, H and W > ksize / 2. */
+int mscl_gauss_blur(const float* x, float* tmp, float* out, const float* params, int ksize, int B, int frames, int H, int W,
+                    void* stream);
 /* out = relu?(a + b + c) elementwise bf16 (b, c optional) */
 int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, int relu, void* stream);
 /* din = dout * (out > 0) */

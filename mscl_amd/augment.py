@@ -5,9 +5,20 @@ Implemented: the deterministic part -- ImageNet normalisation of the RGB views (
 uv -> colour-wheel FlowVisualizer with its uint8 floor (ssl_aug.py:87-136) for 2-channel flow clips, and the
 horizontal flip GIVEN its per-sample Bernoulli mask (ssl_aug_v2.py:107-118: RGB clips and the visualised flow image
 are mirrored along W) -- all fused into the NCTHW -> NDHWC packing kernels.  3-channel flow clips are taken as already
-visualised and pass through un-normalised (normalize_flow=False -> Identity, ssl_aug_v2.py:88).  The stochastic kornia
-ops (drawing the flip mask, colour jitter, grayscale, blur) are not implemented; asking for them raises.
+visualised and pass through un-normalised (normalize_flow=False -> Identity, ssl_aug_v2.py:88).
+
+stochastic=True adds the random part of the pipeline (ssl_aug_v2.py:31-43, 84, 107-110): per step and view the host
+draws, from the module's own seeded generator, a flip mask (p 0.5 per clip), ColorJitter(0.4, 0.4, 0.4, 0.1) with p 0.8,
+grayscale with p 0.2 and an 11-tap Gaussian blur with p 0.5 (one sigma in [0.1, 2] per call, ssl_aug.py:163-171); the
+decisions are per CLIP (the reference's toVideoAug makes them consistent over time, ssl_aug.py:31-53, 66-70) and so
+are the jitter factors; the four jitter ops run in one random order per call.  The arithmetic runs in the HIP kernels of
+csrc/color_aug.hip from (B,16) parameter rows.  kornia's own random streams cannot be reproduced (it is not available
+and unpinned), so parity for this part is on the arithmetic given the parameters, not on the draws.
 """
+import math
+
+import torch
+
 from . import kernels as K
 from .registry import SSL_AUGS
 
@@ -19,11 +30,49 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 class SyncMoCoAugmentV5:
     def __init__(self, crop_size, flip_transform=dict(p=0.5, same_on_batch=False), sync_level='batch', t=None,
                  flow_suffix='flow_imgs', img_width=112, visualize=True, weak_aug=(False, False), normalize_flow=False,
-                 stochastic=False):
-        if stochastic:
-            raise NotImplementedError('stochastic flip/jitter/grayscale/blur (kornia in the reference) is a "next" row')
+                 stochastic=False, seed=0):
+        if isinstance(sync_level, str):
+            sync_level = (sync_level, sync_level)
+        assert all(v in ('batch', 'params') for v in sync_level)
         self.crop_size, self.t, self.flow_suffix = crop_size, t, flow_suffix
         self.visualize, self.normalize_flow = visualize, normalize_flow
+        self.stochastic = bool(stochastic)
+        self.flip_p = float(flip_transform['p']) if flip_transform else 0.0
+        self.weak_aug = tuple(weak_aug)
+        self.blur_ksize = int(0.1 * crop_size) // 2 * 2 + 1          # ssl_aug.py:166
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def seed(self, seed):
+        self._gen.manual_seed(seed)
+
+    def _uniform(self, n, lo, hi):
+        return lo + (hi - lo) * torch.rand(n, generator=self._gen)
+
+    def draw(self, B):
+        """one step's random decisions for the query and key views, as host tensors:
+        dict(flip_mask=[(B,) uint8 x2], aug_params=[(B,16) fp32 x2]) -- the keys train_step() looks for."""
+        flips, rows = [], []
+        for view in range(2):
+            flips.append((torch.rand(B, generator=self._gen) < self.flip_p).to(torch.uint8))
+            P = torch.zeros(B, K.AUG_PARAMS)
+            if not self.weak_aug[view]:
+                P[:, 0] = (torch.rand(B, generator=self._gen) < 0.8).float()
+                P[:, 1:5] = torch.randperm(4, generator=self._gen).float()
+                P[:, 5] = self._uniform(B, 0.6, 1.4)
+                P[:, 6] = self._uniform(B, 0.6, 1.4)
+                P[:, 7] = self._uniform(B, 0.6, 1.4)
+                P[:, 8] = self._uniform(B, -0.1, 0.1) * (2.0 * math.pi)
+                P[:, 9] = (torch.rand(B, generator=self._gen) < 0.2).float()
+                sigma = float(self._uniform(1, 0.1, 2.0))
+                P[:, 10] = (torch.rand(B, generator=self._gen) < 0.5).float() * sigma
+            rows.append(P)
+        return dict(flip_mask=flips, aug_params=rows)
+
+    def color(self, x, params, view):
+        """jitter / grayscale / blur of an RGB view given its parameter rows (None: nothing to do)"""
+        if params is None or self.weak_aug[view]:
+            return x
+        return K.color_aug(x.contiguous(), params, self.blur_ksize)
 
     def pack_rgb(self, x, flip=None):
         return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, flip=flip)
@@ -42,8 +91,13 @@ class SyncMoCoAugmentV5:
 
 @SSL_AUGS.register_module()
 class IdentityAug:
+    stochastic = False
+
     def __init__(self, **kwargs):
         pass
+
+    def color(self, x, params, view):
+        return x
 
     def __call__(self, clips):
         return clips

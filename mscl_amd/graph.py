@@ -13,6 +13,7 @@ class GraphedStep:
         self.model, self.opt = model, optimizer
         model.shuffle_mode = 'gather'            # all-to-all split sizes change per step and cannot be baked into a graph
         dev = model.arena.device
+        example_batch = model.with_aug_draw(example_batch)      # stochastic augmenter: static mask / parameter buffers
         self.static = {k: [t.to(dev).clone() for t in v] for k, v in example_batch.items()}
         self.B = self.static[model.im_key][0].shape[0]
         cur = torch.cuda.current_stream()
@@ -29,8 +30,10 @@ class GraphedStep:
         fk = model.flow_key[0]
         model._pre_step_host(self.B)
         with torch.cuda.graph(self.graph):
+            flips = self.static.get('flip_mask', (None, None))
+            rows = self.static.get('aug_params', (None, None))
             loss, logs = model._device_step(self.static[model.im_key][0], self.static[model.im_key][1],
-                                            self.static[fk][0], self.static[fk][1])
+                                            self.static[fk][0], self.static[fk][1], flips[0], flips[1], rows[0], rows[1])
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
@@ -56,6 +59,7 @@ class GraphedStep:
 
     def step(self, batch):
         """one training step on `batch` (device tensors); returns (loss, logs) as static device tensors."""
+        batch = self.model.with_aug_draw(batch)
         for k, v in self.static.items():
             for dst, src in zip(v, batch[k]):
                 if dst.data_ptr() != src.data_ptr():

@@ -174,6 +174,25 @@ def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None):
     return out
 
 
+AUG_PARAMS = 16          # floats per sample in the colour-augmentation parameter rows (include/mscl_hip.h)
+
+
+def color_aug(x, params, blur_ksize=0):
+    """colour jitter / grayscale (and, with blur_ksize > 0, the Gaussian blur) of a (B,3,T,H,W) fp32 clip in [0,1],
+    given per-sample parameter rows (B,16) on the device (ssl_aug_v2.py:31-43); returns a new fp32 clip."""
+    B, C, T, H, W = x.shape
+    if C != 3 or not x.is_contiguous() or x.dtype != torch.float32:
+        raise lib.MsclError('color_aug needs a contiguous fp32 (B,3,T,H,W) clip')
+    if tuple(params.shape) != (B, AUG_PARAMS) or params.dtype != torch.float32 or not params.is_contiguous():
+        raise lib.MsclError(f'color_aug needs ({B},{AUG_PARAMS}) fp32 parameter rows')
+    out = torch.empty_like(x)
+    call('mscl_color_aug', ptr(x), ptr(out), ptr(params), B, T, H, W, stream_ptr())
+    if blur_ksize:
+        tmp = torch.empty_like(x)
+        call('mscl_gauss_blur', ptr(out), ptr(tmp), ptr(out), ptr(params), blur_ksize, B, 3 * T, H, W, stream_ptr())
+    return out
+
+
 def flow_visualize(uv, t_off=0, T=None, flip=None, want_levels=False):
     """(B,2,Ttot,H,W) fp32 optical flow -> colour-wheel image (B,T,H,W,8) bf16 (ssl_aug.py:87-136);
     with want_levels also the quantised bytes (B,T,H,W,3)."""

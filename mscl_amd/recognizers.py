@@ -369,11 +369,27 @@ class MSCLWithAug(nn.Module):
         for item in self.aux_info:
             assert item in data_batch
             aux[item] = data_batch[item]
+        data_batch = self.with_aug_draw(data_batch)
         if 'flip_mask' in data_batch:           # [mask_q, mask_k], uint8 (B,): the Bernoulli draw of ssl_aug_v2.py:107-110
             aux['flip_q'], aux['flip_k'] = data_batch['flip_mask'][0], data_batch['flip_mask'][1]
+        if 'aug_params' in data_batch:          # [rows_q, rows_k], fp32 (B,16): jitter / grayscale / blur parameters
+            aux['color_q'], aux['color_k'] = data_batch['aug_params'][0], data_batch['aug_params'][1]
         loss, logs = self.forward_train(im_q, im_k, aux)
         log_vars = self._parse_logs(logs, sync_logs)
         return dict(loss=loss, log_vars=log_vars, num_samples=im_q.shape[0])
+
+    def with_aug_draw(self, data_batch):
+        """a stochastic augmenter draws this step's flip masks and colour parameters unless the batch brings its own"""
+        aug = self.aug_gpu
+        if not getattr(aug, 'stochastic', False) or 'aug_params' in data_batch:
+            return data_batch
+        dev = data_batch[self.im_key][0].device
+        drawn = aug.draw(data_batch[self.im_key][0].shape[0])
+        out = dict(data_batch)
+        for k, v in drawn.items():
+            if k not in out:
+                out[k] = [t.to(dev, non_blocking=True) for t in v]
+        return out
 
     def forward(self, im_q, im_k, aux_info, return_loss=True, **kwargs):
         if not return_loss:
@@ -399,7 +415,8 @@ class MSCLWithAug(nn.Module):
         fk = self.flow_key[0]
         self._pre_step_host(im_q.shape[0])
         loss, logs = self._device_step(im_q, im_k, aux_info[f'{fk}_q'], aux_info[f'{fk}_k'],
-                                       aux_info.get('flip_q'), aux_info.get('flip_k'))
+                                       aux_info.get('flip_q'), aux_info.get('flip_k'),
+                                       aux_info.get('color_q'), aux_info.get('color_k'))
         self._post_step_host()
         return loss, logs
 
@@ -476,7 +493,7 @@ class MSCLWithAug(nn.Module):
             return parallel.exchange_rows(k, ix[8 + 4 * slot], ix[9 + 4 * slot], p.recv_splits, p.send_splits)
         return parallel.all_gather_cat(k).index_select(0, self._idx_dev[3 + slot])
 
-    def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None):
+    def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None, color_q=None, color_k=None):
         rec, recf = self.recognizer, self.recognizer_flow
         T2 = flow_q.shape[2]
         if T2 % 2:
@@ -526,12 +543,13 @@ class MSCLWithAug(nn.Module):
         if side_k is not main:
             side_k.wait_stream(main)
         with torch.cuda.stream(side_k):
+            im_k = aug.color(im_k, color_k, 1)               # on the owner, before the shuffle (mscl.py:227 precedes moco.py:532)
             x_k = aug.pack_rgb(self._shuffle(im_k, 0), self._shuffle_mask(flip_k, 0))
             rec.momentum_update(sc[0:1])
             k_rgb, _ = rec.encode_k(x_k)
             k_rgb = self._unshuffle(k_rgb, 0)
         # -- RGB query branch
-        x_q = aug.pack_rgb(im_q, flip_q)
+        x_q = aug.pack_rgb(aug.color(im_q, color_q, 0), flip_q)
         q_rgb, maps_rgb = rec.encode_q(x_q)
         if side_k is not main:
             main.wait_stream(side_k)

@@ -174,3 +174,29 @@ def test_reference_config_file_loads_unchanged():
     norm = lambda o: json.loads(json.dumps(o, default=lambda x: dict(x) if hasattr(x, 'items') else list(x)))
     for key in ('model', 'optimizer', 'optimizer_config', 'lr_config', 'total_epochs'):
         assert norm(cfg[key]) == norm(mine[key]), key
+
+
+def test_stochastic_aug_draws():
+    """SyncMoCoAugmentV5(stochastic=True): draws are reproducible from the seed and stay inside the ranges of
+    ssl_aug_v2.py:31-43 (jitter 0.4/0.4/0.4/0.1, sigma in [0.1, 2], one op order and one sigma per call)."""
+    import math
+    from mscl_amd.augment import SyncMoCoAugmentV5
+    a = SyncMoCoAugmentV5(crop_size=112, t=(16, 16), stochastic=True, seed=5)
+    assert a.blur_ksize == 11
+    d1 = a.draw(64)
+    a.seed(5)
+    d2 = a.draw(64)
+    for k in d1:
+        for x, y in zip(d1[k], d2[k]):
+            assert torch.equal(x, y)
+    for P, m in zip(d1['aug_params'], d1['flip_mask']):
+        assert P.shape == (64, 16) and m.dtype == torch.uint8 and 0 < int(m.sum()) < 64
+        assert set(P[:, 0].tolist()) <= {0.0, 1.0} and 30 < P[:, 0].sum() < 62
+        assert sorted(P[0, 1:5].tolist()) == [0, 1, 2, 3] and bool((P[:, 1:5] == P[0, 1:5]).all())
+        for col in (5, 6, 7):
+            assert 0.6 <= float(P[:, col].min()) and float(P[:, col].max()) <= 1.4
+        assert float(P[:, 8].abs().max()) <= 0.1 * 2 * math.pi + 1e-6
+        sig = P[:, 10][P[:, 10] > 0]
+        assert len(sig) > 10 and 0.1 <= float(sig[0]) <= 2.0 and bool((sig == sig[0]).all())
+    weak = SyncMoCoAugmentV5(crop_size=112, t=(16, 16), stochastic=True, weak_aug=(True, False)).draw(4)
+    assert float(weak['aug_params'][0].abs().sum()) == 0 and float(weak['aug_params'][1].abs().sum()) > 0

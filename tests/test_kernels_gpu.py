@@ -422,3 +422,41 @@ def test_edge_cases_and_error_codes(dev):
         K_.pack_input(torch.zeros((1, 3, 4, 4, 4)), None, None)                                     # CPU tensor
     with pytest.raises(lib.MsclError):
         lib.call('mscl_sumsq', None, None, 0, None, 0, None)
+
+
+def test_color_aug_and_blur_match_oracle(dev):
+    """csrc/color_aug.hip vs oracle/coloraug.py (the restated kornia arithmetic of ssl_aug_v2.py:31-43): every jitter op
+    alone and chained in several orders, grayscale, blur at small / large sigma, samples left untouched."""
+    from mscl_amd import kernels as K
+    from oracle import coloraug
+    g = torch.Generator().manual_seed(17)
+    B, T, H, W = 8, 3, 20, 27
+    x = torch.rand((B, 3, T, H, W), generator=g)
+    x[0, :, 0, :4, :4] = 0.5                          # grey pixels: zero saturation, delta == 0 branch
+    x[1, 0, 0, :4, :4] = x[1, 1, 0, :4, :4]           # ties between channel maxima
+    P = torch.zeros(B, K.AUG_PARAMS)
+    orders = [[0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3], [3, 0, 1, 2], [2, 3, 0, 1], [0, 2, 1, 3]]
+    P[:, 1:5] = torch.tensor(orders, dtype=torch.float32)
+    P[:, 0] = torch.tensor([1, 1, 1, 1, 0, 1, 1, 1.])
+    P[:, 5] = torch.tensor([0.6, 1.4, 1.0, 1.1, 1.3, 0.9, 0.7, 1.2])
+    P[:, 6] = torch.tensor([1.4, 0.6, 1.0, 0.8, 1.3, 1.1, 1.2, 0.9])
+    P[:, 7] = torch.tensor([0.6, 1.4, 1.3, 1.0, 0.7, 0.8, 1.1, 1.2])
+    P[:, 8] = torch.tensor([-0.1, 0.1, 0.05, -0.03, 0.1, 0.0, 0.08, -0.07]) * 6.283185307179586
+    P[:, 9] = torch.tensor([0, 0, 1, 0, 0, 1, 0, 0.])
+    P[:, 10] = torch.tensor([0, 0.1, 2.0, 0, 0.7, 0, 1.3, 0])
+    for ks in (0, 11, 5):
+        got = K.color_aug(x.to(dev), P.to(dev), ks).cpu()
+        ref = coloraug.color_aug(x, P, ks)
+        assert (got - ref).abs().max().item() < 3e-5, ks
+    untouched = K.color_aug(x.to(dev), torch.zeros(B, K.AUG_PARAMS, device=dev), 11).cpu()
+    assert torch.equal(untouched, x)
+    # argument checks: blur wider than the frame allows, even tap count, aliased scratch
+    from mscl_amd import lib
+    xs = torch.rand((1, 3, 1, 4, 4), device=dev)
+    with pytest.raises(lib.MsclError):
+        K.color_aug(xs, torch.zeros(1, K.AUG_PARAMS, device=dev), 11)
+    with pytest.raises(lib.MsclError):
+        K.color_aug(xs, torch.zeros(1, K.AUG_PARAMS, device=dev), 4)
+    with pytest.raises(lib.MsclError):
+        K.color_aug(xs, torch.zeros(2, K.AUG_PARAMS, device=dev), 0)
+    assert K.color_aug(torch.empty((0, 3, 2, 8, 8), device=dev), torch.zeros(0, K.AUG_PARAMS, device=dev), 3).shape[0] == 0

@@ -333,6 +333,57 @@ def test_uv_flow_and_flip_inputs(dev):
             loss_close(losses['uv+mask'][k], v, k)      # (+-1 colour level on <= 0.5 % of the pixels + fp32-atomic order noise)
 
 
+def test_color_aug_inputs_and_stochastic_mode(dev):
+    """SURVEY section 8(f)#1, random part: a step fed per-sample jitter / grayscale / blur parameter rows equals the step
+    on clips augmented by the CPU restatement (oracle/coloraug.py); stochastic=True draws masks and rows itself,
+    reproducibly from its seed, and trains in eager and graph-replay mode."""
+    from mscl_amd import ClipSGD
+    from mscl_amd.graph import GraphedStep
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import coloraug
+    B, T, H, Kq = 2, 8, 32, 64
+    batch = synthetic_batch(B, T, H, H, 0, 0)
+    model, cfg = build(T, Kq, dev)
+    model.aug_gpu.stochastic = True
+    model.aug_gpu.seed(11)
+    drawn = model.aug_gpu.draw(B)
+    rows = drawn['aug_params']
+    rows[0][:, 0] = 1; rows[1][0, 9] = 1; rows[0][1, 10] = 1.1; rows[1][:, 10] = 0.6      # make every op run somewhere
+    ks = model.aug_gpu.blur_ksize
+    assert ks == 11                                 # the config's crop_size 112 -> int(11.2) // 2 * 2 + 1 (ssl_aug.py:166)
+    variants = {
+        'rows': dict(batch, aug_params=rows, flip_mask=drawn['flip_mask']),
+        'host': dict(batch, imgs=[coloraug.color_aug(x, r, ks) for x, r in zip(batch['imgs'], rows)],
+                     flip_mask=drawn['flip_mask'], aug_params=[torch.zeros_like(r) for r in rows]),
+    }
+    losses = {}
+    for name, b in variants.items():
+        m, _ = build(T, Kq, dev)
+        losses[name] = m.train_step({k: [t.to(dev) for t in v] for k, v in b.items()})['log_vars']
+    for k, v in losses['host'].items():
+        if 'loss' in k:
+            loss_close(losses['rows'][k], v, k)
+    # the module's own draws: same seed -> same step; and they differ from the un-augmented step
+    outs = []
+    for seed in (3, 3, 4):
+        m, _ = build(T, Kq, dev)
+        m.aug_gpu.stochastic = True
+        m.aug_gpu.seed(seed)
+        outs.append(m.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})['log_vars']['loss'])
+    assert outs[0] == outs[1] or abs(outs[0] - outs[1]) < 2e-3 * abs(outs[0])
+    assert abs(outs[0] - outs[2]) > 1e-4
+    # graph replay with a stochastic augmenter: masks and rows are static buffers refreshed per step
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    dbatch = {k: [t.to(dev) for t in v] for k, v in batch.items()}
+    gs = GraphedStep(model, opt, dbatch, warmup=1)
+    seen = set()
+    for _ in range(3):
+        loss, _ = gs.step(dbatch)
+        assert torch.isfinite(loss).item()
+        seen.add(tuple(gs.static['aug_params'][0].flatten().tolist()))
+    assert len(seen) == 3
+
+
 def test_full_size_step_properties(dev):
     """BASELINE.json's configuration (B=8, T=16, 112x112, K=65536) is too large for the CPU oracle inside a test, so the
     full-size step is checked through identities that hold at any size:

@@ -110,3 +110,28 @@ def test_fra_oracle_vs_reference_golden():
     for b in range(g['uv'].shape[0]):
         out = flowaug.fra([g['uv'][b, t] for t in range(g['uv'].shape[1])], int(g['cid'][b]))
         assert np.array_equal(np.stack(out).astype(np.float64), g['normed'][b])
+
+
+def test_coloraug_restatement_properties():
+    """oracle/coloraug.py has no reference vector to pin it (kornia is absent and unpinned: 'parity unpinned'); what can be
+    checked are the identities the colour model guarantees: HSV round trip, unit factors are the identity, hue shift by a
+    full turn is the identity, grayscale is channel-constant with the 601 weights, blur preserves constants and mass."""
+    import math
+    from oracle import coloraug as c
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand((2, 3, 2, 9, 10), generator=g)
+    h, s, v = c.rgb_to_hsv(x[0].permute(1, 0, 2, 3))
+    assert (c.hsv_to_rgb(h, s, v) - x[0].permute(1, 0, 2, 3)).abs().max() < 5e-6
+    assert float(h.min()) >= 0 and float(h.max()) < 2 * math.pi + 1e-6
+    P = torch.zeros(2, 16)
+    P[:, 0] = 1; P[:, 1:5] = torch.tensor([0., 1., 2., 3.]); P[:, 5:8] = 1.0
+    assert (c.color_aug(x, P) - x).abs().max() < 5e-6
+    P[:, 8] = 2 * math.pi
+    assert (c.color_aug(x, P) - x).abs().max() < 5e-6
+    P[:, 0] = 0; P[:, 9] = 1
+    y = c.color_aug(x, P)
+    assert torch.equal(y[:, 0], y[:, 1]) and torch.equal(y[:, 1], y[:, 2])
+    assert (y[:, 0] - (0.299 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2])).abs().max() < 1e-6
+    ones = torch.ones(1, 3, 12, 12)
+    assert (c.gaussian_blur(ones, 11, 1.7) - 1).abs().max() < 1e-6
+    assert abs(float(c.gaussian_taps(11, 0.1)[5]) - 1.0) < 1e-6           # sigma 0.1: a delta
