@@ -73,9 +73,14 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    forced = world == 1 and os.environ.get('MSCL_FORCE_DIST') == '1'    # diagnostic: run every collective on a 1-rank RCCL group
+    if world > 1 or forced:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if forced:
+            os.environ.setdefault('MASTER_PORT', '29531')
+            dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from mscl_amd import ClipSGD, Config, build_model, kernels
     from mscl_amd.fill import fill_module
@@ -135,12 +140,12 @@ def main():
     # (one stream for these two steps: an event pair on one stream would otherwise also time the other streams' kernels
     #  sharing the CUs -- 154 us instead of 131 us for this launch; the in-graph average is in profiles/*kernel_stats*)
     kernels.PROFILE_CONV = dict(sig=(BATCH, T_FRAMES, SIDE // 2, SIDE // 2, 64, 64, 3), events=[])
-    streams_were = model.two_streams
-    model.two_streams = False
+    streams_were, keyg_were = model.two_streams, model.key_graphs
+    model.two_streams = model.key_graphs = False         # plain launches on one stream: events inside a capture are not timeable
     for i in range(2):
         eager_step(i)
     torch.cuda.synchronize()
-    model.two_streams = streams_were
+    model.two_streams, model.key_graphs = streams_were, keyg_were
     prof = kernels.PROFILE_CONV
     kernels.PROFILE_CONV = None
     tmax = torch.tensor([dt], device=dev)
@@ -168,8 +173,9 @@ def main():
             'config': {'workload': 'full MSCLWithAug step (dual-stream R3D-18 + r2d_18, MoCo queues K=65536, '
                                    'cross-modal InfoNCE, LMCL, backward, clip+SGD), mscl_r18 config with T=16',
                        'clip': f'{T_FRAMES}x{SIDE}x{SIDE}', 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
-                       'parallelism': f'dp{world}', 'weights': 'closed-form fill, fp32 masters + bf16 shadows',
-                       'launch': 'one captured HIP graph per step' if graphed is not None else 'eager',
+                       'parallelism': f'dp{world}' + (' (collectives forced on a 1-rank RCCL group)' if forced else ''), 'weights': 'closed-form fill, fp32 masters + bf16 shadows',
+                       'launch': 'one captured HIP graph per step' if graphed is not None
+                                 else 'eager launches, key branches replayed from HIP sub-graphs',
                        'aug': 'stochastic flip+jitter+grayscale+blur (variant)' if args.stochastic_aug
                               else 'normalise only (BASELINE.json workload)'},
             'final_loss': loss,
@@ -182,7 +188,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -126,6 +126,18 @@ def exchange_rows(x, send_order, recv_order, send_splits, recv_splits):
     return out.index_select(0, recv_order)
 
 
+@torch.no_grad()
+def gather_unshuffle(keys, inv):
+    """The way back of shuffle-BN for several key blocks at once (moco.py:174-191 + the gather of moco.py:426).
+    keys: list of (B, dim) blocks this rank ENCODED (rows in shuffled order); inv: (len(keys), W*B) int64, inv[i] =
+    argsort of block i's permutation.  One all-gather moves all blocks; returns (full, own): full[i] = every replica's
+    keys of block i in global sample order (what the queue enqueues), own[i] = this rank's B rows of it."""
+    B, dim, r = keys[0].shape[0], keys[0].shape[1], rank()
+    allk = all_gather_cat(torch.cat(keys, dim=1))
+    full = [allk[:, i * dim:(i + 1) * dim].index_select(0, inv[i]) for i in range(len(keys))]
+    return full, [f[r * B:(r + 1) * B] for f in full]
+
+
 def bucket_plan(total, bucket_elems):
     """[(start, end)] covering [0, total) in buckets of at most bucket_elems (last one short)."""
     out, a = [], 0

@@ -124,12 +124,60 @@ class MoCoV2(nn.Module):
         return mlp_head(self.mlp_k, emb), maps
 
     @torch.no_grad()
-    def dequeue_and_enqueue(self, keys):
-        """ref: moco.py:423-440 (keys are all-gathered first; bookkeeping is bit-exact int64 on device)."""
-        keys = parallel.all_gather_cat(keys)
+    def dequeue_and_enqueue(self, keys, gathered=None):
+        """ref: moco.py:423-440 (keys are all-gathered first; bookkeeping is bit-exact int64 on device).
+        `gathered`: the keys of all replicas in global sample order, when the caller already holds them."""
+        keys = gathered if gathered is not None else parallel.all_gather_cat(keys)
         if self.K % keys.shape[0] != 0:
             raise AssertionError('K % batch_size == 0 (moco.py:432)')
         K.queue_enqueue(self.queue, self.count, self.queue_ptr, keys.contiguous())
+
+
+class KeyGraph:
+    """EMA update + key-encoder forward of one call site as a replayable HIP graph.
+
+    The key branches carry no gradient and contain no collective (the shuffle-BN exchanges sit before and after them),
+    so they can be captured on their own even when the step as a whole is launched eagerly -- which is how world
+    size > 1 runs (RCCL inside one whole-step graph was only validated on a one-GPU box).  That
+    takes ~330 of the ~900 kernel launches per step off the host, which is what bounds the eager step.
+    The first two calls run eagerly (lazy plans, first-use allocations), the third captures and replays.
+    BatchNorm statistics scratch comes from a private pre-zeroed pool that the graph clears itself."""
+
+    def __init__(self, warmup=2):
+        self.graph, self.shape, self.calls, self.warmup = None, None, 0, warmup
+        self.pool = K.ZeroPool()
+
+    def _body(self, rec, x, m_dev):
+        rec.momentum_update(m_dev)
+        return rec.encode_k(x)[0]
+
+    def run(self, rec, x, m_dev):
+        if torch.cuda.is_current_stream_capturing():        # inside a whole-step capture: stay part of that graph
+            return self._body(rec, x, m_dev)
+        if self.graph is not None and self.shape == tuple(x.shape):
+            self.static_in.copy_(x)
+            self.graph.replay()
+            return self.out
+        self.calls += 1
+        if self.calls <= self.warmup:
+            return self._body(rec, x, m_dev)
+        self.graph, self.shape = None, tuple(x.shape)
+        self.static_in = x.clone()
+        stream = torch.cuda.current_stream()
+        graph = torch.cuda.CUDAGraph()
+        shared = K.ZEROS
+        self.pool.reset(x.device, size=2 << 20)
+        try:
+            K.ZEROS = self.pool
+            with torch.cuda.graph(graph, stream=stream if stream != torch.cuda.default_stream() else None,
+                                  capture_error_mode='thread_local'):      # other threads (RCCL watchdog) keep running
+                self.pool.buf.zero_()
+                self.out = self._body(rec, self.static_in, m_dev)
+        finally:
+            K.ZEROS = shared
+        self.graph = graph
+        graph.replay()
+        return self.out
 
 
 class _MSCLLossFn(torch.autograd.Function):
@@ -162,15 +210,16 @@ class _MSCLLossFn(torch.autograd.Function):
         lossA, rankA, dA = run(rec, QA, k_rgb.repeat(len(rowsA), 1), ones.repeat(len(rowsA)))
         # pass B: flow queue before enqueue -> loss_cls_flow
         lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
-        recf.dequeue_and_enqueue(k_fb)                                   # base pass: update_queue=True (mscl.py:239)
+        kg = model._kglobal
+        recf.dequeue_and_enqueue(k_fb, kg.get('fb'))                     # base pass: update_queue=True (mscl.py:239)
         # pass C: flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug
         rowsC = [q_fa, q_rgb] + ([q_rgb] if use_aug_mx else [])
         keysC = [k_fa, k_fb] + ([k_fa] if use_aug_mx else [])
         scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
         lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC)
         if model.update_aug_flow:
-            recf.dequeue_and_enqueue(k_fa)
-        rec.dequeue_and_enqueue(k_rgb)
+            recf.dequeue_and_enqueue(k_fa, kg.get('fa'))
+        rec.dequeue_and_enqueue(k_rgb, kg.get('rgb'))
         # LMCL (local_cl_head.py:57-73): RGB frame-slot features vs [base flow | rotated flow] frames
         t = p_rgb.shape[0] // B
         C = p_rgb.shape[1]
@@ -226,6 +275,8 @@ class MSCLWithAug(nn.Module):
         self.shuffle_mode = os.environ.get('MSCL_SHUFFLE', 'a2a')      # 'a2a' | 'gather' (shuffle-BN exchange, world size > 1)
         self._a2a = False
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
+        self.key_graphs = os.environ.get('MSCL_KEY_GRAPHS', '1') == '1'          # key branches as sub-graphs in eager steps
+        self._key_graph = [KeyGraph(), KeyGraph(), KeyGraph()]                  # RGB, flow base, flow rotated
         self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0') == '1'     # measured 13 % slower: two MFMA-heavy kernels thrash     # MSCL_STREAMS=1: everything on the current stream
         self._side = None
 
@@ -432,6 +483,8 @@ class MSCLWithAug(nn.Module):
             self._scal_dev = torch.zeros(4, dtype=torch.float32, device=dev)
             self._idx_host = torch.zeros((18, B), dtype=torch.long).pin_memory()
             self._idx_dev = torch.zeros((18, B), dtype=torch.long, device=dev)
+            self._inv_host = torch.zeros((3, bg), dtype=torch.long).pin_memory()      # argsort(perm): gathered keys -> global order
+            self._inv_dev = torch.zeros((3, bg), dtype=torch.long, device=dev)
         # all-to-all split sizes change every step, so a captured graph (graph.py) switches to the all-gather formulation
         self._a2a = (not parallel.single()) and self.shuffle_mode == 'a2a'
         rec.m = momentum_at(rec.iters, rec.max_iters, rec.m_base)
@@ -443,12 +496,12 @@ class MSCLWithAug(nn.Module):
             self._plans = [None] * 3
             for slot in range(3):
                 perm = parallel.shuffle_perm(W * B, self._step, slot)
+                self._inv_host[slot] = torch.argsort(perm)
                 if self._a2a:                   # two all-to-alls move B rows per rank instead of gathering W * B
                     plan = self._plans[slot] = parallel.ShufflePlan(W, B, r, perm)
                     self._idx_host[6 + 4 * slot:10 + 4 * slot] = plan.index_rows()
                 else:
                     self._idx_host[slot] = perm.view(W, B)[r]
-                    self._idx_host[3 + slot] = torch.argsort(perm).view(W, B)[r]
         self._bg = bg
 
     def _post_step_host(self):
@@ -461,9 +514,69 @@ class MSCLWithAug(nn.Module):
 
     def _side_stream(self, i=0):
         if self._side is None:
-            prio = int(os.environ.get('MSCL_SIDE_PRIORITY', '0'))      # HIP: larger = lower priority than the main chain
-            self._side = [torch.cuda.Stream(device=self.arena.device, priority=prio) for _ in range(3)]
+            self._side = self._pick_streams(3)
         return self._side[i]
+
+    def _pick_streams(self, n):
+        """n side streams that really run next to the current stream.  HIP multiplexes streams onto a few hardware
+        queues (4 by default) in creation order, and two streams that land on one queue serialise: with a process group
+        alive (its own stream plus RCCL's) a freshly created side stream aliased the main stream and the three-chain
+        overlap was gone (13.2 instead of 9.4 ms per step, rocprofv3 kernel trace: both streams on queue 4).  So:
+        create a few candidates and keep those that a spin kernel shows to overlap with everything chosen so far."""
+        import time
+        dev = self.arena.device
+        prio = int(os.environ.get('MSCL_SIDE_PRIORITY', '0'))          # HIP: larger = lower priority than the main chain
+        cand = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n if os.environ.get('MSCL_STREAM_PROBE') == '0' else 12)]
+        if len(cand) == n or torch.cuda.is_current_stream_capturing():
+            return cand[:n]
+        main = torch.cuda.current_stream()
+
+        def spin(streams, cycles):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        cycles = 200000
+        spin([main] + cand, 1000)                                      # first use of a stream may set up its hardware queue
+        spin([main], cycles)
+        t = spin([main], cycles)
+        cycles = int(cycles * max(1.0, 1.5e-3 / max(t, 1e-5)))         # ~1.5 ms per spin: far above launch latency
+        one = min(spin([main], cycles) for _ in range(2))
+        chosen = []                                                    # one representative per hardware queue other than main's
+        for c in cand:
+            if spin([main] + chosen + [c], cycles) < 1.4 * one:
+                chosen.append(c)
+        comm_free = None
+        if not parallel.single() and dist.get_backend() == 'nccl' and len(chosen) > 1 and os.environ.get('MSCL_STREAM_PROBE') != 'nocomm':
+            # the communicator's stream sits on one of the queues too: a side stream sharing it would stall behind every
+            # gradient bucket.  Same test, with a large all-reduce (issued from the idle main stream) as the other party.
+            buf = torch.zeros(48 << 20, device=dev)
+
+            def comm(streams, cyc):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        torch.cuda._sleep(cyc)
+                dist.all_reduce(buf)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            comm([], 0)
+            t_c = min(comm([], 0) for _ in range(2))
+            cyc = max(1000, int(cycles * t_c / one))                    # spin about as long as the all-reduce
+            t_s = min(spin([main], cyc) for _ in range(2))
+            free = [c for c in chosen if min(comm([c], cyc) for _ in range(2)) < max(t_c, t_s) + 0.5 * min(t_c, t_s)]
+            comm_free = len(free)
+            chosen = free + [c for c in chosen if all(c is not x for x in free)]
+            del buf
+        self.stream_probe = dict(spin_ms=1e3 * one, queues_beside_main=len(chosen), beside_comm=comm_free, wanted=n,
+                                 candidates=len(cand))
+        rest = [c for c in cand if all(c is not x for x in chosen)]
+        return (chosen + rest)[:n]
 
     def sync_streams(self):
         """make the current stream wait for the flow stream (parameter gradients are written by kernels, not by
@@ -485,13 +598,12 @@ class MSCLWithAug(nn.Module):
             return m
         return self._shuffle(m.view(-1, 1), slot).view(-1).contiguous()
 
-    def _unshuffle(self, k, slot):
-        if parallel.single():
-            return k
-        if self._a2a:
-            p, ix = self._plans[slot], self._idx_dev
-            return parallel.exchange_rows(k, ix[8 + 4 * slot], ix[9 + 4 * slot], p.recv_splits, p.send_splits)
-        return parallel.all_gather_cat(k).index_select(0, self._idx_dev[3 + slot])
+    def _encode_key(self, slot, rec, x, m_dev):
+        """EMA update (moco.py:408-421) then the key forward (moco.py:535-545), replayed from a sub-graph when allowed"""
+        if self.key_graphs and self.training:
+            return self._key_graph[slot].run(rec, x, m_dev)
+        rec.momentum_update(m_dev)
+        return rec.encode_k(x)[0]
 
     def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None, color_q=None, color_k=None):
         rec, recf = self.recognizer, self.recognizer_flow
@@ -502,8 +614,10 @@ class MSCLWithAug(nn.Module):
         aug = self.aug_gpu
         K.ZEROS.reset(im_q.device)
         self._scal_dev.copy_(self._scal_host, non_blocking=True)
-        if not parallel.single():
+        dp = not parallel.single()
+        if dp:
             self._idx_dev.copy_(self._idx_host, non_blocking=True)
+            self._inv_dev.copy_(self._inv_host, non_blocking=True)
         sc = self._scal_dev
         ids = self.sup_head.mlvl_ids
         hw = lambda m: m.shape[2] * m.shape[3]
@@ -511,8 +625,11 @@ class MSCLWithAug(nn.Module):
         # The flow chain is ~200 small, latency-bound launches and the key chains carry no gradient, so they
         # run on side HIP streams and fill the CUs the big RGB-query kernels leave idle (tail waves, small layers);
         # autograd replays each node's backward on its forward stream, so the backward passes overlap too.
-        # Collectives issued from the side streams are still enqueued in host program order (identical on every
-        # rank) on the communicator's own stream, so the same layout holds for world size > 1.
+        # World size > 1: every collective runs on the communicator's ONE stream in host program order, each waiting for
+        # the work already issued to the stream it was called from.  So the three shuffle-BN exchanges of the key clips
+        # are issued first (their inputs exist at step start; issued after the flow query passes they would hold the RGB
+        # key branch back by that whole chain), and the encoded keys come back in ONE all-gather at the join below, which
+        # also serves both queue writes (moco.py:426) -- 4 collectives per step in the forward instead of 9.
         main = torch.cuda.current_stream()
         multi = self.two_streams
         nn_hip.WGRAD_SIDE.clear()
@@ -524,6 +641,16 @@ class MSCLWithAug(nn.Module):
         for st in (s_fq, s_fk):
             if st is not main:
                 st.wait_stream(main)
+        side_k = self._side_stream(1) if side is not main else main
+        if side_k is not main:
+            side_k.wait_stream(main)
+        if dp:
+            with torch.cuda.stream(side_k):
+                im_k = aug.color(im_k, color_k, 1)           # on the owner, before the shuffle (mscl.py:227 precedes moco.py:532)
+                im_k_x, flip_k0 = self._shuffle(im_k, 0), self._shuffle_mask(flip_k, 0)
+            with torch.cuda.stream(s_fk):
+                fk_b, flip_k1 = self._shuffle(flow_k[:, :, :Th], 1), self._shuffle_mask(flip_k, 1)
+                fk_a, flip_k2 = self._shuffle(flow_k[:, :, Th:], 2), self._shuffle_mask(flip_k, 2)
         with torch.cuda.stream(s_fq):
             q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th, flip_q))
             q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th, flip_q))
@@ -532,22 +659,19 @@ class MSCLWithAug(nn.Module):
             p_fa = pool(m_fa, m_fa.shape[0] * m_fa.shape[1], hw(m_fa))
         with torch.cuda.stream(s_fk):
             # two EMA updates, two BN-statistics passes (App. E-5)
-            recf.momentum_update(sc[1:2])
-            k_fb, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 1), 0, Th, self._shuffle_mask(flip_k, 1)))
-            k_fb = self._unshuffle(k_fb, 1)
-            recf.momentum_update(sc[2:3])
-            k_fa, _ = recf.encode_k(aug.pack_flow(self._shuffle(flow_k, 2), Th, Th, self._shuffle_mask(flip_k, 2)))
-            k_fa = self._unshuffle(k_fa, 2)
+            if dp:
+                k_fb = self._encode_key(1, recf, aug.pack_flow(fk_b, 0, Th, flip_k1), sc[1:2])
+                k_fa = self._encode_key(2, recf, aug.pack_flow(fk_a, 0, Th, flip_k2), sc[2:3])
+            else:
+                k_fb = self._encode_key(1, recf, aug.pack_flow(flow_k, 0, Th, flip_k), sc[1:2])
+                k_fa = self._encode_key(2, recf, aug.pack_flow(flow_k, Th, Th, flip_k), sc[2:3])
         # -- RGB key branch (no gradient): a third stream, it only meets the query branch in the loss
-        side_k = self._side_stream(1) if side is not main else main
-        if side_k is not main:
-            side_k.wait_stream(main)
         with torch.cuda.stream(side_k):
-            im_k = aug.color(im_k, color_k, 1)               # on the owner, before the shuffle (mscl.py:227 precedes moco.py:532)
-            x_k = aug.pack_rgb(self._shuffle(im_k, 0), self._shuffle_mask(flip_k, 0))
-            rec.momentum_update(sc[0:1])
-            k_rgb, _ = rec.encode_k(x_k)
-            k_rgb = self._unshuffle(k_rgb, 0)
+            if dp:
+                x_k = aug.pack_rgb(im_k_x, flip_k0)
+            else:
+                x_k = aug.pack_rgb(aug.color(im_k, color_k, 1), flip_k)
+            k_rgb = self._encode_key(0, rec, x_k, sc[0:1])
         # -- RGB query branch
         x_q = aug.pack_rgb(aug.color(im_q, color_q, 0), flip_q)
         q_rgb, maps_rgb = rec.encode_q(x_q)
@@ -562,6 +686,12 @@ class MSCLWithAug(nn.Module):
             main.wait_stream(s_fk)
             for tns in (q_fb, k_fb, q_fa, k_fa, p_fb, p_fa):
                 tns.record_stream(main)
+        self._kglobal = {}
+        if dp:
+            # keys come back: one all-gather of the three (B,128) blocks, put into global sample order with the inverse
+            # permutations; the own rows are this rank's keys (moco.py:174-191), the whole is what the queues enqueue
+            full, (k_rgb, k_fb, k_fa) = parallel.gather_unshuffle([k_rgb, k_fb, k_fa], self._inv_dev)
+            self._kglobal = dict(rgb=full[0], fb=full[1], fa=full[2])
         if m_rgb.shape[1] != m_fb.shape[1] or m_rgb.shape[1] != self.sup_head.t:
             raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {m_fb.shape[1]}, head t={self.sup_head.t}')
         self._dbg = dict(q_rgb=q_rgb.detach(), q_fb=q_fb.detach(), q_fa=q_fa.detach(), k_rgb=k_rgb, k_fb=k_fb, k_fa=k_fa)

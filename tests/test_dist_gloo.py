@@ -49,6 +49,15 @@ def _worker(rank, world, port, q):
             assert torch.equal(got, parallel.shuffle_select(x, step=step, slot=1))
             back = parallel.exchange_rows(got * 2.0, plan.back_send_order, plan.back_recv_order, plan.recv_splits, plan.send_splits)
             assert torch.equal(back, x * 2.0)
+        # keys of several blocks come back in ONE all-gather: own rows in the owner's order + the global order for the queue
+        perms = [parallel.shuffle_perm(world * b, 9, slot) for slot in range(3)]
+        inv = torch.stack([torch.argsort(p) for p in perms])
+        mine = [(torch.arange(b, dtype=torch.float32).view(b, 1) + 100 * rank + 1000 * i).repeat(1, 3) for i in range(3)]
+        enc = [parallel.all_gather_cat(m).index_select(0, p.view(world, b)[rank]) * 2.0 for m, p in zip(mine, perms)]
+        full, own = parallel.gather_unshuffle(enc, inv)
+        for i in range(3):
+            assert torch.equal(own[i], mine[i] * 2.0)
+            assert torch.equal(full[i], parallel.all_gather_cat(mine[i]) * 2.0)
         state = torch.cat([rec.queue.flatten(), rec.count.float(), rec.queue_ptr.float()])
         states = parallel.all_gather_cat(state[None])
         assert torch.equal(states[0], states[1])

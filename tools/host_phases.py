@@ -12,6 +12,11 @@ from mscl_amd.synthetic import synthetic_batch              # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dev = torch.device('cuda', 0)
+if os.environ.get('MSCL_FORCE_DIST') == '1':            # the world-size > 1 host path on a 1-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29535')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
 cfg.model.sup_head.t = 8
 model = build_model(cfg.model); fill_module(model); model.materialize(dev).train()
@@ -29,4 +34,12 @@ for it in range(25):
     t3 = time.perf_counter()
     if it >= 5:
         acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for it in range(20):
+    out = model.train_step(batch, sync_logs=False)
+    opt.zero_grad(); out['loss'].backward(); opt.step()
+torch.cuda.synchronize()
+print('wall ms/step %.2f' % (1e3 * (time.perf_counter() - t0) / 20))
+print('stream probe', getattr(model, 'stream_probe', None))
 print('host ms/step: forward %.2f  backward %.2f  optimizer %.2f' % tuple(1e3 * a / 20 for a in acc))

@@ -13,6 +13,11 @@ from mscl_amd.synthetic import synthetic_batch              # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dev = torch.device('cuda', 0)
+if os.environ.get('MSCL_FORCE_DIST') == '1':            # profile the world-size > 1 host path on a 1-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29534')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
 cfg.model.sup_head.t = 8
 model = build_model(cfg.model); fill_module(model); model.materialize(dev).train()
@@ -35,4 +40,4 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats(os.environ.get('SORT', 'tottime')).print_stats(int(os.environ.get('ROWS', '28')))
