@@ -487,14 +487,22 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restr
   dw[e] += s;
   if (i == 0 && db) db[o] += sb;
 }
+// hipMemsetAsync is NOT used for the pre-zeroing: on ROCm 7.0 a memset node inside any HIP graph other than the first one
+// a process instantiates writes garbage from its second replay on (tools/_ms.py reproduces it with this very entry
+// point); a fill kernel has no such problem and costs the same launch.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
 extern "C" int mscl_linear_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                                float* db, int rows, int in_f, int out_f, int relu, void* stream) {
   if (!x || !w || !y || !dy || !dw || rows <= 0 || in_f <= 0 || out_f <= 0) return MSCL_E_ARG;
   if (rows > LIN_MAX_ROWS) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
-    hipError_t me = hipMemsetAsync(dx, 0, (size_t)rows * in_f * sizeof(float), st);
-    if (me != hipSuccess) return (int)me;
+    const long nz = (long)rows * in_f;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, dx, nz);
+    MSCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((in_f + 255) / 256, (out_f + LIN_OCHUNK - 1) / LIN_OCHUNK), dim3(256), 0, st, w, y,
                        dy, dx, rows, in_f, out_f, relu);
     MSCL_LAUNCH_CHECK();

@@ -176,8 +176,13 @@ def _wgrad(conv, x, dy):
     dy.record_stream(side)
 
 
+HOLD_BUCKETS = [False]          # True while a branch's backward is being captured into a sub-graph (recognizers.QueryGraph)
+
+
 def _bucket_done(mod):
     """data-parallel hook: this module's backward completes a gradient bucket -> start its all-reduce now"""
+    if HOLD_BUCKETS[0]:
+        return                  # nothing executes during capture; the replaying node fires the trigger itself
     buckets = getattr(mod, '_grad_buckets', ())
     if buckets and not parallel.single():
         cur = torch.cuda.current_stream()

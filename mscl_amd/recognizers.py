@@ -180,6 +180,85 @@ class KeyGraph:
         return self.out
 
 
+class _ReplayFn(torch.autograd.Function):
+    """autograd node of a QueryGraph replay: forward and backward are one graph launch each"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, holder):
+        holder.static_x.copy_(x)
+        holder.fwd.replay()
+        ctx.holder = holder
+        return holder.q.detach(), holder.p.detach()
+
+    @staticmethod
+    def backward(ctx, dq, dp):
+        h = ctx.holder
+        h.gq.copy_(dq)
+        h.gp.copy_(dp)
+        h.bwd.replay()
+        nn_hip._bucket_done(h.trigger)          # the flow trunk's bucket (counts both traversals, GradReducer.need)
+        return None, None, None
+
+
+class QueryGraph:
+    """One flow query pass (trunk + projection + LMCL pooling) as two replayable HIP graphs, forward and backward.
+
+    The flow trunk is ~160 small launches per pass and direction, run twice per step: a third of what the host issues in an
+    eager (world size > 1) step after the key branches (KeyGraph).  Its backward holds no collective except the bucket
+    trigger at the very end, which the replaying autograd node fires itself.  Forward and backward share one private
+    memory pool, so the activations the backward reads are the ones the forward replay wrote."""
+
+    def __init__(self, warmup=2):
+        self.fwd, self.shape, self.calls, self.warmup = None, None, 0, warmup
+        self.fpool, self.bpool = K.ZeroPool(), K.ZeroPool()
+        self.failed = False
+
+    def capture(self, body, x, trigger):
+        dev = x.device
+        self.static_x = x.clone()
+        self.trigger = trigger
+        stream = torch.cuda.current_stream()
+        cap = dict(stream=stream if stream != torch.cuda.default_stream() else None, capture_error_mode='thread_local')
+        mem = torch.cuda.graph_pool_handle()
+        fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        shared = K.ZEROS
+        self.fpool.reset(dev, size=1 << 20)
+        self.bpool.reset(dev, size=1 << 20)
+        nn_hip.HOLD_BUCKETS[0] = True
+        try:
+            K.ZEROS = self.fpool
+            with torch.cuda.graph(fwd, pool=mem, **cap):
+                self.fpool.buf.zero_()
+                with torch.enable_grad():
+                    q, p, self.map_shape = body(self.static_x)
+            self.gq, self.gp = torch.zeros_like(q), torch.zeros_like(p)
+            K.ZEROS = self.bpool
+            with torch.cuda.graph(bwd, pool=mem, **cap):
+                self.bpool.buf.zero_()
+                torch.autograd.backward([q, p], [self.gq, self.gp])
+        finally:
+            K.ZEROS = shared
+            nn_hip.HOLD_BUCKETS[0] = False
+        self.q, self.p, self.fwd, self.bwd, self.shape = q.detach(), p.detach(), fwd, bwd, tuple(x.shape)
+
+    def run(self, body, x, trigger, anchor):
+        """body(x) -> (q, pooled map, map shape) is the eager formulation; returns the same triple"""
+        usable = not (self.failed or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled())
+        if usable and self.fwd is not None and self.shape == tuple(x.shape):
+            q, p = _ReplayFn.apply(x, anchor, self)
+            return q, p, self.map_shape
+        self.calls += 1
+        if not usable or self.calls <= self.warmup:
+            return body(x)
+        try:
+            self.capture(body, x, trigger)
+        except Exception as e:      # noqa: BLE001 -- nothing has executed during a capture: the eager launch below is still exact
+            self.failed, self.error = True, f'{type(e).__name__}: {e}'
+            return body(x)
+        q, p = _ReplayFn.apply(x, anchor, self)
+        return q, p, self.map_shape
+
+
 class _MSCLLossFn(torch.autograd.Function):
     """Loss phase as ONE graph node: the 7 InfoNCE terms over 3 queue snapshots + LMCL."""
 
@@ -277,6 +356,9 @@ class MSCLWithAug(nn.Module):
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
         self.key_graphs = os.environ.get('MSCL_KEY_GRAPHS', '1') == '1'          # key branches as sub-graphs in eager steps
         self._key_graph = [KeyGraph(), KeyGraph(), KeyGraph()]                  # RGB, flow base, flow rotated
+        self.query_graphs = os.environ.get('MSCL_QUERY_GRAPHS', '1') == '1'      # flow query passes (fwd + bwd) likewise
+        self._query_graph = [QueryGraph(), QueryGraph()]                         # flow base, flow rotated
+        self._graph_anchor = None
         self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0') == '1'     # measured 13 % slower: two MFMA-heavy kernels thrash     # MSCL_STREAMS=1: everything on the current stream
         self._side = None
 
@@ -605,6 +687,20 @@ class MSCLWithAug(nn.Module):
         rec.momentum_update(m_dev)
         return rec.encode_k(x)[0]
 
+    def _flow_query_body(self, x):
+        q, maps = self.recognizer_flow.encode_q(x)
+        m = maps[self.sup_head.mlvl_ids[1]]
+        return q, pool(m, m.shape[0] * m.shape[1], m.shape[2] * m.shape[3]), tuple(m.shape)
+
+    def _flow_query(self, slot, x):
+        """one flow query pass (moco.py:517-529 on the flow recognizer) + the LMCL pooling of its layer-4 map
+        (local_cl_head.py:57-62); replayed from a forward and a backward sub-graph in eager training steps"""
+        if not (self.query_graphs and self.training):
+            return self._flow_query_body(x)
+        if self._graph_anchor is None:
+            self._graph_anchor = torch.zeros(1, device=x.device, requires_grad=True)
+        return self._query_graph[slot].run(self._flow_query_body, x, self.recognizer_flow.encoder_q.stem, self._graph_anchor)
+
     def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None, color_q=None, color_k=None):
         rec, recf = self.recognizer, self.recognizer_flow
         T2 = flow_q.shape[2]
@@ -645,18 +741,26 @@ class MSCLWithAug(nn.Module):
         if side_k is not main:
             side_k.wait_stream(main)
         if dp:
-            with torch.cuda.stream(side_k):
+            # Issued from a stream of their own, never from one that later captures a sub-graph: a collective whose
+            # completion the process group's watchdog has not yet polled, issued from stream S, made the watchdog's
+            # event query fail ("event last recorded in a capturing stream") once S began the backward capture.
+            xs = self._side_stream(2) if multi else main
+            if xs is not main:
+                xs.wait_stream(main)
+            with torch.cuda.stream(xs):
                 im_k = aug.color(im_k, color_k, 1)           # on the owner, before the shuffle (mscl.py:227 precedes moco.py:532)
                 im_k_x, flip_k0 = self._shuffle(im_k, 0), self._shuffle_mask(flip_k, 0)
-            with torch.cuda.stream(s_fk):
                 fk_b, flip_k1 = self._shuffle(flow_k[:, :, :Th], 1), self._shuffle_mask(flip_k, 1)
                 fk_a, flip_k2 = self._shuffle(flow_k[:, :, Th:], 2), self._shuffle_mask(flip_k, 2)
+            if xs is not main:
+                for st in (side_k, s_fk):
+                    st.wait_stream(xs)
+                for tns in (im_k_x, fk_b, fk_a, flip_k0, flip_k1, flip_k2):
+                    if tns is not None:
+                        tns.record_stream(side_k if tns is im_k_x or tns is flip_k0 else s_fk)
         with torch.cuda.stream(s_fq):
-            q_fb, maps_fb = recf.encode_q(aug.pack_flow(flow_q, 0, Th, flip_q))
-            q_fa, maps_fa = recf.encode_q(aug.pack_flow(flow_q, Th, Th, flip_q))
-            m_fb, m_fa = maps_fb[ids[1]], maps_fa[ids[1]]
-            p_fb = pool(m_fb, m_fb.shape[0] * m_fb.shape[1], hw(m_fb))
-            p_fa = pool(m_fa, m_fa.shape[0] * m_fa.shape[1], hw(m_fa))
+            q_fb, p_fb, fmap_shape = self._flow_query(0, aug.pack_flow(flow_q, 0, Th, flip_q))
+            q_fa, p_fa, _ = self._flow_query(1, aug.pack_flow(flow_q, Th, Th, flip_q))
         with torch.cuda.stream(s_fk):
             # two EMA updates, two BN-statistics passes (App. E-5)
             if dp:
@@ -692,8 +796,8 @@ class MSCLWithAug(nn.Module):
             # permutations; the own rows are this rank's keys (moco.py:174-191), the whole is what the queues enqueue
             full, (k_rgb, k_fb, k_fa) = parallel.gather_unshuffle([k_rgb, k_fb, k_fa], self._inv_dev)
             self._kglobal = dict(rgb=full[0], fb=full[1], fa=full[2])
-        if m_rgb.shape[1] != m_fb.shape[1] or m_rgb.shape[1] != self.sup_head.t:
-            raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {m_fb.shape[1]}, head t={self.sup_head.t}')
+        if m_rgb.shape[1] != fmap_shape[1] or m_rgb.shape[1] != self.sup_head.t:
+            raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {fmap_shape[1]}, head t={self.sup_head.t}')
         self._dbg = dict(q_rgb=q_rgb.detach(), q_fb=q_fb.detach(), q_fa=q_fa.detach(), k_rgb=k_rgb, k_fb=k_fb, k_fa=k_fa)
         return _MSCLLossFn.apply(q_rgb, q_fb, q_fa, p_rgb, p_fb, p_fa, k_rgb, k_fb, k_fa, self)
 

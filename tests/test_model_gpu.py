@@ -434,6 +434,48 @@ def test_key_branch_subgraphs_equal_eager(dev):
     assert torch.isfinite(model.train_step(synthetic_batch(B, T, H, H, 0, 9, device=dev))['loss']).item()
 
 
+def test_flow_query_subgraphs_equal_eager(dev):
+    """recognizers.QueryGraph: a flow query pass replayed from a forward and a backward HIP sub-graph leaves the losses and
+    the flow recognizer's parameter gradients that the eager launches leave (same state, same batch; yardstick = two eager
+    runs, which differ by the order of the fp32 statistics atomics)."""
+    from mscl_amd import ClipSGD
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H, Kq = 4, 8, 64, 64                               # batch-4, 64x64: BatchNorm populations large enough to keep fp32-order noise small
+    model, cfg = build(T, Kq, dev)
+    model.key_graphs = False
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    for s in range(2):                                       # the two eager warm-up calls of each QueryGraph
+        out = model.train_step(synthetic_batch(B, T, H, H, 0, s, device=dev))
+        opt.zero_grad(); out['loss'].backward(); opt.step()
+    assert all(g.fwd is None for g in model._query_graph)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synthetic_batch(B, T, H, H, 0, 7, device=dev)
+    a, b = model.arena.ranges['flow']
+
+    def run(graphs):
+        model.load_state_dict(before)
+        model.query_graphs = graphs
+        out = model.train_step(batch)
+        opt.zero_grad(); out['loss'].backward()
+        model.sync_streams()
+        torch.cuda.synchronize()
+        return out['log_vars'], model.arena.G[a:b].clone(), model.arena.G.clone()
+    e1, e2, g1, g2 = run(False), run(False), run(True), run(True)
+    assert all(g.fwd is not None and not g.failed for g in model._query_graph)
+    cos = lambda x, y: torch.nn.functional.cosine_similarity(x.double(), y.double(), dim=0).item()
+    noise = 1 - cos(e1[1], e2[1])
+    print('1-cos flow grads: eager/eager %.2e, graph/eager %.2e %.2e; all grads: %.2e, %.2e %.2e' % (
+        noise, 1 - cos(g1[1], e1[1]), 1 - cos(g2[1], e1[1]), 1 - cos(e1[2], e2[2]), 1 - cos(g1[2], e1[2]), 1 - cos(g2[2], e1[2])))
+    for g in (g1, g2):                                       # capture + first replay, then a pure replay
+        assert 1 - cos(g[1], e1[1]) <= max(10 * noise, 3e-3), (1 - cos(g[1], e1[1]), noise)
+        assert 1 - cos(g[2], e1[2]) <= max(10 * (1 - cos(e1[2], e2[2])), 3e-3)
+        assert abs(g[1].norm().item() / e1[1].norm().item() - 1) < 5e-2
+        for k, v in e1[0].items():
+            if 'loss' in k:
+                loss_close(g[0][k], v, k)
+    assert e1[1].abs().max().item() > 0
+
+
 def test_full_size_step_properties(dev):
     """BASELINE.json's configuration (B=8, T=16, 112x112, K=65536) is too large for the CPU oracle inside a test, so the
     full-size step is checked through identities that hold at any size:

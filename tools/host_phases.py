@@ -4,6 +4,9 @@ import sys
 import time
 
 import torch
+if os.environ.get('HANG_DUMP'):
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ['HANG_DUMP']), exit=True)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mscl_amd import ClipSGD, Config, build_model          # noqa: E402
@@ -19,6 +22,27 @@ if os.environ.get('MSCL_FORCE_DIST') == '1':            # the world-size > 1 hos
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
 cfg.model.sup_head.t = 8
+if os.environ.get('HANG_DUMP'):
+    import traceback
+    import torch.distributed as dist
+    for name in ('all_reduce', 'all_gather_into_tensor', 'all_to_all_single', 'barrier', 'all_gather'):
+        def wrap(fn, name=name):
+            def inner(*a, **k):
+                cap = torch.cuda.is_current_stream_capturing()
+                print('[coll]', name, 'capturing' if cap else '', 'stream', hex(torch.cuda.current_stream().cuda_stream), flush=True)
+                if cap:
+                    traceback.print_stack(limit=6)
+                return fn(*a, **k)
+            return inner
+        setattr(dist, name, wrap(getattr(dist, name)))
+    import mscl_amd.recognizers as R
+    oc = R.QueryGraph.capture
+    def cap2(self, *a, **k):
+        print('[capture] QueryGraph begin, stream', hex(torch.cuda.current_stream().cuda_stream), flush=True)
+        r = oc(self, *a, **k)
+        print('[capture] QueryGraph end', flush=True)
+        return r
+    R.QueryGraph.capture = cap2
 model = build_model(cfg.model); fill_module(model); model.materialize(dev).train()
 opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
 batch = synthetic_batch(8, 16, 112, 112, 0, 0, device=dev)
