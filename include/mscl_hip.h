@@ -84,7 +84,9 @@ int mscl_weight_transpose_batched(const void* table, int n, int total_blocks, vo
  * and updates running_mean/var (momentum, unbiased var) and num_batches_tracked (int64) in place.
  * If res_sum != NULL the residual is itself a raw conv output normalised with its own statistics
  * (the downsample branch r3d.py:285-288): its saved mean/invstd go to res_mean/res_invstd and its
- * running buffers are updated too. */
+ * running buffers are updated too.
+ * Evaluation mode (module.eval(), used by Recognizer3D._do_test, recognizers/recognizer3d.py:33-96): pass
+ * sum = sumsq = NULL; the running statistics normalise, nothing is written (save_* may be NULL). */
 typedef struct {
   const float* sum; const float* sumsq; const float* gamma; const float* beta;
   float* running_mean; float* running_var; int64_t* num_batches_tracked;

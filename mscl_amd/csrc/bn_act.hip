@@ -11,6 +11,13 @@ struct BnDev {
 
 __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* shift, int C, float inv_n,
                                            float unbias, float eps, float momentum, bool writer) {
+  if (b.sum == nullptr) {           // evaluation mode (nn.BatchNorm3d.eval()): running statistics, nothing is written
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float sc = b.gamma[c] * rsqrtf(b.rvar[c] + eps);
+      scale[c] = sc; shift[c] = b.beta[c] - b.rmean[c] * sc;
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -78,14 +85,15 @@ extern "C" int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn, cons
                                float momentum, int relu, void* stream) {
   if (!y || !bn || !out || rows <= 0 || C <= 0) return MSCL_E_ARG;
   if (C % 8 || C > 2048 || rows * (C / 8) >= (1LL << 31)) return MSCL_E_SHAPE;
-  if (!bn->sum || !bn->sumsq || !bn->gamma || !bn->beta || !bn->running_mean || !bn->running_var ||
-      !bn->save_mean || !bn->save_invstd) return MSCL_E_ARG;
+  if (!bn->gamma || !bn->beta || !bn->running_mean || !bn->running_var) return MSCL_E_ARG;
+  if ((bn->sum == nullptr) != (bn->sumsq == nullptr)) return MSCL_E_ARG;
+  if (bn->sum && (!bn->save_mean || !bn->save_invstd)) return MSCL_E_ARG;       // training mode keeps mean / invstd for backward
   BnDev b{bn->sum, bn->sumsq, bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->num_batches_tracked,
           bn->save_mean, bn->save_invstd};
   BnDev rb{};
   int res_is_bn = 0;
   if (res_bn) {
-    if (!residual) return MSCL_E_ARG;
+    if (!residual || (res_bn->sum == nullptr) != (bn->sum == nullptr)) return MSCL_E_ARG;
     rb = BnDev{res_bn->sum, res_bn->sumsq, res_bn->gamma, res_bn->beta, res_bn->running_mean, res_bn->running_var,
                res_bn->num_batches_tracked, res_bn->save_mean, res_bn->save_invstd};
     res_is_bn = 1;

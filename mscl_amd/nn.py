@@ -139,6 +139,23 @@ def cba_fwd(conv, bn, x, residual, relu):
     return y, out, save
 
 
+def cba_eval(conv, bn, x, residual, relu):
+    """cba_fwd in evaluation mode (module.eval()): BatchNorm normalises with its running statistics, nothing is saved or
+    updated.  ref: nn.BatchNorm3d inference branch as used by Recognizer3D._do_test (recognizers/recognizer3d.py:33-96)."""
+    rt = conv._rt
+    if rt is None:
+        raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
+    y = K.conv3d_fwd(x, rt['w'], conv.desc(x.shape), bias=rt['bias'])
+    out = torch.empty_like(y)
+    C = conv.out_channels
+    brt = bn._rt
+    bp = lib.BnParams(None, None, brt['gamma'].data_ptr(), brt['beta'].data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), None, None, None)
+    lib.call('mscl_bn_act_fwd', y.data_ptr(), ctypes.byref(bp), residual.data_ptr() if residual is not None else None, None,
+             out.data_ptr(), y.numel() // C, C, bn.eps, bn.momentum, int(relu), lib.stream_ptr())
+    return out
+
+
 def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_addend=None):
     """backward of cba_fwd: BN(+ReLU) input gradient, conv weight gradient (into the arena), conv input
     gradient (optionally fused with `dx_addend`).  Returns (dx|None, dres|None)."""
@@ -314,8 +331,23 @@ class VideoResNetHip(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    @torch.no_grad()
+    def forward_eval(self, x):
+        """the same trunk with BatchNorm in evaluation mode (running statistics); no autograd graph"""
+        x = cba_eval(self.stem[0], self.stem[1], x, None, True)
+        outs = []
+        for li in range(1, 5):
+            for blk in getattr(self, f'layer{li}'):
+                a1 = cba_eval(blk.conv1[0], blk.conv1[1], x, None, True)
+                res = x if blk.downsample is None else cba_eval(blk.downsample[0], blk.downsample[1], x, None, False)
+                x = cba_eval(blk.conv2[0], blk.conv2[1], a1, res, True)
+            outs.append(x)
+        return outs
+
     def forward(self, x):
         _need_gpu(x)
+        if not self.training:
+            return self.forward_eval(x)
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
         x = _StemFn.apply(x, self._anchor, self.stem)

@@ -135,3 +135,26 @@ def test_coloraug_restatement_properties():
     ones = torch.ones(1, 3, 12, 12)
     assert (c.gaussian_blur(ones, 11, 1.7) - 1).abs().max() < 1e-6
     assert abs(float(c.gaussian_taps(11, 0.1)[5]) - 1.0) < 1e-6           # sigma 0.1: a delta
+
+
+def test_finetune_oracle_vs_reference_golden():
+    """oracle/recognizer3d.py reproduces what the reference's Recognizer3D + I3DHead gave on the same closed-form weights
+    and seeded clips (G9, tools/oracle/make_golden_finetune.py): losses, gradient norms, evaluation-mode probabilities."""
+    import json
+    from oracle import fill as ofill, recognizer3d as orec
+    gold = json.load(open(os.path.join(GOLD, 'finetune_g9.json')))
+    cfg = gold['config']
+    g = torch.Generator().manual_seed(cfg['seed'])
+    imgs = torch.randn((cfg['B'], 1, 3, cfg['T'], cfg['H'], cfg['H']), generator=g)
+    test_imgs = torch.randn((cfg['B'], cfg['clips'], 3, cfg['T'], cfg['H'], cfg['H']), generator=g)
+    m = orec.Recognizer3D(cfg['num_classes'], dropout_ratio=0.0)
+    ofill.fill_module(m)
+    m.train()
+    out = m.train_step(dict(imgs=imgs, label=torch.tensor(cfg['labels']).view(-1, 1)))
+    out['loss'].backward()
+    for k, v in gold['log_vars'].items():
+        assert abs(out['log_vars'][k] - v) <= 1e-5 * max(1.0, abs(v)), k
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
+    assert abs(gn - gold['grad_norm']) <= 1e-4 * gold['grad_norm']
+    m.eval()
+    assert (m.forward_test(test_imgs) - torch.tensor(gold['probs'])).abs().max() < 1e-5
