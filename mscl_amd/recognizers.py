@@ -146,6 +146,7 @@ class KeyGraph:
     def __init__(self, warmup=2):
         self.graph, self.shape, self.calls, self.warmup = None, None, 0, warmup
         self.pool = K.ZeroPool()
+        self.failed = False
 
     def _body(self, rec, x, m_dev):
         rec.momentum_update(m_dev)
@@ -173,6 +174,10 @@ class KeyGraph:
                                   capture_error_mode='thread_local'):      # other threads (RCCL watchdog) keep running
                 self.pool.buf.zero_()
                 self.out = self._body(rec, self.static_in, m_dev)
+        except Exception as e:      # noqa: BLE001 -- nothing has executed during a capture: the eager launch below is still exact
+            K.ZEROS = shared
+            self.failed, self.error, self.warmup = True, f'{type(e).__name__}: {e}', 1 << 60
+            return self._body(rec, x, m_dev)
         finally:
             K.ZEROS = shared
         self.graph = graph
