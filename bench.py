@@ -181,7 +181,8 @@ def main():
                        'clip': f'{T_FRAMES}x{SIDE}x{SIDE}', 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
                        'parallelism': f'dp{world}' + (' (collectives forced on a 1-rank RCCL group)' if forced else ''), 'weights': 'closed-form fill, fp32 masters + bf16 shadows',
                        'launch': 'one captured HIP graph per step' if graphed is not None
-                                 else 'eager launches, key branches replayed from HIP sub-graphs',
+                                 else 'eager launches, %d of 5 collective-free branches replayed from HIP sub-graphs' % (
+                                     sum(g.graph is not None for g in model._key_graph) + sum(g.fwd is not None for g in model._query_graph)),
                        'aug': 'stochastic flip+jitter+grayscale+blur (variant)' if args.stochastic_aug
                               else 'normalise only (BASELINE.json workload)'},
             'final_loss': loss,
