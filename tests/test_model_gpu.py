@@ -239,7 +239,7 @@ def _two_rank_worker(rank, world, port, q):
         patched(orc.recognizer, lambda: 0)
         patched(orc.recognizer_flow, flow_slot)
         cos = torch.nn.functional.cosine_similarity
-        for s in range(2):
+        for s in range(4):                          # steps 2 and 3 capture and replay the key / flow-query sub-graphs
             state['step'] = s
             batch = synthetic_batch(B, T, H, H, rank, s)
             out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
@@ -267,6 +267,7 @@ def _two_rank_worker(rank, world, port, q):
                 assert rec.batch_size == orec.batch_size == world * B
                 assert torch.equal(rec.count.cpu(), orec.count), nm
                 assert abs(rec.m - orec.m) < 1e-12
+        assert all(g.graph is not None for g in model._key_graph) and all(g.fwd is not None for g in model._query_graph)
         # replicas stay bit-identical: masters, momentum, both queues
         blob = torch.cat([model.arena.Q.flatten(), model.arena.MOM.flatten(), model.arena.KX.flatten(),
                           model.recognizer.queue.flatten().float(), model.recognizer_flow.queue.flatten().float()]).cpu()
