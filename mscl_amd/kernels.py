@@ -111,13 +111,21 @@ class ZeroPool:
     statistics / reduction scratch used to cost ~190 tiny fill launches per step)."""
 
     def __init__(self):
-        self.buf, self.used = None, 0
+        self.buf, self.used, self.high = None, 0, 0
 
     def reset(self, device, size=4 << 20):
         if self.buf is None or self.buf.device != torch.device(device):
             self.buf = torch.zeros(size, dtype=torch.float32, device=device)
-        elif self.used:
-            self.buf[:self.used].zero_()
+            self.high = 0
+        else:
+            # Re-zero what has ever been handed out, not just the previous step's share: the consumers differ between
+            # launch modes (branches replayed from sub-graphs bring their own pools), and a reset that is being captured
+            # is replayed for every later step, so it clears the whole buffer (16 MB, ~5 us).
+            self.high = max(self.high, self.used)
+            if torch.cuda.is_current_stream_capturing():
+                self.buf.zero_()
+            elif self.high:
+                self.buf[:self.high].zero_()
         self.used = 0
 
     def take(self, n, device):

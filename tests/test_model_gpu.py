@@ -477,6 +477,41 @@ def test_flow_query_subgraphs_equal_eager(dev):
     assert e1[1].abs().max().item() > 0
 
 
+def test_whole_step_graph_after_subgraph_steps(dev):
+    """Launch modes may be mixed in one process: eager steps that replay sub-graphs, then a whole-step capture.  The
+    statistics scratch pool is shared by whatever launches eagerly, so its captured reset must clear everything the
+    captured step will take (a stale, smaller reset let BatchNorm sums pile up over replays: tools/soak.py saw the loss
+    climb from 33 to 94).  Replays from one restored state agree with each other and with the eager step."""
+    from mscl_amd import ClipSGD
+    from mscl_amd.graph import GraphedStep
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H, Kq = 4, 8, 64, 64
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    for s in range(4):
+        out = model.train_step(synthetic_batch(B, T, H, H, 0, s, device=dev))
+        opt.zero_grad(); out['loss'].backward(); opt.step()
+    assert all(g.graph is not None for g in model._key_graph) and all(g.fwd is not None for g in model._query_graph)
+    batch = synthetic_batch(B, T, H, H, 0, 9, device=dev)
+    gs = GraphedStep(model, opt, batch, warmup=1)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    mom = model.arena.MOM.clone()
+    losses = []
+    for _ in range(4):
+        model.load_state_dict(before)
+        model.arena.MOM.copy_(mom)
+        loss, _ = gs.step(batch)
+        losses.append(float(loss))
+    model.load_state_dict(before)
+    model.key_graphs = model.query_graphs = False
+    eager = model.train_step(batch)['log_vars']['loss']
+    # batch-4 BatchNorm keeps the run-to-run noise of this state at a few per cent; piled-up statistics moved the loss by
+    # tens of per cent from one replay to the next
+    for v in losses:
+        assert abs(v - eager) <= 0.06 * abs(eager), (losses, eager)
+        assert abs(v - losses[0]) <= 0.06 * abs(eager), (losses, eager)
+
+
 def test_full_size_step_properties(dev):
     """BASELINE.json's configuration (B=8, T=16, 112x112, K=65536) is too large for the CPU oracle inside a test, so the
     full-size step is checked through identities that hold at any size:
