@@ -7,6 +7,8 @@ learning rate, shuffle indices) -- so the captured graph stays valid for the who
 """
 import torch
 
+from . import parallel
+
 
 class GraphedStep:
     def __init__(self, model, optimizer, example_batch, warmup=2):
@@ -26,6 +28,7 @@ class GraphedStep:
         torch.cuda.synchronize()
         # host-side state mutated by the (non-executing) capture pass is rolled back afterwards
         snap = self._host_state()
+        parallel.settle_before_capture()
         self.graph = torch.cuda.CUDAGraph()
         fk = model.flow_key[0]
         model._pre_step_host(self.B)

@@ -33,6 +33,17 @@ def single():
     return dist.get_world_size() == 1 and os.environ.get('MSCL_FORCE_DIST') != '1'
 
 
+def settle_before_capture():
+    """Call before a HIP-graph capture when an RCCL process group is alive.  ProcessGroupNCCL's watchdog thread polls the
+    completion events of recent collectives every 100 ms; if one of those events belongs to a stream that has meanwhile
+    joined a capture, the query fails ("event last recorded in a capturing stream") and the watchdog aborts the process.
+    After a device synchronize every collective is complete, and two watchdog periods later all of them are retired."""
+    if is_dist() and dist.get_backend() == 'nccl':
+        import time
+        torch.cuda.synchronize()
+        time.sleep(0.25)
+
+
 @torch.no_grad()
 def all_gather_cat(t):
     """ref: recognizers/moco.py:558-568 (concat_all_gather); identity for a single replica."""

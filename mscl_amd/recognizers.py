@@ -165,6 +165,7 @@ class KeyGraph:
         self.graph, self.shape = None, tuple(x.shape)
         self.static_in = x.clone()
         stream = torch.cuda.current_stream()
+        parallel.settle_before_capture()
         graph = torch.cuda.CUDAGraph()
         shared = K.ZEROS
         self.pool.reset(x.device, size=2 << 20)
@@ -225,6 +226,7 @@ class QueryGraph:
         stream = torch.cuda.current_stream()
         cap = dict(stream=stream if stream != torch.cuda.default_stream() else None, capture_error_mode='thread_local')
         mem = torch.cuda.graph_pool_handle()
+        parallel.settle_before_capture()
         fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         shared = K.ZEROS
         self.fpool.reset(dev, size=1 << 20)

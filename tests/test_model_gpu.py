@@ -371,7 +371,7 @@ def test_color_aug_inputs_and_stochastic_mode(dev):
         m.aug_gpu.stochastic = True
         m.aug_gpu.seed(seed)
         outs.append(m.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})['log_vars']['loss'])
-    assert outs[0] == outs[1] or abs(outs[0] - outs[1]) < 2e-3 * abs(outs[0])
+    loss_close(outs[0], outs[1], 'same seed, same draws')          # (equal up to the fp32 atomics order, amplified by batch-2 BatchNorm)
     assert abs(outs[0] - outs[2]) > 1e-4
     # graph replay with a stochastic augmenter: masks and rows are static buffers refreshed per step
     opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)

@@ -37,7 +37,7 @@ if MODE in ('both', 'eager'):
         out = m.train_step(batches[i % 8], sync_logs=False); opt.zero_grad(); out['loss'].backward(); opt.step()
         losses.append(out['loss'].detach())
     report('eager + sub-graphs', losses, t0)
-if os.environ.get('MSCL_FORCE_DIST') != '1' and MODE in ('both', 'graph'):
+if (os.environ.get('MSCL_FORCE_DIST') != '1' or os.environ.get('MSCL_GRAPH_DP') == '1') and MODE in ('both', 'graph'):
     gs = GraphedStep(m, opt, batches[0], warmup=2)
     losses = []
     t0 = time.perf_counter()
