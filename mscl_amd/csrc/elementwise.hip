@@ -315,20 +315,34 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restr
     q = fdiv(r, dv.Hs); const int hs = r - q * Hs; r = q;
     const int n = fdiv(r, dv.Ts), ts = r - n * Ts;
     float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // candidate fine ranges: a coarse index influences fine indices within +-ceil(out/in)+1 of its centre
-    const int rt = Td / Ts + 2, rh = Hd / Hs + 2, rw = Wd / Ws + 2;
-    const int ct = fdiv(ts * Td, dv.Ts), ch = fdiv(hs * Hd, dv.Hs), cw = fdiv(ws * Wd, dv.Ws);
-    for (int t = max(0, ct - rt); t <= min(Td - 1, ct + rt); ++t) {
+    // candidate fine ranges.  nearest: fine d reads coarse floor(d * in / out), so coarse i is read by d in [i*s, (i+1)*s),
+    // s = out / in.  trilinear (align_corners = False): d reads i0 = floor(src), i1 = i0 + 1 with src = (d + 0.5) / s - 0.5,
+    // so i is touched when src is in (i - 1, i + 1), i.e. d in ((i - 0.5) s - 0.5, (i + 1.5) s - 0.5).  floor / ceil of the
+    // OPEN bounds already add a zero-weight candidate each side when they are integers, which is also the only case float
+    // rounding could move a bound; the weights below stay the exact test.
+    // (The window used to be +-(s + 2) around the centre: 9^3 candidates at s = 2, now 6^3 trilinear / 3^3 nearest.)
+    const float st_ = (float)Td / (float)Ts, sh_ = (float)Hd / (float)Hs, sw_ = (float)Wd / (float)Ws;
+    int tlo, thi, hlo, hhi, wlo, whi;
+    if (!trilinear) {
+      tlo = (int)floorf(ts * st_); thi = (int)ceilf((ts + 1) * st_);
+      hlo = (int)floorf(hs * sh_); hhi = (int)ceilf((hs + 1) * sh_);
+      wlo = (int)floorf(ws * sw_); whi = (int)ceilf((ws + 1) * sw_);
+    } else {
+      tlo = (int)floorf((ts - 0.5f) * st_ - 0.5f); thi = (int)ceilf((ts + 1.5f) * st_ - 0.5f);
+      hlo = (int)floorf((hs - 0.5f) * sh_ - 0.5f); hhi = (int)ceilf((hs + 1.5f) * sh_ - 0.5f);
+      wlo = (int)floorf((ws - 0.5f) * sw_ - 0.5f); whi = (int)ceilf((ws + 1.5f) * sw_ - 0.5f);
+    }
+    for (int t = max(0, tlo); t <= min(Td - 1, thi); ++t) {
       float wt_t;
       if (!trilinear) { wt_t = (fdiv(t * Ts, dv.Td) == ts) ? 1.f : 0.f; }
       else { int i0, i1; float a; lin_coord(t, Ts, Td, i0, i1, a); wt_t = (i0 == ts ? 1.f - a : 0.f) + (i1 == ts ? a : 0.f); }
       if (wt_t == 0.f) continue;
-      for (int h = max(0, ch - rh); h <= min(Hd - 1, ch + rh); ++h) {
+      for (int h = max(0, hlo); h <= min(Hd - 1, hhi); ++h) {
         float wt_h;
         if (!trilinear) { wt_h = (fdiv(h * Hs, dv.Hd) == hs) ? 1.f : 0.f; }
         else { int i0, i1; float a; lin_coord(h, Hs, Hd, i0, i1, a); wt_h = (i0 == hs ? 1.f - a : 0.f) + (i1 == hs ? a : 0.f); }
         if (wt_h == 0.f) continue;
-        for (int w = max(0, cw - rw); w <= min(Wd - 1, cw + rw); ++w) {
+        for (int w = max(0, wlo); w <= min(Wd - 1, whi); ++w) {
           float wt_w;
           if (!trilinear) { wt_w = (fdiv(w * Ws, dv.Wd) == ws) ? 1.f : 0.f; }
           else { int i0, i1; float a; lin_coord(w, Ws, Wd, i0, i1, a); wt_w = (i0 == ws ? 1.f - a : 0.f) + (i1 == ws ? a : 0.f); }
@@ -412,65 +426,82 @@ extern "C" int mscl_pool_bwd(const float* dout, uint16_t* dx, int outer, int inn
 // ---------------------------------------------------------------- Linear on a few rows (fp32)
 // y[r][o] = relu?( sum_i x[r][i] w[o][i] + b[o] ).  One wave per output feature, all rows at once.
 #define LIN_MAX_ROWS 32
+// The row count is a template parameter (8 / 16 / 32, rows beyond the real count are clamped duplicates that are never
+// stored): with a run-time `if (r < rows)` inside the unrolled row loops every row became its own branch with its own
+// dependent load, and these two kernels -- a few KB of work each, on the path into and out of the loss -- took 10-36 us.
+template <int ROWS>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ y, int rows,
                                                          int in_f, int out_f, int relu) {
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= out_f) return;
-  float acc[LIN_MAX_ROWS];
+  float acc[ROWS];
 #pragma unroll
-  for (int r = 0; r < LIN_MAX_ROWS; ++r) acc[r] = 0.f;
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
   for (int i = lane; i < in_f; i += 64) {
     const float wv = w[(long)o * in_f + i];
+    float xv[ROWS];
 #pragma unroll
-    for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) acc[r] += wv * x[(long)r * in_f + i];
+    for (int r = 0; r < ROWS; ++r) xv[r] = x[(long)(r < rows ? r : rows - 1) * in_f + i];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = fmaf(wv, xv[r], acc[r]);
   }
+  const float bv = b ? b[o] : 0.f;
 #pragma unroll
-  for (int r = 0; r < LIN_MAX_ROWS; ++r) {
-    if (r < rows) {
-      float v = wave_sum(acc[r]) + (b ? b[o] : 0.f);
-      if (relu) v = fmaxf(v, 0.f);
-      if (lane == 0) y[(long)r * out_f + o] = v;
-    }
+  for (int r = 0; r < ROWS; ++r) {
+    float v = wave_sum(acc[r]) + bv;
+    if (relu) v = fmaxf(v, 0.f);
+    if (lane == 0 && r < rows) y[(long)r * out_f + o] = v;
   }
 }
 extern "C" int mscl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
                                int relu, void* stream) {
   if (!x || !w || !y || rows <= 0 || in_f <= 0 || out_f <= 0) return MSCL_E_ARG;
   if (rows > LIN_MAX_ROWS) return MSCL_E_SHAPE;
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((out_f + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, y, rows, in_f, out_f, relu);
+  const dim3 grid((out_f + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 8) hipLaunchKernelGGL(linear_fwd_kernel<8>, grid, dim3(256), 0, st, x, w, b, y, rows, in_f, out_f, relu);
+  else if (rows <= 16) hipLaunchKernelGGL(linear_fwd_kernel<16>, grid, dim3(256), 0, st, x, w, b, y, rows, in_f, out_f, relu);
+  else hipLaunchKernelGGL(linear_fwd_kernel<32>, grid, dim3(256), 0, st, x, w, b, y, rows, in_f, out_f, relu);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
 // backward: g = dy * (y>0 if relu);  dx[r][i] = sum_o g[r][o] w[o][i];  dw[o][i] += sum_r g[r][o] x[r][i];  db[o] += sum_r g[r][o]
 // dx[r][i] += sum over this block's 32 output features; grid = (in_f/256, out_f/32); dx is pre-zeroed
 #define LIN_OCHUNK 32
+template <int ROWS>
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dx, int rows,
                                                             int in_f, int out_f, int relu) {
-  __shared__ float g[LIN_MAX_ROWS * LIN_OCHUNK];
+  __shared__ float g[LIN_OCHUNK * ROWS];             // [oo][r]: a thread reads its ROWS values of one oo as float4s
   const int o0 = blockIdx.y * LIN_OCHUNK;
-  for (int e = threadIdx.x; e < rows * LIN_OCHUNK; e += 256) {
-    const int r = e / LIN_OCHUNK, o = o0 + e % LIN_OCHUNK;
+  for (int e = threadIdx.x; e < ROWS * LIN_OCHUNK; e += 256) {
+    const int r = e / LIN_OCHUNK, oo = e % LIN_OCHUNK, o = o0 + oo;
     float v = 0.f;
-    if (o < out_f) { v = dy[(long)r * out_f + o]; if (relu && !(y[(long)r * out_f + o] > 0.f)) v = 0.f; }
-    g[e] = v;
+    if (r < rows && o < out_f) { v = dy[(long)r * out_f + o]; if (relu && !(y[(long)r * out_f + o] > 0.f)) v = 0.f; }
+    g[oo * ROWS + r] = v;                             // rows beyond the real count and features beyond out_f hold zeros
   }
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= in_f) return;
-  float acc[LIN_MAX_ROWS];
+  float acc[ROWS];
 #pragma unroll
-  for (int r = 0; r < LIN_MAX_ROWS; ++r) acc[r] = 0.f;
-  const int on = min(LIN_OCHUNK, out_f - o0);
-  for (int oo = 0; oo < on; ++oo) {
-    const float wv = w[(long)(o0 + oo) * in_f + i];
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  float wv[LIN_OCHUNK];
 #pragma unroll
-    for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) acc[r] = fmaf(g[r * LIN_OCHUNK + oo], wv, acc[r]);
+  for (int oo = 0; oo < LIN_OCHUNK; ++oo) wv[oo] = w[(long)(o0 + oo < out_f ? o0 + oo : out_f - 1) * in_f + i];
+#pragma unroll
+  for (int oo = 0; oo < LIN_OCHUNK; ++oo) {
+#pragma unroll
+    for (int r4 = 0; r4 < ROWS; r4 += 4) {
+      const float4 gv = *reinterpret_cast<const float4*>(&g[oo * ROWS + r4]);
+      acc[r4] = fmaf(gv.x, wv[oo], acc[r4]); acc[r4 + 1] = fmaf(gv.y, wv[oo], acc[r4 + 1]);
+      acc[r4 + 2] = fmaf(gv.z, wv[oo], acc[r4 + 2]); acc[r4 + 3] = fmaf(gv.w, wv[oo], acc[r4 + 3]);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < LIN_MAX_ROWS; ++r) if (r < rows) atomicAdd(&dx[(long)r * in_f + i], acc[r]);
+  for (int r = 0; r < ROWS; ++r) if (r < rows) atomicAdd(&dx[(long)r * in_f + i], acc[r]);
 }
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dw,
@@ -503,8 +534,10 @@ extern "C" int mscl_linear_bwd(const float* x, const float* w, const float* y, c
     const long nz = (long)rows * in_f;
     hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, dx, nz);
     MSCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((in_f + 255) / 256, (out_f + LIN_OCHUNK - 1) / LIN_OCHUNK), dim3(256), 0, st, w, y,
-                       dy, dx, rows, in_f, out_f, relu);
+    const dim3 grid((in_f + 255) / 256, (out_f + LIN_OCHUNK - 1) / LIN_OCHUNK);
+    if (rows <= 8) hipLaunchKernelGGL(linear_bwd_dx_kernel<8>, grid, dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
+    else if (rows <= 16) hipLaunchKernelGGL(linear_bwd_dx_kernel<16>, grid, dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
+    else hipLaunchKernelGGL(linear_bwd_dx_kernel<32>, grid, dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
     MSCL_LAUNCH_CHECK();
   }
   const long tot = (long)out_f * in_f;

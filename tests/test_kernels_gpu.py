@@ -49,6 +49,7 @@ CONV_CASES = [
     ('stem_flow', 1, 4, 20, 20, 8, 16, (1, 7, 7), (2, 2, 2), (0, 3, 3)),
     ('big_m_tail', 3, 5, 13, 11, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('l1_plane_56', 1, 3, 56, 56, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # real layer-1 plane: 13 halo tiles, last partial
+    ('lat_bias_long', 2, 4, 48, 48, 16, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # 18 432 rows: the bias-gradient column sum takes a full and a partial trip
 ]
 
 
@@ -174,6 +175,28 @@ def test_bn_act_fwd_bwd(C, relu, resmode, dev):
         close(rdg, m2.weight.grad, 2e-3, 'res dgamma'); close(rdb, m2.bias.grad, 2e-3, 'res dbeta')
 
 
+def test_bn_act_fwd_large_map(dev):
+    """a map larger than one sweep of the 2048-block grid: the unrolled loop takes a full and a partial trip"""
+    from mscl_amd import kernels as K_
+    from mscl_amd.kernels import STAT_SLOTS, _bnp
+    C, shape = 64, (2, 4, 96, 96, 64)                 # 589 824 granules > 2048 * 256
+    y = bf(rnd(shape, 11) * 1.5 + 0.3).to(dev); res = bf(rnd(shape, 12)).to(dev)
+    gamma = (1 + 0.1 * rnd((C,), 2)).to(dev); beta = (0.1 * rnd((C,), 3)).to(dev)
+    f = y.float().reshape(-1, C)
+    st = torch.zeros((STAT_SLOTS, 2, C), device=dev)
+    st[0, 0] = f.sum(0); st[0, 1] = (f * f).sum(0)
+    mean = f.mean(0); var = f.var(0, unbiased=False)
+    ref = torch.relu((y.float() - mean) * torch.rsqrt(var + 1e-5) * gamma + beta + res.float())
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nbt = torch.zeros((), dtype=torch.long, device=dev)
+    sm, si = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    bn = _bnp((st[0, 0], st[0, 1]), gamma, beta, rm, rv, nbt, sm, si)
+    out = K_.bn_act_fwd(y, bn, residual=res, relu=True)
+    close(out, ref, BF16_TOL, 'bn_act_fwd large map')
+    out = K_.bn_act_fwd(y, bn, relu=False)
+    close(out, (y.float() - mean) * torch.rsqrt(var + 1e-5) * gamma + beta, BF16_TOL, 'bn_act_fwd large map, plain')
+
+
 def test_pack_add_relu_pool(dev):
     from mscl_amd import kernels as K_
     x = torch.rand(2, 3, 4, 6, 5, generator=torch.Generator().manual_seed(0))
@@ -221,7 +244,8 @@ def test_upsample(tri, dev):
 
 def test_linear_l2norm(dev):
     from mscl_amd import kernels as K_
-    for rows, i, o, relu in ((8, 512, 512, True), (8, 512, 128, False), (2, 128, 128, True), (16, 128, 128, False)):
+    for rows, i, o, relu in ((8, 512, 512, True), (8, 512, 128, False), (2, 128, 128, True), (16, 128, 128, False),
+                             (20, 100, 40, True), (32, 300, 70, False), (1, 64, 8, True)):
         x = rnd((rows, i), 1).requires_grad_(True); w = (rnd((o, i), 2) / i ** 0.5).requires_grad_(True); b = rnd((o,), 3).requires_grad_(True)
         y = F.linear(x, w, b); y = F.relu(y) if relu else y
         yd = K_.linear_fwd(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev), relu)
