@@ -26,7 +26,13 @@ struct WGeom {
   FastDiv dWo, dHo, dTo;
 };
 
-__device__ __forceinline__ int wswz(int row) { return (row & 2) | ((row >> 1) & 4); }   // XOR on the 16-byte granule index
+// XOR on the 16-byte granule index.  G = granules per tile row: a 32-lane group of a transposing read touches 8 rows x 32 B;
+// with 128-byte rows odd / even rows already sit in opposite halves of the 256-byte bank row, with 256-byte rows (G = 16) they
+// alias, so row bit 0 goes into granule bit 3 as well.
+template <int G>
+__device__ __forceinline__ int wswz(int row) {
+  return (row & 2) | ((row >> 1) & 4) | (G == 16 ? ((row & 1) << 3) : 0);
+}
 
 // ds_read_b64_tr_b16 as inline asm (see the main loop) + the matching hand-placed wait; the "+v" operands tie the
 // consumers of the two registers to the wait
@@ -45,15 +51,20 @@ __device__ __forceinline__ auto wg_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int CO, int NCOL>
+// WCO = waves along the output-channel axis (1: the 4 waves split the columns and every wave reads the whole dy tile;
+// 2: a 2 x 2 arrangement, used with the 128 x 128 tile where each wave then owns 64 x 64 and one LDS byte feeds 2.5x the MFMAs)
+template <int CO, int NCOL, int WCO>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf16_t* __restrict__ x,
                                                          const bf16_t* __restrict__ dy, float* __restrict__ dw) {
   constexpr int PB = 64;                        // positions per step
   constexpr int GA = CO / 8, GB = NCOL / 8;     // granules per tile row
   constexpr int NA = (PB * GA + 255) / 256;     // dy DMA passes (one 1-KiB chunk per wave per pass)
   constexpr int NB = PB * GB / 256;             // x DMA passes
-  constexpr int IA = CO / 16;
-  constexpr int WN = NCOL / 4, JB = WN / 16;    // columns per wave
+  constexpr int WCOL = 4 / WCO;
+  constexpr int WM = CO / WCO, IA = WM / 16;    // output channels per wave
+  constexpr int WN = NCOL / WCOL, JB = WN / 16; // columns per wave
+  static_assert(WCO == 1 || WCO == 2, "wave arrangement");
+  static_assert(WM % 16 == 0 && (GA < 16 || GA == 16) && (GB < 16 || GB == 16 || GB == 24), "swizzle covers rows of up to 16 granules (24: unswizzled bit 3)");
   static_assert((PB * GB) % 256 == 0 && WN % 16 == 0 && (PB * GA) % 64 == 0, "tile config");
   constexpr bool SWA = GA >= 8, SWB = GB >= 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
   for (int p = 0; p < NB; ++p) {
     const int G = (p * 4 + wave) * 64 + lane;
     const int row = G / GB, pg = G % GB;
-    const int lg = SWB ? (pg ^ wswz(row)) : pg;             // logical granule fetched into physical slot pg
+    const int lg = SWB ? (pg ^ wswz<GB>(row)) : pg;         // logical granule fetched into physical slot pg
     const int jg = (n0 >> 3) + lg;                          // global column granule
     int delta = 0, bits = 0;
     if (jg * 8 < g.ncols) {
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
   for (int p = 0; p < NA; ++p) {
     const int G = (p * 4 + wave) * 64 + lane;
     const int row = G / GA, pg = G % GA;
-    const int lg = SWA ? (pg ^ wswz(row)) : pg;
+    const int lg = SWA ? (pg ^ wswz<GA>(row)) : pg;
     ya_row[p] = row; ya_off[p] = (co0 + lg * 8 < g.K) ? (co0 + lg * 8) * 2 : -1;
   }
 
@@ -165,6 +176,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
     for (int j = 0; j < JB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int wco = wave / WCOL, wcol = wave % WCOL;
   decode_rows(0);
   decode_rows(4);
   __syncthreads();
@@ -187,8 +199,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r = ks * 32 + 8 * grp + 4 * h + qq;
-          const int gq = i * 2 + (pp >> 1);
-          const unsigned char* ad = a + r * (CO * 2) + ((SWA ? (gq ^ wswz(r)) : gq) * 16) + (pp & 1) * 8;
+          const int gq = (wco * WM) / 8 + i * 2 + (pp >> 1);
+          const unsigned char* ad = a + r * (CO * 2) + ((SWA ? (gq ^ wswz<GA>(r)) : gq) * 16) + (pp & 1) * 8;
           va[i][h] = lds_tr_read(ad);
         }
       }
@@ -197,8 +209,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r = ks * 32 + 8 * grp + 4 * h + qq;
-          const int gq = (wave * WN) / 8 + j * 2 + (pp >> 1);
-          const unsigned char* bd = b + r * (NCOL * 2) + ((SWB ? (gq ^ wswz(r)) : gq) * 16) + (pp & 1) * 8;
+          const int gq = (wcol * WN) / 8 + j * 2 + (pp >> 1);
+          const unsigned char* bd = b + r * (NCOL * 2) + ((SWB ? (gq ^ wswz<GB>(r)) : gq) * 16) + (pp & 1) * 8;
           vb[j][h] = lds_tr_read(bd);
         }
       }
@@ -234,8 +246,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
     for (int j = 0; j < JB; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
-        const int col = n0 + wave * WN + j * 16 + (lane & 15);
+        const int co = co0 + wco * WM + i * 16 + (lane >> 4) * 4 + r;
+        const int col = n0 + wcol * WN + j * 16 + (lane & 15);
         if (co < g.K && col < g.ncols) atomicAdd(&dw[(long)co * g.ncols + col], acc[i][j][r]);
       }
 }
@@ -271,12 +283,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
 }
 
-template <int CO, int NCOL>
+template <int CO, int NCOL, int WCO = 1>
 static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipStream_t st) {
   g.co_tiles = (g.K + CO - 1) / CO;
   g.col_tiles = (g.ncols + NCOL - 1) / NCOL;
   const long tiles = (long)g.co_tiles * g.col_tiles;
-  long want = (768 + tiles - 1) / tiles;                  // ~3 blocks per CU overall
+  long target = (CO + NCOL) > 128 ? 512 : 768;            // blocks overall: 2 per CU with the 68-KB 128 x 128 tile, ~3 otherwise
+  if (const char* f = getenv("MSCL_WGRAD_TARGET")) { if ((CO + NCOL) > 128 && atoi(f) > 0) target = atoi(f); }   // tuning aid
+  long want = (CO + NCOL) > 128 ? (target / tiles > 0 ? target / tiles : 1) : (target + tiles - 1) / tiles;
   long maxs = (g.M + 255) / 256;                          // at least 4 steps per block
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -284,7 +298,7 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   g.per_split = (int)per;
   g.splits = (int)((g.M + per - 1) / per);
   const size_t lds = (size_t)2 * 64 * (CO + NCOL) * 2 + (size_t)8 * 64 * sizeof(int2);
-  auto kern = conv_wgrad_kernel<CO, NCOL>;
+  auto kern = conv_wgrad_kernel<CO, NCOL, WCO>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -297,6 +311,18 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
 
 int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                       hipStream_t st);           // conv_wgrad_halo.hip
+
+// 128 x 128 tile, 2 x 2 waves of 64 x 64: per 64-position step a wave makes 16 transposing reads for 16 MFMAs (the 64 x 64
+// tile with the columns split four ways makes 10 for 4 and asks the LDS for 320 B/clk), and a block stages 32 KB for 128
+// MFMAs instead of 16 KB for 32.  MSCL_WGRAD_TILE=64 / 128 forces the choice.
+static bool big_tile(const mscl_conv_desc* d) {
+  if (d->K < 128 || d->C < 64) return false;
+  if (const char* f = getenv("MSCL_WGRAD_TILE")) return atoi(f) == 128;
+  // measured (us, 64 -> 128 tile): 50176 positions x 27 taps 110 -> 86 (128 ch), 65 -> 57 (64 -> 128 ch, stride 2); 6272 positions
+  // 58 -> 56; but 9-tap / 1-tap layers and maps of a few thousand positions lose (too few tiles to split over): 44 -> 47, 24 -> 32
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  return M >= 16384 && (long)d->kT * d->kH * d->kW * d->C >= 1728;
+}
 
 extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
                                  float* dbias, float* ws, int64_t ws_floats, void* stream) {
@@ -320,6 +346,7 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   bool wide = false;     // NCOL = 192 (three taps share one dy tile) measured slower than 64: fewer blocks per CU
   if (const char* f = getenv("MSCL_WGRAD_NCOL")) wide = atoi(f) == 192;
   if (hres == 1) e = 0;
+  else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st);
   else if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st) : launch_w<64, 64>(g, x, dy, dw, st);
   else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st) : launch_w<32, 64>(g, x, dy, dw, st);
   else if (d->K == 16) e = wide ? launch_w<16, 192>(g, x, dy, dw, st) : launch_w<16, 64>(g, x, dy, dw, st);
