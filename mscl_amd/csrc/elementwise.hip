@@ -39,6 +39,39 @@ extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, in
   return 0;
 }
 
+// ---------------------------------------------------------------- W-pairing of a packed 3-channel clip (RGB stem)
+// (rows, W, 8) -> (rows, W/2 + 1, 8): pair j holds pixels w = 2j - 1 and 2j of its row as channels [3p + c] (p = 0, 1; channels
+// 6, 7 zero; pixels outside the row zero).  A 7-wide stride-2 pad-3 convolution along W over 3 (padded to 8) channels is then
+// a 4-wide stride-1 pad-1 convolution over the pairs -- kw = 2j' + p -- with the SAME outputs: 4 x 8 = 32 reduction slots per
+// (kt, kh) instead of 7 x 8 = 56, 21 of them live either way.  The stem's implicit GEMM shrinks from K = 1176 to 672.
+__global__ __launch_bounds__(256) void pair_w_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long rows, int W, int Wp) {
+  const long total = rows * Wp;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / Wp; const int j = (int)(e - r * Wp);
+    const int w0 = 2 * j - 1, w1 = 2 * j;
+    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+    if (w0 >= 0) a = *reinterpret_cast<const uint4*>(x + (r * W + w0) * 8);
+    if (w1 < W) b = *reinterpret_cast<const uint4*>(x + (r * W + w1) * 8);
+    // bf16 channels: a = [a0 a1 | a2 .. ], b likewise; out = [a0 a1 | a2 b0 | b1 b2 | 0 0]
+    uint4 o;
+    o.x = a.x;
+    o.y = (a.y & 0xFFFFu) | (b.x << 16);
+    o.z = (b.x >> 16) | (b.y << 16);
+    o.w = 0u;
+    *reinterpret_cast<uint4*>(out + e * 8) = o;
+  }
+}
+extern "C" int mscl_pair_w(const uint16_t* x, uint16_t* out, int64_t rows, int W, void* stream) {
+  if (!x || !out || rows <= 0 || W <= 0) return MSCL_E_ARG;
+  if (W % 2) return MSCL_E_SHAPE;
+  const int Wp = W / 2 + 1;
+  const long total = rows * Wp;
+  long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pair_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)rows, W, Wp);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- optical flow (u, v) -> colour wheel image
 // ref: common/ssl_aug.py:87-136 (flow_uv_to_colors / FlowVisualizer), colour wheel tools/RAFT/core/utils/flow_viz.py:19-68.
 // The reference mixes precisions and this kernel follows it operation by operation: radius, angle and the wheel
@@ -380,10 +413,23 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const long base = (long)blockIdx.x * inner * C;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int r = tr; r < inner; r += RP) {
-    float f[8]; unpack8(*reinterpret_cast<const uint4*>(x + base + (long)r * C + tg * 8), f);
+  // eight rows in flight per thread: with one, the 8-block launch over the layer-4 map (98 rows x 512 channels per clip, on
+  // the way into the projection head of every chain) was 25 dependent round trips = 40 us for 0.8 MB
+  constexpr int UNR = 8;
+  for (int r0 = tr; r0 < inner; r0 += RP * UNR) {
+    uint4 v[UNR];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] += f[i];
+    for (int u = 0; u < UNR; ++u) {
+      const int r = r0 + u * RP;
+      v[u] = *reinterpret_cast<const uint4*>(x + base + (long)(r < inner ? r : r0) * C + tg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (r0 + u * RP >= inner) break;
+      float f[8]; unpack8(v[u], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
   }
   block_channel_sum(s, red, G, C, 1, 0);
   __syncthreads();

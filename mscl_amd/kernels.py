@@ -182,6 +182,28 @@ def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None):
     return out
 
 
+def pair_w(x):
+    """(B,T,H,W,8) packed 3-channel clip -> (B,T,H,W/2+1,8): pixel pairs along W as channels (RGB stem, see mscl_pair_w)"""
+    B, T, H, W, C = x.shape
+    if C != 8 or W % 2:
+        raise lib.MsclError(f'pair_w needs (B,T,H,even W,8), got {tuple(x.shape)}')
+    out = torch.empty((B, T, H, W // 2 + 1, 8), dtype=torch.bfloat16, device=x.device)
+    call('mscl_pair_w', ptr(x), ptr(out), B * T * H, W, stream_ptr())
+    return out
+
+
+def pair_w_weight(w, w8):
+    """w physical (Cout,kT,kH,7,3) -> w8 (Cout,kT,kH,4,8): w8[..., j, 3p + c] = w[..., 2j + p, c]"""
+    w8[..., :, 0:3].copy_(w[..., 0::2, :])
+    w8[..., 0:3, 3:6].copy_(w[..., 1::2, :])
+
+
+def pair_w_grad_fold(dw8, g):
+    """inverse of pair_w_weight for the gradient staging buffer: g (Cout,kT,kH,7,3) += the 21 live slots of dw8"""
+    g[..., 0::2, :].add_(dw8[..., :, 0:3])
+    g[..., 1::2, :].add_(dw8[..., 0:3, 3:6])
+
+
 AUG_PARAMS = 16          # floats per sample in the colour-augmentation parameter rows (include/mscl_hip.h)
 
 

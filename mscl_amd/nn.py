@@ -7,6 +7,7 @@ never travel through autograd: kernels accumulate them straight into the flat gr
 (mscl_amd/arena.py), so a fused block is one graph node.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -30,7 +31,7 @@ def _need_gpu(t):
 class Conv3dHip(nn.Module):
     """Parameter holder + kernel front-end for nn.Conv3d (state-dict: `weight` (Cout,Cin,kT,kH,kW), `bias`)."""
 
-    def __init__(self, cin, cout, kernel, stride=1, padding=0, bias=False):
+    def __init__(self, cin, cout, kernel, stride=1, padding=0, bias=False, pair_w=False):
         super().__init__()
         self.in_channels, self.out_channels = cin, cout
         self.kernel_size, self.stride, self.padding = _triple(kernel), _triple(stride), _triple(padding)
@@ -38,6 +39,14 @@ class Conv3dHip(nn.Module):
         self.bias = nn.Parameter(torch.empty(cout)) if bias else None
         self.cin_eff = cin if cin % 8 == 0 else 8
         self.taps = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        # W-paired execution of a 3-channel (kT,kH,7) / stride-2 / pad-3 stem (kernels.pair_w): the kernels see a
+        # (kT,kH,4) / stride-1 / pad-1 convolution over pixel pairs; state dict and results are unchanged
+        self.pair_w = bool(pair_w)
+        if self.pair_w and not (cin == 3 and self.kernel_size[2] == 7 and self.stride[2] == 2 and self.padding[2] == 3):
+            raise ValueError('pair_w covers the 3-channel 7-wide stride-2 pad-3 stem only')
+        self.k_exec = (self.kernel_size[0], self.kernel_size[1], 4) if self.pair_w else self.kernel_size
+        self.s_exec = (self.stride[0], self.stride[1], 1) if self.pair_w else self.stride
+        self.p_exec = (self.padding[0], self.padding[1], 1) if self.pair_w else self.padding
         self._rt = None           # runtime views, set by materialize()
         self._plans = {}          # per input shape: cached descriptor / workspace size (cba_fwd)
         self._descs = {}
@@ -48,7 +57,7 @@ class Conv3dHip(nn.Module):
     def desc(self, x_shape):
         d = self._descs.get(tuple(x_shape))
         if d is None:
-            d = K.conv_desc(tuple(x_shape), self.out_channels, self.kernel_size, self.stride, self.padding)
+            d = K.conv_desc(tuple(x_shape), self.out_channels, self.k_exec, self.s_exec, self.p_exec)
             self._descs[tuple(x_shape)] = d
         return d
 
@@ -174,6 +183,7 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
 # Weight gradients are leaves of the backward dependency chain (only the input gradient feeds the next layer), so
 # the convs whose backward runs on a stream registered here launch their wgrad kernel on the paired side stream:
 # the dgrad / BN-backward chain no longer waits for them.  {stream handle: side torch.cuda.Stream}
+PAIR_STEM = os.environ.get('MSCL_PAIR_STEM', '1') != '0'     # RGB stem on W-paired input (kernels.pair_w): K 1176 -> 672
 WGRAD_SIDE = {}
 
 
@@ -210,10 +220,16 @@ def _bucket_done(mod):
         red.bucket_done(i)
 
 
+def stem_input(conv, x):
+    """the packed clip as the stem's kernels read it: pixel pairs along W for a pair_w stem (one 3-us pass)"""
+    return K.pair_w(x) if conv.pair_w else x
+
+
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, stem):
         conv, bn = stem[0], stem[1]
+        x = stem_input(conv, x)
         y, out, save = cba_fwd(conv, bn, x, None, True)
         ctx.stem = stem
         ctx.save_for_backward(x, y, out, save)
@@ -227,7 +243,10 @@ class _StemFn(torch.autograd.Function):
         fl = conv._rt.get('dw8_flush')
         if fl is not None:                      # 3-channel stem: fold the 8-channel staging gradient into the arena now,
             dw8, gview, cin = fl                # so the bucket all-reduce launched below sees it
-            gview.add_(dw8[..., :cin])
+            if conv.pair_w:
+                K.pair_w_grad_fold(dw8, gview)
+            else:
+                gview.add_(dw8[..., :cin])
             dw8.zero_()
         _bucket_done(ctx.stem)
         return None, None, None
@@ -303,7 +322,8 @@ class VideoResNetHip(nn.Module):
         self.kind = kind
         if kind == 'rgb':
             base, kernel, pad = 64, (3, 3, 3), (1, 1, 1)
-            self.stem = nn.Sequential(Conv3dHip(3, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)), BatchNorm3dHip(64), nn.ReLU(inplace=True))
+            self.stem = nn.Sequential(Conv3dHip(3, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), pair_w=PAIR_STEM), BatchNorm3dHip(64),
+                                      nn.ReLU(inplace=True))
             st = lambda s: (s, s, s)
         elif kind == 'flow':
             base, kernel, pad = 16, (1, 3, 3), (0, 1, 1)
@@ -334,7 +354,7 @@ class VideoResNetHip(nn.Module):
     @torch.no_grad()
     def forward_eval(self, x):
         """the same trunk with BatchNorm in evaluation mode (running statistics); no autograd graph"""
-        x = cba_eval(self.stem[0], self.stem[1], x, None, True)
+        x = cba_eval(self.stem[0], self.stem[1], stem_input(self.stem[0], x), None, True)
         outs = []
         for li in range(1, 5):
             for blk in getattr(self, f'layer{li}'):

@@ -444,15 +444,18 @@ class MSCLWithAug(nn.Module):
                 if not key:
                     rt['dw'] = ar.packed('G', sw)
             else:       # 3-channel stems: zero-padded 8-channel shadow (and padded gradient staging)
-                w8 = torch.zeros((m.out_channels, *m.kernel_size, 8), dtype=torch.bfloat16, device=dev)
+                w8 = torch.zeros((m.out_channels, *m.k_exec, 8), dtype=torch.bfloat16, device=dev)
                 rt['w'] = w8
                 src = ar.packed(P, sw)
 
-                def refresh(w8=w8, src=src, cin=m.in_channels):
-                    w8[..., :cin].copy_(src)
+                def refresh(w8=w8, src=src, cin=m.in_channels, pair=m.pair_w):
+                    if pair:
+                        K.pair_w_weight(src, w8)
+                    else:
+                        w8[..., :cin].copy_(src)
                 (rec._k_refresh if key else rec._q_refresh).append(refresh)
                 if not key:
-                    dw8 = torch.zeros((m.out_channels, *m.kernel_size, 8), dtype=torch.float32, device=dev)
+                    dw8 = torch.zeros((m.out_channels, *m.k_exec, 8), dtype=torch.float32, device=dev)
                     rt['dw'] = dw8
                     rt['dw8_flush'] = (dw8, ar.packed('G', sw), m.in_channels)
             if not key and m.cin_eff == m.in_channels:

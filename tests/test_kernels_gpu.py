@@ -103,6 +103,36 @@ def test_conv_fwd_dgrad_wgrad(case, dev):
     close(dw, 2 * wr.grad, F32_TOL, 'conv wgrad accumulate')
 
 
+def test_stem_w_paired_equals_plain_stem(dev):
+    """RGB stem (r3d.py:176-184: Conv3d(3,64,(3,7,7),(1,2,2),(1,3,3))) run on W-paired input (mscl_pair_w): same outputs,
+    same weight gradient after folding the paired staging buffer back to (64,3,7,7,3)"""
+    from mscl_amd import kernels as K_
+    N, T, H, W, Co = 2, 4, 20, 24, 64
+    x3 = bf(rnd((N, T, H, W, 3), 1)); w = bf(rnd((Co, 3, 7, 7, 3), 2, scale=(2.0 / (3 * 147)) ** 0.5))      # physical (Cout,kT,kH,kW,Cin)
+    x8 = torch.zeros((N, T, H, W, 8), dtype=torch.bfloat16); x8[..., :3] = x3
+    xr = x3.float().requires_grad_(True); wr = w.float().requires_grad_(True)
+    yr = _conv_ref(xr, wr, (1, 2, 2), (1, 3, 3))
+    xp = K_.pair_w(x8.to(dev))
+    assert tuple(xp.shape) == (N, T, H, W // 2 + 1, 8)
+    exp = torch.zeros((N, T, H, W // 2 + 1, 2, 3), dtype=torch.bfloat16)         # pair j = pixels 2j-1, 2j
+    exp[:, :, :, 1:, 0] = x3[:, :, :, 1::2]; exp[:, :, :, :-1, 1] = x3[:, :, :, 0::2]
+    assert torch.equal(xp.cpu()[..., :6], exp.reshape(N, T, H, W // 2 + 1, 6)) and not xp.cpu()[..., 6:].any()
+    w8 = torch.zeros((Co, 3, 7, 4, 8), dtype=torch.bfloat16, device=dev)
+    K_.pair_w_weight(w.to(dev), w8)
+    d = K_.conv_desc(tuple(xp.shape), Co, (3, 7, 4), (1, 2, 1), (1, 3, 1))
+    st = torch.zeros((K_.STAT_SLOTS, 2, Co), device=dev)
+    y = K_.conv3d_fwd(xp, w8, d, stats=(st[0, 0], st[0, 1]))
+    close(y, yr, BF16_TOL, 'paired stem fwd')
+    close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'paired stem bn sum')
+    dy = bf(rnd(tuple(yr.shape), 5)); yr.backward(dy.float())
+    dw8 = torch.zeros((Co, 3, 7, 4, 8), dtype=torch.float32, device=dev)
+    K_.conv3d_wgrad(xp, dy.to(dev), d, dw8, None)
+    g = torch.zeros((Co, 3, 7, 7, 3), dtype=torch.float32, device=dev)
+    K_.pair_w_grad_fold(dw8, g)
+    close(g, wr.grad, F32_TOL, 'paired stem wgrad')
+    assert float(dw8[..., 6:].abs().max()) == 0.0          # (slot j = 3, p = 1 is kw = 7: real pixels, no kernel column -- dropped by the fold)
+
+
 @pytest.mark.parametrize('C,relu,resmode', [(64, True, 'none'), (64, True, 'identity'), (128, True, 'bn'),
                                             (16, False, 'none'), (32, True, 'identity'), (512, True, 'bn')])
 def test_bn_act_fwd_bwd(C, relu, resmode, dev):

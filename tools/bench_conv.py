@@ -19,6 +19,7 @@ SHAPES = [
     ('l4_256_512_s2', (8, 4, 14, 14, 256), 512, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     ('l4_512_512', (8, 2, 7, 7, 512), 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('stem_rgb', (8, 16, 112, 112, 8), 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)),
+    ('stem_rgb_pairw', (8, 16, 112, 57, 8), 64, (3, 7, 4), (1, 2, 1), (1, 3, 1)),     # the same stem on W-paired input (kernels.pair_w)
     ('sepc_128', (8, 8, 28, 28, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('fpn_133', (8, 8, 28, 28, 128), 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('neck_lat_l3', (8, 4, 14, 14, 256), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
