@@ -582,11 +582,17 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   g.ksplit = 1;
   const long out_elems = (long)g.N * g.Tr * g.Hr * g.Wr * g.Cr;
   if (ws != nullptr && blocks <= 256 && nk >= 32) {           // too few tiles for 256 CUs and a long K loop
-    long want = (512 + blocks - 1) / blocks;
-    if (want > nk / 8) want = nk / 8;
+    // measured on the 6272- and 784-position layers (tools/sweep_ksplit.sh): one round of <= 2 blocks per CU beats more
+    // splits (98 tiles x 6 = 588 blocks ran 52 us, x 4 = 392 blocks 44 us), and a block wants >= 12 K steps
+    long want = 448 / blocks;
+    if (want > nk / 12) want = nk / 12;
     if (want > 16) want = 16;
     if (want * out_elems > ws_floats) want = ws_floats / out_elems;
     if (want > 1) g.ksplit = (int)want;
+  }
+  if (const char* f = getenv("MSCL_IGEMM_KSPLIT")) {        // tuning aid
+    long want = atoi(f);
+    if (ws != nullptr && want >= 1 && want <= nk && want * out_elems <= ws_floats) g.ksplit = (int)want;
   }
   float* partial = g.ksplit > 1 ? ws : nullptr;
   bool launched = false;
@@ -656,6 +662,9 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   const bool can_split = ws != nullptr;
   if (bk64) {
     if (Cr >= 128) {
+      // a few dozen 128 x 128 tiles (784-position maps): 64-row tiles double the tiles per split, so fewer fp32 slabs
+      // make the same number of blocks (512 -> 512 3x3x3 on 784 positions: 34 -> 32 us, 128 -> 128 on 6272: 30 -> 25 us)
+      if (can_split && g.nclass == 0 && blocks(128, 128) <= 64) GO(64, 128, 64, 2, 2);
       if (blocks(128, 128) >= 384 || can_split) GO(128, 128, 64, 2, 2);
       GO(64, 128, 64, 2, 2);
     }
