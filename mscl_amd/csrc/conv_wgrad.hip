@@ -289,7 +289,8 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   g.col_tiles = (g.ncols + NCOL - 1) / NCOL;
   const long tiles = (long)g.co_tiles * g.col_tiles;
   long target = (CO + NCOL) > 128 ? 512 : 768;            // blocks overall: 2 per CU with the 68-KB 128 x 128 tile, ~3 otherwise
-  if (const char* f = getenv("MSCL_WGRAD_TARGET")) { if ((CO + NCOL) > 128 && atoi(f) > 0) target = atoi(f); }   // tuning aid
+  if (g.C <= 8) target = 2048;                            // stems: 16-byte gathers per position, the DMA latency wants more waves (95 -> 81 us)
+  if (const char* f = getenv("MSCL_WGRAD_TARGET")) { if (atoi(f) > 0) target = atoi(f); }   // tuning aid
   long want = (CO + NCOL) > 128 ? (target / tiles > 0 ? target / tiles : 1) : (target + tiles - 1) / tiles;
   long maxs = (g.M + 255) / 256;                          // at least 4 steps per block
   if (want > maxs) want = maxs;
