@@ -98,11 +98,14 @@ int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn,
                     uint16_t* out, int64_t rows, int C, float eps, float momentum, int relu, void* stream);
 
 /* backward of the above.  dz = dout * (out > 0 if relu).  Pass 1 reduces dgamma/dbeta (accumulated
- * into the fp32 gradient buffers, caller-zeroed) and keeps the two sums in `scratch` (4*C floats,
- * caller-zeroed); pass 2 writes dy (and dres: dz itself for an identity residual, the BN input
- * gradient for a normalised residual). */
+ * into the fp32 gradient buffers, caller-zeroed) and keeps the sums in `scratch` (MSCL_STAT_SLOTS * 4*C
+ * floats, caller-zeroed: blocks spread their partial sums over the slots); pass 2 writes dy (and dres: dz itself for an identity residual, the BN input
+ * gradient for a normalised residual).
+ * beta (optional; only with relu and no residual of either kind): the ReLU mask is recomputed as
+ * gamma*invstd*(y - mean) + beta > 0, the forward's own arithmetic, and `out` is not read (may be NULL):
+ * one map less per pass for the conv1 / stem BatchNorms (r3d.py:116-118, :176-184). */
 int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y,
-                    const float* gamma, const float* save_mean, const float* save_invstd,
+                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                     float* dgamma, float* dbeta,
                     const uint16_t* res_y, const float* res_gamma, const float* res_mean, const float* res_invstd,
                     float* res_dgamma, float* res_dbeta,

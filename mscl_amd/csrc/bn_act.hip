@@ -126,16 +126,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ inv, const bf16_t* __restrict__ ry,
     const float* __restrict__ rmean, const float* __restrict__ rinv, float* __restrict__ scratch, long rows, int C,
-    int relu) {
+    int relu, const float* __restrict__ gamma, const float* __restrict__ beta) {
   extern __shared__ float sm[];     // red[3][4 waves][C]
   const int G = C >> 3;             // threads per row; 256 % G == 0 required (C/8 power of two)
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const int c0 = tg * 8;
-  float mu[8], iv[8], rmu[8], riv[8];
+  float mu[8], iv[8], rmu[8], riv[8], msc[8], msh[8];
+  // beta != NULL (no residual): the ReLU mask is recomputed as bn(y) > 0 with the forward's own arithmetic instead of being
+  // read back from `out` -- one of the three maps of this pass
+  const bool mask_y = relu && beta != nullptr;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     mu[i] = mean[c0 + i]; iv[i] = inv[c0 + i];
     rmu[i] = ry ? rmean[c0 + i] : 0.f; riv[i] = ry ? rinv[c0 + i] : 0.f;
+    msc[i] = mask_y ? gamma[c0 + i] * iv[i] : 0.f;
+    msh[i] = mask_y ? beta[c0 + i] - mu[i] * msc[i] : 0.f;
   }
   float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // UNR rows per trip, every load issued before the first use: the loop is latency-bound (a thread makes only ~12
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       const long o = (r < rows ? r : r0) * C + c0;          // clamped: the duplicate is masked out below
       vd[u] = *reinterpret_cast<const uint4*>(dout + o);
       vy[u] = *reinterpret_cast<const uint4*>(y + o);
-      if (relu) va[u] = *reinterpret_cast<const uint4*>(out + o);
+      if (relu && !mask_y) va[u] = *reinterpret_cast<const uint4*>(out + o);
       if (ry) vr[u] = *reinterpret_cast<const uint4*>(ry + o);
     }
 #pragma unroll
@@ -159,7 +164,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       float d[8], a[8], yy[8];
       unpack8(vd[u], d);
       unpack8(vy[u], yy);
-      if (relu) {
+      if (mask_y) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = (yy[i] * msc[i] + msh[i]) > 0.f ? d[i] : 0.f;
+      } else if (relu) {
         unpack8(va[u], a);
 #pragma unroll
         for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
@@ -184,7 +192,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const int vv = i / C, c = i % C;
     float t = 0.f;
     for (int w = 0; w < 4; ++w) t += sm[(vv * 4 + w) * C + c];
-    atomicAdd(&scratch[i], t);
+    // 16 slots: with one, the 1024 blocks of the layer-1 map each ended on the same 128 addresses, and same-address float
+    // atomics serialise in L2 at ~25 ns apiece -- a 25-us tail on a 45-us pass
+    atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_SLOTS) * 4 * C + i], t);
   }
 }
 
@@ -195,18 +205,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ ry, const float* __restrict__ rgamma, const float* __restrict__ rmean,
     const float* __restrict__ rinv, const float* __restrict__ scratch, bf16_t* __restrict__ dy,
     bf16_t* __restrict__ dres, int identity_dres, long rows, int C, int relu,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rdgamma, float* __restrict__ rdbeta) {
-  extern __shared__ float sm[];   // k0[C] (gamma*inv), k1[C] (mean), k2[C] (inv), a[C], b[C]; then res: 5*C more
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rdgamma, float* __restrict__ rdbeta,
+    const float* __restrict__ beta) {
+  extern __shared__ float sm[];   // k0[C] (gamma*inv), k1[C] (mean), k2[C] (inv), a[C], b[C]; then res: 4*C more; mask shift[C]
   float* gi = sm; float* mu = sm + C; float* iv = sm + 2 * C; float* ca = sm + 3 * C; float* cb = sm + 4 * C;
   float* rgi = sm + 5 * C; float* rmu = sm + 6 * C; float* riv = sm + 7 * C; float* rcb = sm + 8 * C;
+  float* msh = sm + 9 * C;        // mask from y: bn(y) = y * gi + msh  (see the reduce pass)
+  const bool mask_y = relu && beta != nullptr;
   const float inv_n = 1.f / (float)rows;
   for (int c = threadIdx.x; c < C; c += 256) {
     gi[c] = gamma[c] * inv[c]; mu[c] = mean[c]; iv[c] = inv[c];
-    ca[c] = scratch[c] * inv_n; cb[c] = scratch[C + c] * inv_n;
-    if (ry) { rgi[c] = rgamma[c] * rinv[c]; rmu[c] = rmean[c]; riv[c] = rinv[c]; rcb[c] = scratch[2 * C + c] * inv_n; }
+    msh[c] = mask_y ? beta[c] - mean[c] * (gamma[c] * inv[c]) : 0.f;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) {
+      t0 += scratch[sl * 4 * C + c]; t1 += scratch[sl * 4 * C + C + c];
+      if (ry) t2 += scratch[sl * 4 * C + 2 * C + c];
+    }
+    ca[c] = t0 * inv_n; cb[c] = t1 * inv_n;
+    if (ry) { rgi[c] = rgamma[c] * rinv[c]; rmu[c] = rmean[c]; riv[c] = rinv[c]; rcb[c] = t2 * inv_n; }
     if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step)
-      atomicAdd(&dgamma[c], scratch[C + c]); atomicAdd(&dbeta[c], scratch[c]);
-      if (ry) { atomicAdd(&rdgamma[c], scratch[2 * C + c]); atomicAdd(&rdbeta[c], scratch[c]); }
+      atomicAdd(&dgamma[c], t1); atomicAdd(&dbeta[c], t0);
+      if (ry) { atomicAdd(&rdgamma[c], t2); atomicAdd(&rdbeta[c], t0); }
     }
   }
   __syncthreads();
@@ -218,7 +238,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     float d[8], yy[8], o8[8];
     unpack8(*reinterpret_cast<const uint4*>(dout + e * 8), d);
     unpack8(*reinterpret_cast<const uint4*>(y + e * 8), yy);
-    if (relu) {
+    if (mask_y) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[i] = (yy[i] * gi[c0 + i] + msh[c0 + i]) > 0.f ? d[i] : 0.f;
+    } else if (relu) {
       float a[8]; unpack8(*reinterpret_cast<const uint4*>(out + e * 8), a);
 #pragma unroll
       for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
@@ -244,13 +267,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y, const float* gamma,
-                               const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                               const float* beta, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                                const uint16_t* res_y, const float* res_gamma, const float* res_mean,
                                const float* res_invstd, float* res_dgamma, float* res_dbeta, uint16_t* dy,
                                uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
                                void* stream) {
   if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
-  if (relu && !out) return MSCL_E_ARG;
+  if (beta && (res_y || want_identity_dres || !relu)) return MSCL_E_ARG;     // the mask depends on the residual too: pass `out`
+  if (relu && !out && !beta) return MSCL_E_ARG;
   if (rows <= 0 || C <= 0) return MSCL_E_ARG;
   if (C % 8 || ilog2_exact(C / 8) < 0 || C > 512 || rows * (C / 8) >= (1LL << 31)) return MSCL_E_SHAPE;      // block_channel_sum needs C/8 <= 64
   if (res_y && (!res_gamma || !res_mean || !res_invstd || !res_dgamma || !res_dbeta || !dres)) return MSCL_E_ARG;
@@ -259,13 +283,13 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
   const int RP = 256 / (C / 8);
   long blocks = (rows + RP * 8 - 1) / (RP * 8); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;   // wider grids measured slower (more atomics)
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)12 * C * sizeof(float), st, dout,
-                     out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu);
+                     out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu, gamma, beta);
   MSCL_LAUNCH_CHECK();
   const long total = rows * (C / 8);
   long b2 = (total + 255) / 256; if (b2 > 2048) b2 = 2048;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)9 * C * sizeof(float), st, dout, out, y,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)10 * C * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
-                     want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta);
+                     want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -154,14 +154,15 @@ def bn_act_fwd(y, bn, residual=None, res_bn=None, relu=True, eps=1e-5, momentum=
     return out
 
 
-def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, res=None, want_identity_dres=False):
-    """res = None | dict(y=, gamma=, mean=, invstd=, dgamma=, dbeta=).  Returns (dy, dres|None)."""
+def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, res=None, want_identity_dres=False, beta=None):
+    """res = None | dict(y=, gamma=, mean=, invstd=, dgamma=, dbeta=).  Returns (dy, dres|None).
+    beta (no residual, relu): ReLU mask recomputed from y instead of read from `out`."""
     C = y.shape[-1]
     rows = y.numel() // C
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if (res is not None or want_identity_dres) else None
     r = res or {}
-    call('mscl_bn_act_bwd', ptr(dout), ptr(out), ptr(y), ptr(gamma), ptr(smean), ptr(sinv), ptr(dgamma), ptr(dbeta),
+    call('mscl_bn_act_bwd', ptr(dout), ptr(out), ptr(y), ptr(gamma), ptr(beta), ptr(smean), ptr(sinv), ptr(dgamma), ptr(dbeta),
          ptr(r.get('y')), ptr(r.get('gamma')), ptr(r.get('mean')), ptr(r.get('invstd')), ptr(r.get('dgamma')),
          ptr(r.get('dbeta')), ptr(dy), ptr(dres), int(want_identity_dres and res is None), ptr(scratch), rows, C,
          int(relu), stream_ptr())

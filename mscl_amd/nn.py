@@ -170,9 +170,9 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
     gradient (optionally fused with `dx_addend`).  Returns (dx|None, dres|None)."""
     rt = bn._rt
     C = conv.out_channels
-    scratch = K.ZEROS.take(4 * C, dout.device)
+    scratch = K.ZEROS.take(K.STAT_SLOTS * 4 * C, dout.device)
     dy, dres = K.bn_act_bwd(dout, out, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], relu, scratch,
-                            want_identity_dres=want_dres)
+                            want_identity_dres=want_dres, beta=rt['beta'] if (relu and not want_dres and y.numel() >= MASK_FROM_Y_MIN) else None)
     rt['slot_g'].touched = True
     rt['slot_b'].touched = True
     _wgrad(conv, x, dy)
@@ -184,6 +184,7 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
 # the convs whose backward runs on a stream registered here launch their wgrad kernel on the paired side stream:
 # the dgrad / BN-backward chain no longer waits for them.  {stream handle: side torch.cuda.Stream}
 PAIR_STEM = os.environ.get('MSCL_PAIR_STEM', '1') != '0'     # RGB stem on W-paired input (kernels.pair_w): K 1176 -> 672
+MASK_FROM_Y_MIN = 1 << 24    # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
 WGRAD_SIDE = {}
 
 

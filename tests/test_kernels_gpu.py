@@ -189,7 +189,7 @@ def test_bn_act_fwd_bwd(C, relu, resmode, dev):
     mask = (out.float().cpu() > 0).float() if relu else torch.ones(shape)
     z.backward(dout.float() * mask)
     dgamma = torch.zeros(C, device=dev); dbeta = torch.zeros(C, device=dev)
-    scratch = torch.zeros(4 * C, device=dev)
+    scratch = torch.zeros(K_.STAT_SLOTS * 4 * C, device=dev)
     resd = None
     if resmode == 'bn':
         rdg = torch.zeros(C, device=dev); rdb = torch.zeros(C, device=dev)
@@ -198,6 +198,15 @@ def test_bn_act_fwd_bwd(C, relu, resmode, dev):
                              res=resd, want_identity_dres=(resmode == 'identity'))
     close(dy, yr.grad, 2 * BF16_TOL, 'bn dy')
     close(dgamma, m1.weight.grad, 2e-3, 'dgamma'); close(dbeta, m1.bias.grad, 2e-3, 'dbeta')
+    if relu and resmode == 'none':          # same pass with the ReLU mask recomputed from y (no read of `out`)
+        dg2 = torch.zeros(C, device=dev); db2 = torch.zeros(C, device=dev)
+        dy2, _ = K_.bn_act_bwd(dout.to(dev), None, y.to(dev), g1, s1['sm'], s1['si'], dg2, db2, relu,
+                               torch.zeros(K_.STAT_SLOTS * 4 * C, device=dev), beta=b1)
+        # the two masks differ only where bn(y) is within bf16 rounding of 0
+        frac = (dy2.float() != dy.float()).float().mean().item()
+        assert frac < 0.02, frac
+        close(dy2, yr.grad, 3 * BF16_TOL, 'bn dy (mask from y)')
+        close(dg2, m1.weight.grad, 4e-3, 'dgamma (mask from y)'); close(db2, m1.bias.grad, 4e-3, 'dbeta (mask from y)')
     if resmode == 'identity':
         close(dres, rr.grad, BF16_TOL, 'identity dres')
     if resmode == 'bn':
