@@ -290,10 +290,19 @@ class _MSCLLossFn(torch.autograd.Function):
             K.nce_pos_bwd(Kp, pos, lse, scale, dq, inv_T)
             return loss_rows, rank, dq
 
-        # pass A: RGB queue before this step's enqueue (moco.py:484-488 snapshot; fr logits moco_head_v2.py:44,47)
+        # pass A: RGB queue before this step's enqueue (moco.py:484-488 snapshot; fr logits moco_head_v2.py:44,47).
+        # It shares nothing with passes B -> enqueue -> C on the flow queue, and this phase is a string of small launches
+        # with every other chain already joined: A runs on the (now idle) RGB-key stream beside B / C.
         rowsA = [q_rgb, q_fb] + ([q_fa] if use_aug_mx else [])
-        QA = torch.cat(rowsA, 0)
-        lossA, rankA, dA = run(rec, QA, k_rgb.repeat(len(rowsA), 1), ones.repeat(len(rowsA)))
+        main = torch.cuda.current_stream()
+        fork = model._side_stream(1) if (model.two_streams and model.loss_fork) else None
+        if fork is not None:
+            fork.wait_stream(main)
+            for tns in rowsA + [k_rgb, ones]:
+                tns.record_stream(fork)
+        with torch.cuda.stream(fork if fork is not None else main):
+            QA = torch.cat(rowsA, 0)
+            lossA, rankA, dA = run(rec, QA, k_rgb.repeat(len(rowsA), 1), ones.repeat(len(rowsA)))
         # pass B: flow queue before enqueue -> loss_cls_flow
         lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
         kg = model._kglobal
@@ -305,6 +314,10 @@ class _MSCLLossFn(torch.autograd.Function):
         lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC)
         if model.update_aug_flow:
             recf.dequeue_and_enqueue(k_fa, kg.get('fa'))
+        if fork is not None:
+            main.wait_stream(fork)                    # pass A has read the RGB queue: the enqueue below may overwrite it
+            for tns in (lossA, rankA, dA):
+                tns.record_stream(main)
         rec.dequeue_and_enqueue(k_rgb, kg.get('rgb'))
         # LMCL (local_cl_head.py:57-73): RGB frame-slot features vs [base flow | rotated flow] frames
         t = p_rgb.shape[0] // B
@@ -361,6 +374,7 @@ class MSCLWithAug(nn.Module):
         self.shuffle_mode = os.environ.get('MSCL_SHUFFLE', 'a2a')      # 'a2a' | 'gather' (shuffle-BN exchange, world size > 1)
         self._a2a = False
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
+        self.loss_fork = os.environ.get('MSCL_LOSS_FORK', '1') != '0'          # RGB-queue InfoNCE pass beside the flow-queue passes
         self.key_graphs = os.environ.get('MSCL_KEY_GRAPHS', '1') == '1'          # key branches as sub-graphs in eager steps
         self._key_graph = [KeyGraph(), KeyGraph(), KeyGraph()]                  # RGB, flow base, flow rotated
         self.query_graphs = os.environ.get('MSCL_QUERY_GRAPHS', '1') == '1'      # flow query passes (fwd + bwd) likewise
