@@ -120,10 +120,10 @@ int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y
  * along W = the horizontal flip of common/ssl_aug_v2.py:107-118 given its Bernoulli draw. */
 int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
                     const float* mean3, const float* std3, const uint8_t* flip_mask, void* stream);
-/* (rows, W, 8) bf16 packed 3-channel clip -> (rows, W/2 + 1, 8): pair j = pixels 2j-1 and 2j of the row as channels
+/* (rows, W, 8) bf16 packed 3-channel clip -> (rows, (W+1)/2 + 1, 8): pair j = pixels 2j-1 and 2j of the row as channels
  * [3p + c], zeros outside.  Turns the RGB stem (torchvision BasicStem == backbones/r3d.py:176-184: Conv3d(3, 64, (3,7,7),
  * stride (1,2,2), padding (1,3,3))) into a (3,7,4) / stride (1,2,1) / padding (1,3,1) convolution over the pairs with
- * weights w2[co][kt][kh][j][3p + c] = w[co][c][kt][kh][2j + p] (zero for kw = 7) and identical outputs.  W must be even. */
+ * weights w2[co][kt][kh][j][3p + c] = w[co][c][kt][kh][2j + p] (zero for kw = 7) and identical outputs. */
 int mscl_pair_w(const uint16_t* x, uint16_t* out, int64_t rows, int W, void* stream);
 /* optical flow (B,2,T_total,H,W) fp32 uv -> colour-wheel image, frames [t_off, t_off+T), as (B,T,H,W,8) bf16 NDHWC
  * (channels 3..7 zero): FlowVisualizer / flow_uv_to_colors of common/ssl_aug.py:87-136 with the Middlebury wheel of

@@ -40,7 +40,7 @@ extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, in
 }
 
 // ---------------------------------------------------------------- W-pairing of a packed 3-channel clip (RGB stem)
-// (rows, W, 8) -> (rows, W/2 + 1, 8): pair j holds pixels w = 2j - 1 and 2j of its row as channels [3p + c] (p = 0, 1; channels
+// (rows, W, 8) -> (rows, (W+1)/2 + 1, 8): pair j holds pixels w = 2j - 1 and 2j of its row as channels [3p + c] (p = 0, 1; channels
 // 6, 7 zero; pixels outside the row zero).  A 7-wide stride-2 pad-3 convolution along W over 3 (padded to 8) channels is then
 // a 4-wide stride-1 pad-1 convolution over the pairs -- kw = 2j' + p -- with the SAME outputs: 4 x 8 = 32 reduction slots per
 // (kt, kh) instead of 7 x 8 = 56, 21 of them live either way.  The stem's implicit GEMM shrinks from K = 1176 to 672.
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void pair_w_kernel(const bf16_t* __restrict__ 
     const long r = e / Wp; const int j = (int)(e - r * Wp);
     const int w0 = 2 * j - 1, w1 = 2 * j;
     uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-    if (w0 >= 0) a = *reinterpret_cast<const uint4*>(x + (r * W + w0) * 8);
+    if (w0 >= 0 && w0 < W) a = *reinterpret_cast<const uint4*>(x + (r * W + w0) * 8);
     if (w1 < W) b = *reinterpret_cast<const uint4*>(x + (r * W + w1) * 8);
     // bf16 channels: a = [a0 a1 | a2 .. ], b likewise; out = [a0 a1 | a2 b0 | b1 b2 | 0 0]
     uint4 o;
@@ -63,8 +63,7 @@ __global__ __launch_bounds__(256) void pair_w_kernel(const bf16_t* __restrict__ 
 }
 extern "C" int mscl_pair_w(const uint16_t* x, uint16_t* out, int64_t rows, int W, void* stream) {
   if (!x || !out || rows <= 0 || W <= 0) return MSCL_E_ARG;
-  if (W % 2) return MSCL_E_SHAPE;
-  const int Wp = W / 2 + 1;
+  const int Wp = (W + 1) / 2 + 1;          // odd W: one more (all-zero) pair so that the paired conv yields (W + 1) / 2 outputs
   const long total = rows * Wp;
   long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pair_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long)rows, W, Wp);

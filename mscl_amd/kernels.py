@@ -184,11 +184,11 @@ def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None):
 
 
 def pair_w(x):
-    """(B,T,H,W,8) packed 3-channel clip -> (B,T,H,W/2+1,8): pixel pairs along W as channels (RGB stem, see mscl_pair_w)"""
+    """(B,T,H,W,8) packed 3-channel clip -> (B,T,H,(W+1)/2+1,8): pixel pairs along W as channels (RGB stem, see mscl_pair_w)"""
     B, T, H, W, C = x.shape
-    if C != 8 or W % 2:
-        raise lib.MsclError(f'pair_w needs (B,T,H,even W,8), got {tuple(x.shape)}')
-    out = torch.empty((B, T, H, W // 2 + 1, 8), dtype=torch.bfloat16, device=x.device)
+    if C != 8:
+        raise lib.MsclError(f'pair_w needs (B,T,H,W,8), got {tuple(x.shape)}')
+    out = torch.empty((B, T, H, (W + 1) // 2 + 1, 8), dtype=torch.bfloat16, device=x.device)
     call('mscl_pair_w', ptr(x), ptr(out), B * T * H, W, stream_ptr())
     return out
 

@@ -103,20 +103,23 @@ def test_conv_fwd_dgrad_wgrad(case, dev):
     close(dw, 2 * wr.grad, F32_TOL, 'conv wgrad accumulate')
 
 
-def test_stem_w_paired_equals_plain_stem(dev):
+@pytest.mark.parametrize('W', [24, 23])
+def test_stem_w_paired_equals_plain_stem(W, dev):
     """RGB stem (r3d.py:176-184: Conv3d(3,64,(3,7,7),(1,2,2),(1,3,3))) run on W-paired input (mscl_pair_w): same outputs,
     same weight gradient after folding the paired staging buffer back to (64,3,7,7,3)"""
     from mscl_amd import kernels as K_
-    N, T, H, W, Co = 2, 4, 20, 24, 64
+    N, T, H, Co = 2, 4, 20, 64
+    Wp = (W + 1) // 2 + 1
     x3 = bf(rnd((N, T, H, W, 3), 1)); w = bf(rnd((Co, 3, 7, 7, 3), 2, scale=(2.0 / (3 * 147)) ** 0.5))      # physical (Cout,kT,kH,kW,Cin)
     x8 = torch.zeros((N, T, H, W, 8), dtype=torch.bfloat16); x8[..., :3] = x3
     xr = x3.float().requires_grad_(True); wr = w.float().requires_grad_(True)
     yr = _conv_ref(xr, wr, (1, 2, 2), (1, 3, 3))
     xp = K_.pair_w(x8.to(dev))
-    assert tuple(xp.shape) == (N, T, H, W // 2 + 1, 8)
-    exp = torch.zeros((N, T, H, W // 2 + 1, 2, 3), dtype=torch.bfloat16)         # pair j = pixels 2j-1, 2j
-    exp[:, :, :, 1:, 0] = x3[:, :, :, 1::2]; exp[:, :, :, :-1, 1] = x3[:, :, :, 0::2]
-    assert torch.equal(xp.cpu()[..., :6], exp.reshape(N, T, H, W // 2 + 1, 6)) and not xp.cpu()[..., 6:].any()
+    assert tuple(xp.shape) == (N, T, H, Wp, 8)
+    exp = torch.zeros((N, T, H, Wp, 2, 3), dtype=torch.bfloat16)                  # pair j = pixels 2j-1, 2j
+    odd, even = x3[:, :, :, 1::2], x3[:, :, :, 0::2]
+    exp[:, :, :, 1:1 + odd.shape[3], 0] = odd; exp[:, :, :, :even.shape[3], 1] = even
+    assert torch.equal(xp.cpu()[..., :6], exp.reshape(N, T, H, Wp, 6)) and not xp.cpu()[..., 6:].any()
     w8 = torch.zeros((Co, 3, 7, 4, 8), dtype=torch.bfloat16, device=dev)
     K_.pair_w_weight(w.to(dev), w8)
     d = K_.conv_desc(tuple(xp.shape), Co, (3, 7, 4), (1, 2, 1), (1, 3, 1))
