@@ -179,8 +179,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases / M0 stay scalar
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int split = bid % g.ksplit; bid /= g.ksplit;
+  // parity class (0 when nclass == 0) is the FASTEST index after the split: xcd_remap hands each XCD a contiguous run of
+  // logical ids, and with the class slowest XCD 7 got nothing but the 8-tap class (8/27 of the work on 1/8 of the chip)
+  // while XCD 0 got the 1-tap one; interleaved, the 8 classes of a tile also share their dy rows in one L2
+  int ci = 0;
+  if (g.nclass > 0) { ci = bid % g.nclass; bid /= g.nclass; }
   const int nt = bid % g.ntiles; bid /= g.ntiles;
-  const int mt = bid % g.mtiles; const int ci = bid / g.mtiles;       // parity class (0 when nclass == 0)
+  const int mt = bid;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // class geometry (dense launches: one class covering every row, identity tap list)
