@@ -674,6 +674,9 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
       GO(64, 128, 64, 2, 2);
     }
     if (Cr > 32) {
+      // strided input gradient into 64 channels: a class has 1-8 taps, i.e. 2-16 K steps of 64; half-depth steps pipeline
+      // these short loops better (97 -> 84 us on the layer-2 entry conv)
+      if (g.nclass > 0 && Cr <= 64) GO(128, 64, 32, 2, 2);
       if (blocks(128, 64) >= 384 || can_split) GO(128, 64, 64, 2, 2);   // 48 KB LDS: 3 blocks/CU
       GO(64, 64, 64, 2, 2);
     }
