@@ -1,0 +1,62 @@
+"""BASELINE.json configs[1]: the R3D-18 trunk alone (Conv3d / BatchNorm3d HIP kernels only), forward + backward on one
+(8, 3, 16, 112, 112) batch, loss = mean of the layer-4 map, eager launches on one stream.
+Prints one JSON line: clips/s, ms per iteration and the fraction of the dense bf16 MFMA peak over the whole iteration
+(algorithmic 241.3 GFLOP per clip: forward 81.39 + input gradients without the stem's + weight gradients).
+usage: python tools/bench_trunk.py [--iters N] [--warmup W]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+GFLOP_FWD_PER_CLIP = 81.39
+GFLOP_STEM_FWD_PER_CLIP = 2.832
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    a = ap.parse_args()
+    from mscl_amd import Config, build_model
+    from mscl_amd.fill import fill_module
+    from mscl_amd.synthetic import synthetic_batch
+    dev = torch.device('cuda:0')
+    B, T, H = 8, 16, 112
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    cfg.model.sup_head.t = T // 2
+    model = build_model(cfg.model)
+    fill_module(model)
+    model.materialize(dev).train()
+    x = synthetic_batch(B, T, H, H, 0, 0, device=dev)['imgs'][0]
+    trunk = model.recognizer.encoder_q
+
+    def it():
+        model.zero_grad()
+        maps = trunk(model.aug_gpu.pack_rgb(x))
+        maps[-1].float().mean().backward()
+    for _ in range(a.warmup):
+        it()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        it()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    gflop = B * (3 * GFLOP_FWD_PER_CLIP - GFLOP_STEM_FWD_PER_CLIP)
+    tf = gflop / ms
+    print(json.dumps({'metric': 'clips/sec (R3D-18 trunk fwd+bwd, 16x112^2, bs8, 1 GPU)', 'value': B / ms * 1e3, 'unit': 'clips/s',
+                      'ms_per_iter': ms, 'iters': a.iters, 'dtype': 'bf16', 'launch': 'eager, one stream',
+                      'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
+                                   'algorithmic_gflop_per_iter': gflop,
+                                   'note': 'whole iteration incl. BatchNorm passes and launch gaps, not one kernel'}}))
+
+
+if __name__ == '__main__':
+    main()
