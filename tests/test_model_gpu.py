@@ -678,6 +678,36 @@ def test_rccl_backend_single_rank_forced(dev):
     assert all(v == v for r in res for v in r.values())
 
 
+@pytest.mark.parametrize('B,T,H,W', [(3, 8, 90, 90), (2, 4, 70, 58), (1, 4, 224, 224)])
+def test_step_other_shapes(B, T, H, W, dev):
+    """Shapes that switch kernel paths: odd map widths (45 / 29 after the stem: paired stem with an odd pixel count, ragged
+    halo tiles), a batch that is not a power of two, and 224^2 clips whose layer-1 planes (W = 112) are too wide for the
+    window-resident kernels.  Losses as in the step test, gradient norm within 8 % of the fp32 oracle, queue state equal."""
+    from mscl_amd import ClipSGD, Config, build_model
+    from mscl_amd.fill import fill_module
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    Kq = 16 * B
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    batch = synthetic_batch(B, T, H, W, 0, 0)
+    out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
+    opt.zero_grad(); out['loss'].backward()
+    orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
+    torch.manual_seed(100)
+    ref = orc.train_step(batch)
+    ref['loss'].backward()
+    for k, v in ref['log_vars'].items():
+        if 'loss' in k:
+            loss_close(out['log_vars'][k], v, f'{(B, T, H, W)} {k}')
+    gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
+    gn_h = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.requires_grad and p.grad is not None)))
+    assert abs(gn_h - gn_o) <= 0.08 * gn_o, (gn_h, gn_o)
+    opt.step()
+    assert int(model.recognizer.queue_ptr) == int(orc.recognizer.queue_ptr) == B % Kq
+    assert torch.equal(model.recognizer_flow.count.cpu(), orc.recognizer_flow.count)
+
+
 def test_r3d18_single_stream_full_size(dev):
     """BASELINE.json configs[1]: the R3D-18 trunk alone, forward + backward on one (8, 3, 16, 112, 112) batch, loss = mean
     of the layer-4 map, against the oracle trunk on the host (fp32).  bf16 storage tolerances as in the step test:
