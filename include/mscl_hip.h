@@ -56,6 +56,15 @@ int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* 
 int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                      const uint16_t* addend, float* stat_sum, float* stat_sq, void* stream);
 
+/* Layer-1 input gradient (mode 1 of mscl_conv_halo64) fused with the backward REDUCE of the BatchNorm(+ReLU) that consumes
+ * it (r3d.py:116-127 run backwards: conv2's input gradient feeds bn1/relu, conv1's + the shortcut feed the previous block's
+ * bn2/relu): writes dz = (conv_transpose(dy, wT) + addend) * (bn_mask > 0) and accumulates sum(dz), sum(dz * xhat) into
+ * `scratch` ([MSCL_STAT_SLOTS][4*C] floats, zeroed; xhat = (bn_y - mean) * invstd).  Follow with mscl_bn_act_bwd(relu = 2).
+ * Returns 1 when launched, 0 when the shape is not covered (caller falls back to mscl_conv3d_dgrad + the full mscl_bn_act_bwd). */
+int mscl_conv_halo64_dgrad_bn(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT, uint16_t* dz,
+                              const uint16_t* addend, const uint16_t* bn_y, const uint16_t* bn_mask,
+                              const float* bn_mean, const float* bn_invstd, float* scratch, void* stream);
+
 /* dx = conv_transpose(dy, w) [+ addend]; wT_bf16 is the kernel re-laid out [Cin][kT][kH][kW][Cout]
  * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient. */
 int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT_bf16, uint16_t* dx,
@@ -101,6 +110,8 @@ int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn,
  * into the fp32 gradient buffers, caller-zeroed) and keeps the sums in `scratch` (MSCL_STAT_SLOTS * 4*C
  * floats, caller-zeroed: blocks spread their partial sums over the slots); pass 2 writes dy (and dres: dz itself for an identity residual, the BN input
  * gradient for a normalised residual).
+ * relu: 0 none, 1 mask by out > 0, 2 = `dout` is dz already and `scratch` already holds the sums (written by
+ * mscl_conv_halo64_dgrad_bn): only pass 2 runs (no residual in this mode).
  * beta (optional; only with relu and no residual of either kind): the ReLU mask is recomputed as
  * gamma*invstd*(y - mean) + beta > 0, the forward's own arithmetic, and `out` is not read (may be NULL):
  * one map less per pass for the conv1 / stem BatchNorms (r3d.py:116-118, :176-184). */

@@ -273,6 +273,11 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
                                uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
                                void* stream) {
   if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
+  // relu == 2: `dout` is dz already (masked by the producer) and `scratch` already holds the two sums -- the fused epilogue of
+  // mscl_conv_halo64_dgrad_bn did this pass's work; only the apply pass runs
+  const bool pre = relu == 2;
+  if (pre && (res_y || want_identity_dres || beta)) return MSCL_E_ARG;
+  if (pre) relu = 0;
   if (beta && (res_y || want_identity_dres || !relu)) return MSCL_E_ARG;     // the mask depends on the residual too: pass `out`
   if (relu && !out && !beta) return MSCL_E_ARG;
   if (rows <= 0 || C <= 0) return MSCL_E_ARG;
@@ -282,9 +287,11 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
   hipStream_t st = (hipStream_t)stream;
   const int RP = 256 / (C / 8);
   long blocks = (rows + RP * 8 - 1) / (RP * 8); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;   // wider grids measured slower (more atomics)
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)12 * C * sizeof(float), st, dout,
-                     out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu, gamma, beta);
-  MSCL_LAUNCH_CHECK();
+  if (!pre) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)12 * C * sizeof(float), st, dout,
+                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu, gamma, beta);
+    MSCL_LAUNCH_CHECK();
+  }
   const long total = rows * (C / 8);
   long b2 = (total + 255) / 256; if (b2 > 2048) b2 = 2048;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)10 * C * sizeof(float), st, dout, out, y,

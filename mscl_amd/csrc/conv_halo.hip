@@ -28,7 +28,13 @@ struct HaloGeom {
   int tiles, mode;                 // tiles per plane; mode 0 forward, 1 input gradient (taps mirrored)
   FastDiv dWp;                     // division by Wp
   FastDiv dT, dTiles;              // persistent kernel: item -> (chain, t), chain -> (n, tile)
+  int stat_stride;                 // floats between two statistics slots (2 * C: forward [slot][2][C]; 4 * C: BatchNorm-backward scratch)
 };
+
+// Input-gradient mode only: the BatchNorm(+ReLU) that consumes this gradient.  With y != NULL the epilogue writes
+// dz = (gradient + addend) * (mask > 0) instead of the gradient and accumulates sum(dz) -> stat_sum, sum(dz * xhat) -> stat_sq
+// (xhat = (y - mean) * invstd): that BatchNorm's backward reduce pass (three map reads) rides on values already in registers.
+struct HaloBn { const bf16_t* y; const bf16_t* mask; const float* mean; const float* inv; };
 
 __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
@@ -70,7 +76,7 @@ template <int NW, int BM, int RING>
 __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
-                                                             float* __restrict__ stat_sq) {
+                                                             float* __restrict__ stat_sq, const HaloBn bn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // The three source planes are visited one after the other, so TWO window slots suffice: the third plane streams into
   // the first one's slot while the second is in use.  The freed LDS holds a deeper weight ring (tiles issued RING taps
@@ -278,6 +284,49 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       for (int j = 0; j < 4; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
+  // ---- fused BatchNorm-backward reduce (input-gradient mode): acc <- dz, per-lane partial sums ----
+  const bool fused_bn = bn.y != nullptr;
+  float sl[4][4], ql[4][4];
+  if (fused_bn) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float mu[4], iv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { mu[r] = bn.mean[j * 16 + fq * 4 + r]; iv[r] = bn.inv[j * 16 + fq * 4 + r]; sl[j][r] = 0.f; ql[j][r] = 0.f; }
+      // branch-free over the position tiles (dropped rows read row 0 and are masked out below) and all loads of a channel
+      // tile issued before the first use: behind a per-row branch they ran one round trip after the other, and at one
+      // block per CU nothing covers an epilogue's latency
+      const int n = j * 16 + fq * 4;
+      uint2 av4[IM], mv4[IM], yv4[IM];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) {
+        const long ro = orow[i] < 0 ? 0 : orow[i];
+        av4[i] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + ro + n) : make_uint2(0u, 0u);
+        mv4[i] = *reinterpret_cast<const uint2*>(bn.mask + ro + n);
+        yv4[i] = *reinterpret_cast<const uint2*>(bn.y + ro + n);
+      }
+#pragma unroll
+      for (int i = 0; i < IM; ++i) {
+        const bool live = orow[i] >= 0;
+        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+        {
+          const uint2 av = av4[i];
+          v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
+          v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
+        }
+        const uint2 mv = mv4[i];
+        const uint2 yv = yv4[i];
+        const float m4[4] = {__uint_as_float(mv.x << 16), __uint_as_float(mv.x & 0xFFFF0000u), __uint_as_float(mv.y << 16), __uint_as_float(mv.y & 0xFFFF0000u)};
+        const float y4[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xFFFF0000u), __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xFFFF0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // the sums are taken over the bf16-rounded dz, the value the apply pass will read back
+          const float dz = (live && m4[r] > 0.f) ? __uint_as_float(pack2bf(v[r], 0.f) << 16) : 0.f;
+          acc[j][i][r] = dz; sl[j][r] += dz; ql[j][r] += dz * ((y4[r] - mu[r]) * iv[r]);
+        }
+      }
+    }
+  }
   // ---- epilogue: BatchNorm statistics ----
   if (stat_sum != nullptr) {
     float* red = reinterpret_cast<float*>(smem);      // [2][64]
@@ -286,10 +335,15 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      if (fused_bn) {
 #pragma unroll
-      for (int i = 0; i < IM; ++i)
+        for (int r = 0; r < 4; ++r) { s[r] = sl[j][r]; q[r] = ql[j][r]; }
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
@@ -305,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
     }
     __syncthreads();
     for (int i = tid; i < HC; i += 64 * NW) {
-      const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * HC;
+      const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * g.stat_stride;
       atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
     }
   }
@@ -316,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
     for (int j = 0; j < 4; ++j) {
       const int n = j * 16 + fq * 4;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      if (addend != nullptr) {
+      if (addend != nullptr && !fused_bn) {
         const uint2 av = *reinterpret_cast<const uint2*>(addend + orow[i] + n);
         v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
         v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
@@ -607,8 +661,31 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
 }
 
 // returns 1 if launched, 0 if the shape is not covered (caller falls back to the implicit-GEMM kernel), <0 / >0 on error
+static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
+                       const uint16_t* addend, float* ssum, float* ssq, HaloBn bn, int stat_stride, void* stream);
+
 extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream) {
+  return halo_launch(d, mode, src, w, out, addend, ssum, ssq, HaloBn{nullptr, nullptr, nullptr, nullptr}, 2 * HC, stream);
+}
+
+// Input gradient of the layer-1 convolution with the backward reduce of the BatchNorm(+ReLU) that consumes it fused into the
+// epilogue: dz = (conv_transpose(dy, w) + addend) * (bn_mask > 0) is written instead of the gradient, and
+// scratch[slot][0:C) += sum(dz), scratch[slot][C:2C) += sum(dz * (bn_y - mean) * invstd) with slot stride 4 * C -- the layout
+// mscl_bn_act_bwd keeps between its two passes, so that call then runs with relu = 2 (apply pass only).
+// Returns 1 if launched, 0 if the shape is not covered (nothing written), <0 / >0 on error.
+extern "C" int mscl_conv_halo64_dgrad_bn(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT, uint16_t* dz,
+                                         const uint16_t* addend, const uint16_t* bn_y, const uint16_t* bn_mask,
+                                         const float* bn_mean, const float* bn_invstd, float* scratch, void* stream) {
+  if (!bn_y || !bn_mask || !bn_mean || !bn_invstd || !scratch) return MSCL_E_ARG;
+  const char* e = getenv("MSCL_HALO");
+  if (e && e[0] == '0') return 0;
+  if (!(e && e[0] == '1') && d && (long)d->H * (d->W + 2) < 1024) return 0;          // as halo_enabled() in conv_igemm.hip
+  return halo_launch(d, 1, dy, wT, dz, addend, scratch, scratch + HC, HaloBn{bn_y, bn_mask, bn_mean, bn_invstd}, 4 * HC, stream);
+}
+
+static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
+                       const uint16_t* addend, float* ssum, float* ssq, HaloBn bn, int stat_stride, void* stream) {
   if (!d || !src || !w || !out) return MSCL_E_ARG;
   if (d->C != HC || d->K != HC || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
       d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
@@ -618,11 +695,12 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
   g.tiles = (d->H * g.Wp + HBM - 1) / HBM; g.mode = mode;
   g.dWp = make_fastdiv(g.Wp);
   g.dT = make_fastdiv(d->T); g.dTiles = make_fastdiv(g.tiles);
+  g.stat_stride = stat_stride;
   // opt-in: alone it is faster on the forward conv (112 vs 125-134 us: statistics once per block) and about equal on
   // the gradient (106-113 vs 112-114 us), but inside the three-stream step its 256 long-lived blocks schedule worse
   // against the other streams' kernels (785-793 vs 804-808 clip-pairs/s)
   const char* pv = getenv("MSCL_HALO_PERSIST");
-  if (pv && pv[0] == '1' && PBM + 2 * g.Wp + 2 <= NHP) {
+  if (pv && pv[0] == '1' && PBM + 2 * g.Wp + 2 <= NHP && bn.y == nullptr) {
     g.tiles = (d->H * g.Wp + PBM - 1) / PBM; g.dTiles = make_fastdiv(g.tiles);
     static int cus = 0;
     static bool attr_done_p = false;
@@ -655,15 +733,15 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
     g.tiles = (d->H * g.Wp + 127) / 128;
     const size_t lds = (size_t)2 * 256 * 128 + 2 * 64 * 128;          // 80 KB: two blocks per CU
     hipLaunchKernelGGL((conv_halo64_kernel<4, 128, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
-                       addend, ssum, ssq);
+                       addend, ssum, ssq, bn);
   } else if (w8 && w8[0] == '8') {
     const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
     hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, st, g, src, w, out,
-                       addend, ssum, ssq);
+                       addend, ssum, ssq, bn);
   } else {
     const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
     hipLaunchKernelGGL((conv_halo64_kernel<4, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
-                       addend, ssum, ssq);
+                       addend, ssum, ssq, bn);
   }
   MSCL_LAUNCH_CHECK();
   return 1;

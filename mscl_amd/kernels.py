@@ -77,6 +77,19 @@ def conv3d_dgrad(dy, wT, d, addend=None):
 WGRAD_HALO_WS = 256 * 9 * 64 * 64       # floats: per-block partial slabs of the window-resident layer-1 weight-gradient kernel
 
 
+def conv_halo64_dgrad_bn(dy, wT, d, bn_y, bn_mask, bn_mean, bn_invstd, scratch, addend=None):
+    """layer-1 input gradient with the consuming BatchNorm's backward reduce fused in: returns dz (masked gradient) or None
+    when the shape is not covered (nothing launched); sums land in `scratch` ([STAT_SLOTS][4C], zeroed)"""
+    dz = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
+    h = lib.call_raw('mscl_conv_halo64_dgrad_bn', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dz), ptr(addend), ptr(bn_y), ptr(bn_mask),
+                     ptr(bn_mean), ptr(bn_invstd), ptr(scratch), stream_ptr())
+    if h == 1:
+        return dz
+    if h == 0:
+        return None
+    raise lib.MsclError(f'mscl_conv_halo64_dgrad_bn -> {h}')
+
+
 def conv3d_wgrad(x, dy, d, dw, dbias=None):
     """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated)."""
     ws = None

@@ -34,6 +34,7 @@ _SIGS = {
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
     'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
+    'mscl_conv_halo64_dgrad_bn': [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P],
     'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],
     'mscl_weight_transpose_batched': [P, c_int, c_int, P],
@@ -119,6 +120,14 @@ def check(code, what):
 
 
 _fns = {}
+
+
+def call_raw(name, *args):
+    """the entry point's return code as is (for the few whose positive codes are not errors)"""
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    return fn(*args)
 
 
 def call(name, *args):

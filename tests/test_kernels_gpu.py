@@ -4,6 +4,8 @@ The CPU side computes in fp32 from the SAME bf16-rounded inputs, so the only dif
 accumulation order (fp32) and the final rounding of bf16 outputs: tolerance = 2^-7 relative to the
 tensor's max magnitude for bf16 outputs, 2e-4 relative for fp32 outputs (stated per test).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -134,6 +136,44 @@ def test_stem_w_paired_equals_plain_stem(W, dev):
     K_.pair_w_grad_fold(dw8, g)
     close(g, wr.grad, F32_TOL, 'paired stem wgrad')
     assert float(dw8[..., 6:].abs().max()) == 0.0          # (slot j = 3, p = 1 is kw = 7: real pixels, no kernel column -- dropped by the fold)
+
+
+@pytest.mark.parametrize('with_addend', [False, True])
+def test_halo_dgrad_with_fused_bn_reduce(with_addend, dev):
+    """mscl_conv_halo64_dgrad_bn + mscl_bn_act_bwd(relu = 2) against the separate path (mscl_conv3d_dgrad, then the full
+    two-pass mscl_bn_act_bwd) on a real layer-1 plane: same dz, same BatchNorm input gradient, same dgamma / dbeta."""
+    from mscl_amd import kernels as K_
+    N, T, H, W, C = 1, 3, 56, 56, 64
+    d = K_.conv_desc((N, T, H, W, C), C, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    dy = bf(rnd((N, T, H, W, C), 1)).to(dev)
+    w = bf(rnd((C, 3, 3, 3, C), 2, scale=(2.0 / (C * 27)) ** 0.5)).to(dev)
+    wT = torch.empty((C, 3, 3, 3, C), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(w, wT, C, 27, C)
+    add = bf(rnd((N, T, H, W, C), 3)).to(dev) if with_addend else None
+    y = bf(rnd((N, T, H, W, C), 4) * 1.5 + 0.2).to(dev)                 # the consuming BatchNorm's input (conv output) ...
+    gamma = (1 + 0.1 * rnd((C,), 5)).to(dev); beta = (0.1 * rnd((C,), 6)).to(dev)
+    f = y.float().reshape(-1, C)
+    mean = f.mean(0); inv = torch.rsqrt(f.var(0, unbiased=False) + 1e-5)
+    out = torch.relu((y.float() - mean) * inv * gamma + beta).to(torch.bfloat16)          # ... and its ReLU output (the mask)
+    # separate path
+    dx = K_.conv3d_dgrad(dy, wT, d, addend=add)
+    dg0, db0 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dyb0, dz0 = K_.bn_act_bwd(dx, out, y, gamma, mean, inv, dg0, db0, True, torch.zeros(K_.STAT_SLOTS * 4 * C, device=dev),
+                              want_identity_dres=True)
+    # fused path
+    scr = torch.zeros(K_.STAT_SLOTS * 4 * C, device=dev)
+    dz = K_.conv_halo64_dgrad_bn(dy, wT, d, y, out, mean, inv, scr, addend=add)
+    assert dz is not None, 'the layer-1 plane must be covered by the window-resident kernel'
+    assert torch.equal(dz, dz0)
+    dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dyb1, _ = K_.bn_act_bwd(dz, None, y, gamma, mean, inv, dg1, db1, 2, scr)
+    close(dyb1, dyb0, 2e-3, 'bn input gradient (fused reduce)')
+    close(dg1, dg0, 1e-4, 'dgamma (fused reduce)'); close(db1, db0, 1e-4, 'dbeta (fused reduce)')
+    # a small plane is not covered: nothing launched, caller falls back
+    d2 = K_.conv_desc((1, 2, 8, 8, C), C, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    small = torch.zeros((1, 2, 8, 8, C), dtype=torch.bfloat16, device=dev)
+    if os.environ.get('MSCL_HALO') != '1':
+        assert K_.conv_halo64_dgrad_bn(small, wT, d2, small, small, mean, inv, scr) is None
 
 
 @pytest.mark.parametrize('C,relu,resmode', [(64, True, 'none'), (64, True, 'identity'), (128, True, 'bn'),
