@@ -288,34 +288,31 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
   const bool fused_bn = bn.y != nullptr;
   float sl[4][4], ql[4][4];
   if (fused_bn) {
+    // Branch-free (dropped rows read row 0 and are masked out below) with EVERY load of the lane issued before the first use:
+    // at one block per CU nothing else covers an epilogue's latency, and bytes in flight are what its bandwidth is made of
+    // (12 loads in flight per lane read the two extra maps at 2.7 TB/s, +38 us on the layer-1 map).
+    uint2 av4[4][IM], mv4[4][IM], yv4[4][IM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i) {
+        const long ro = (orow[i] < 0 ? 0 : orow[i]) + j * 16 + fq * 4;
+        av4[j][i] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + ro) : make_uint2(0u, 0u);
+        mv4[j][i] = *reinterpret_cast<const uint2*>(bn.mask + ro);
+        yv4[j][i] = *reinterpret_cast<const uint2*>(bn.y + ro);
+      }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float mu[4], iv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { mu[r] = bn.mean[j * 16 + fq * 4 + r]; iv[r] = bn.inv[j * 16 + fq * 4 + r]; sl[j][r] = 0.f; ql[j][r] = 0.f; }
-      // branch-free over the position tiles (dropped rows read row 0 and are masked out below) and all loads of a channel
-      // tile issued before the first use: behind a per-row branch they ran one round trip after the other, and at one
-      // block per CU nothing covers an epilogue's latency
-      const int n = j * 16 + fq * 4;
-      uint2 av4[IM], mv4[IM], yv4[IM];
-#pragma unroll
-      for (int i = 0; i < IM; ++i) {
-        const long ro = orow[i] < 0 ? 0 : orow[i];
-        av4[i] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + ro + n) : make_uint2(0u, 0u);
-        mv4[i] = *reinterpret_cast<const uint2*>(bn.mask + ro + n);
-        yv4[i] = *reinterpret_cast<const uint2*>(bn.y + ro + n);
-      }
 #pragma unroll
       for (int i = 0; i < IM; ++i) {
         const bool live = orow[i] >= 0;
         float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-        {
-          const uint2 av = av4[i];
-          v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
-          v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
-        }
-        const uint2 mv = mv4[i];
-        const uint2 yv = yv4[i];
+        const uint2 av = av4[j][i], mv = mv4[j][i], yv = yv4[j][i];
+        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
+        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
         const float m4[4] = {__uint_as_float(mv.x << 16), __uint_as_float(mv.x & 0xFFFF0000u), __uint_as_float(mv.y << 16), __uint_as_float(mv.y & 0xFFFF0000u)};
         const float y4[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xFFFF0000u), __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xFFFF0000u)};
 #pragma unroll
@@ -363,6 +360,15 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
     }
   }
+  const bool plain_add = addend != nullptr && !fused_bn;
+  uint2 add4[4][IM];                                   // all of the lane's addend loads in flight at once (see the fused pass)
+  if (plain_add) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+        add4[j][i] = *reinterpret_cast<const uint2*>(addend + (orow[i] < 0 ? 0 : orow[i]) + j * 16 + fq * 4);
+  }
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
     if (orow[i] < 0) continue;
@@ -370,8 +376,8 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
     for (int j = 0; j < 4; ++j) {
       const int n = j * 16 + fq * 4;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      if (addend != nullptr && !fused_bn) {
-        const uint2 av = *reinterpret_cast<const uint2*>(addend + orow[i] + n);
+      if (plain_add) {
+        const uint2 av = add4[j][i];
         v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
         v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
       }
