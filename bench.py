@@ -41,6 +41,9 @@ def parse():
     return p.parse_args()
 
 
+HOST_THREADS = 0        # torch's default intra-op thread count, recorded by main() before it is lowered for the GPU part
+
+
 def cpu_baseline(cpu_batch):
     """oracle/ (pure-PyTorch fp32 restatement of the reference step) on the host cores.  The box shows 256 logical CPUs but a
     one-GPU job owns a share of them: with torch's default 128 threads the step ran 15.5 s, with 16 threads 1.3 s (B=4).  So the
@@ -61,8 +64,9 @@ def cpu_baseline(cpu_batch):
         opt.step()
         return time.perf_counter() - t0
     default_threads = torch.get_num_threads()
+    avail = max(HOST_THREADS, default_threads) if os.environ.get('OMP_NUM_THREADS') is None else default_threads
     env = os.environ.get('MSCL_CPU_THREADS')
-    cands = [int(env)] if env else sorted({min(n, default_threads) for n in (8, 16, 32)})
+    cands = [int(env)] if env else sorted({min(n, avail) for n in (8, 16, 32)})
     torch.set_num_threads(cands[len(cands) // 2])
     step(0)                                                    # warm-up (allocator, oneDNN primitives)
     trial = {}
@@ -89,6 +93,11 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    # the GPU path needs no CPU parallelism; 128 OpenMP workers spin-waiting beside the launching thread only cost (a one-GPU job
+    # owns ~16 cores of the box; torch.distributed.run already sets OMP_NUM_THREADS=1 for N > 1).  cpu_baseline picks its own count.
+    global HOST_THREADS
+    HOST_THREADS = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(8, HOST_THREADS)))
     forced = world == 1 and os.environ.get('MSCL_FORCE_DIST') == '1'    # diagnostic: run every collective on a 1-rank RCCL group
     if world > 1 or forced:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
