@@ -200,3 +200,34 @@ def test_stochastic_aug_draws():
         assert len(sig) > 10 and 0.1 <= float(sig[0]) <= 2.0 and bool((sig == sig[0]).all())
     weak = SyncMoCoAugmentV5(crop_size=112, t=(16, 16), stochastic=True, weak_aug=(True, False)).draw(4)
     assert float(weak['aug_params'][0].abs().sum()) == 0 and float(weak['aug_params'][1].abs().sum()) > 0
+
+
+def test_paired_stem_algebra_on_cpu():
+    """The W-pairing of the RGB stem (mscl_pair_w + kernels.pair_w_weight / pair_w_grad_fold), restated with plain torch ops:
+    Conv3d(3, 64, (3,7,7), (1,2,2), (1,3,3)) (backbones/r3d.py:176-184) == a (3,7,4) / (1,2,1) / (1,3,1) convolution over pixel
+    pairs, for even and odd widths; folding the paired weight gradient back gives the plain weight gradient."""
+    import torch.nn.functional as F
+    from mscl_amd import kernels as K
+    torch.manual_seed(3)
+    for W in (12, 13):
+        x = torch.randn(2, 3, 4, 10, W, dtype=torch.float64)                         # NCTHW
+        w = torch.randn(8, 3, 3, 7, 7, dtype=torch.float64, requires_grad=True)     # (Cout, Cin, kT, kH, kW)
+        y = F.conv3d(x, w, stride=(1, 2, 2), padding=(1, 3, 3))
+        Wp = (W + 1) // 2 + 1
+        xp = torch.zeros(2, 8, 4, 10, Wp, dtype=torch.float64)                       # channel 3p + c = pixel 2j - 1 + p
+        for j in range(Wp):
+            for p_ in range(2):
+                wpix = 2 * j - 1 + p_
+                if 0 <= wpix < W:
+                    xp[:, 3 * p_:3 * p_ + 3, :, :, j] = x[:, :, :, :, wpix]
+        w_phys = w.detach().permute(0, 2, 3, 4, 1).contiguous()                      # (Cout, kT, kH, kW, Cin) as in the arena
+        w8 = torch.zeros(8, 3, 7, 4, 8, dtype=torch.float64)
+        K.pair_w_weight(w_phys, w8)
+        w8t = w8.permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)            # (Cout, 8, kT, kH, 4)
+        yp = F.conv3d(xp, w8t, stride=(1, 2, 1), padding=(1, 3, 1))
+        assert yp.shape == y.shape and torch.allclose(yp, y, atol=1e-10)
+        g = torch.randn_like(y)
+        y.backward(g); yp.backward(g)
+        folded = torch.zeros(8, 3, 7, 7, 3, dtype=torch.float64)
+        K.pair_w_grad_fold(w8t.grad.permute(0, 2, 3, 4, 1).contiguous(), folded)
+        assert torch.allclose(folded, w.grad.permute(0, 2, 3, 4, 1), atol=1e-9)
