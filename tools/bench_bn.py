@@ -61,7 +61,7 @@ def main():
         ]
         for what, fn, maps in rows:
             us = timeit(fn, a.iters)
-            print(f'{name:18s} {what:14s} {us:7.1f} us  {maps * mb / us / 1e3 * 1e3:7.0f} GB/s ({maps} maps of {mb:.1f} MB)')
+            print(f'{name:18s} {what:14s} {us:7.1f} us  {maps * mb / us * 1e3:7.0f} GB/s ({maps} maps of {mb:.1f} MB)')
 
 
 if __name__ == '__main__':
