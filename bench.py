@@ -26,6 +26,40 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 T_FRAMES, SIDE, BATCH = 16, 112, 8
+# GFLOP (2 * MACs) of one step at B=8, T=16, 112^2, from SURVEY.md Appendix A-C's per-layer forward counts:
+#   reference step (section 8d): 3302 = (RGB trunk 651.14 + neck 145.28 + flow trunk 2 x 14.51) x (3 on the query side + 1 on the
+#   key side).  What this build EXECUTES is less: no stem input gradients (22.66 + 2 x 0.94), the key branch's pyramid is
+#   skipped (145.28: k_mlvl has no reader), and levels 1-2 of the last PConv3D are not computed (13.18 forward; they never had
+#   a backward: their gradient is None in the reference too).  step_frac prices the executed work only.
+_TRUNK, _NECK, _NECK_DEAD, _FLOW, _STEM_DG, _FSTEM_DG = 651.14, 145.28, 13.18, 14.51, 22.659, 0.944
+STEP_GFLOP_REFERENCE = 4 * (_TRUNK + _NECK + 2 * _FLOW)
+STEP_GFLOP_EXECUTED = (3 * _TRUNK - _STEM_DG) + 3 * (_NECK - _NECK_DEAD) + 2 * (3 * _FLOW - _FSTEM_DG) + 2 * _FLOW + _TRUNK
+
+
+def stage_table(events):
+    """per conv shape class of the RGB trunk: algorithmic GFLOP, summed event time and TFLOP/s for forward / input gradient /
+    weight gradient launches of the two single-stream eager steps (events: kernels.PROFILE['events'])"""
+    names = {(64, 64, 56): 'layer1 64->64 @16x56x56', (64, 128, 28): 'layer2.0.conv1 64->128 s2', (128, 128, 28): '128->128 @8x28x28 (layer2, SEPC)',
+             (128, 256, 14): 'layer3.0.conv1 128->256 s2', (256, 256, 14): 'layer3 256->256 @4x14x14',
+             (256, 512, 7): 'layer4.0.conv1 256->512 s2', (512, 512, 7): 'layer4 512->512 @2x7x7'}
+    acc = {}
+    for mode, d, e0, e1 in events:
+        N, T, H, W, C, To, Ho, Wo, K, kT, kH, kW, sT, sH, sW = d
+        if C == 8:                                  # 3-channel stems, padded (and W-paired: kW 4 stands for 7 taps)
+            name, cin, taps = ('stem rgb' if kT == 3 else 'stem flow'), 3, kT * kH * 7
+        elif kT == 3 and kH == 3 and (C, K, Ho) in names:
+            name, cin, taps = names[(C, K, Ho)], C, 27
+        else:
+            name, cin, taps = ('flow trunk' if C <= 64 and kT == 1 else 'neck / shortcuts (1x1x1, 1x3x3, small 3x3x3)'), C, kT * kH * kW
+        gf = 2.0 * N * To * Ho * Wo * K * taps * cin * 1e-9
+        a = acc.setdefault(name, {}).setdefault(mode, [0.0, 0.0, 0])
+        a[0] += gf; a[1] += e0.elapsed_time(e1); a[2] += 1
+    out = {}
+    for name, modes in acc.items():
+        out[name] = {m: {'launches': v[2], 'gflop': round(v[0], 2), 'ms': round(v[1], 4),
+                         'tflops': round(v[0] / max(v[1], 1e-9), 1), 'frac': round(v[0] / max(v[1], 1e-9) / PEAK_BF16_TFLOPS, 4)}
+                     for m, v in modes.items()}
+    return out
 
 
 def parse():
@@ -170,15 +204,15 @@ def main():
     # timed region (same kernels, same data; the timed region itself is one graph launch per step)
     # (one stream for these two steps: an event pair on one stream would otherwise also time the other streams' kernels
     #  sharing the CUs -- 154 us instead of 131 us for this launch; the in-graph average is in profiles/*kernel_stats*)
-    kernels.PROFILE_CONV = dict(sig=(BATCH, T_FRAMES, SIDE // 2, SIDE // 2, 64, 64, 3), events=[])
-    streams_were, keyg_were = model.two_streams, model.key_graphs
-    model.two_streams = model.key_graphs = False         # plain launches on one stream: events inside a capture are not timeable
+    kernels.PROFILE = dict(events=[])
+    streams_were, keyg_were, qg_were = model.two_streams, model.key_graphs, model.query_graphs
+    model.two_streams = model.key_graphs = model.query_graphs = False   # plain launches on one stream: events inside a capture are not timeable
     for i in range(2):
         eager_step(i)
     torch.cuda.synchronize()
-    model.two_streams, model.key_graphs = streams_were, keyg_were
-    prof = kernels.PROFILE_CONV
-    kernels.PROFILE_CONV = None
+    model.two_streams, model.key_graphs, model.query_graphs = streams_were, keyg_were, qg_were
+    prof = kernels.PROFILE
+    kernels.PROFILE = None
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -188,14 +222,19 @@ def main():
         raise SystemExit('loss is NaN')
 
     if rank == 0:
-        ms = [a.elapsed_time(b) for a, b in prof['events']]
+        ms = [a.elapsed_time(b) for mode, d, a, b in prof['events']
+              if mode == 'fwd' and (d[4], d[8], d[9], d[2]) == (64, 64, 3, SIDE // 2)]          # layer-1 3x3x3 64->64 forward launches
         avg_ms = sum(ms) / max(1, len(ms))
         flops = 2.0 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 27 * 64       # 88.8 GFLOP per launch
         achieved = flops / (avg_ms * 1e-3) / 1e12 if ms else 0.0
         traffic = None
-        tp = os.path.join(ROOT, 'profiles', 'r01_traffic_layer1.json')      # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
+        tname = None
+        for tname in ('r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
+            tp = os.path.join(ROOT, 'profiles', tname)
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
+                break
+        step_s = dt / args.steps
         line = {
             'metric': 'clip-pairs/sec/node (R3D-18, 16x112^2, bs8/gpu)',
             'value': world * BATCH * args.steps / dt, 'unit': 'clip-pairs/s',
@@ -214,8 +253,15 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64_kernel fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                          'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': traffic,
-                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_traffic_layer1.json)',
-                         'algorithmic_bytes': 2 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 2 + 64 * 27 * 64 * 2},
+                         'traffic_unit': f'HBM bytes per launch (rocprofv3 PMC, profiles/{tname})',
+                         'algorithmic_bytes': 2 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 2 + 64 * 27 * 64 * 2,
+                         # the whole step against the same peak: executed conv GFLOP of one step / timed step duration
+                         'step_gflop': round(STEP_GFLOP_EXECUTED, 1), 'step_gflop_reference': round(STEP_GFLOP_REFERENCE, 1),
+                         'step_tflops': STEP_GFLOP_EXECUTED * 1e-3 / step_s,
+                         'step_frac': STEP_GFLOP_EXECUTED * 1e-3 / step_s / PEAK_BF16_TFLOPS,
+                         # every conv shape class, forward / input gradient / weight gradient, from event pairs in the same two
+                         # single-stream eager steps (so the >= 0.70 target of north_star is tracked by this line)
+                         'stages': stage_table(prof['events'])},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch)

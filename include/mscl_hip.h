@@ -202,7 +202,9 @@ int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* 
  *   then mscl_nce_finish: lse, loss_r = lse - pos/T, rank_r, and probabilities' normaliser.
  * Pass 2 (mscl_nce_bwd) re-streams the queue and accumulates dq[r] = (1/T) sum_k softmax_k * W[:,k]
  * (the positive-key term is added by the caller's tiny kernel mscl_nce_pos_bwd); ws = scratch for the per-block
- * partial sums, at least ceil(K / 128) * roundup(R, 8) * dim floats. */
+ * partial sums, at least ceil(K / 128) * roundup(min(R, 32), 8) * dim floats.
+ * Any R: rows beyond 32 run as further 32-row tiles over the same snapshot (3 row groups of a per-GPU batch of 32 = 96
+ * rows); part then holds [tile][blk][rows of the tile], R * nblk * 3 floats in all. */
 int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit,
                  float* part, int R, int dim, int K, float inv_T, void* stream);
 int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank,

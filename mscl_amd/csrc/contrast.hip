@@ -185,36 +185,46 @@ __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __rest
 #define NCE_DISPATCH(RV, CALL8, CALL16, CALL24, CALL32) \
   if ((RV) <= 8) { CALL8; } else if ((RV) <= 16) { CALL16; } else if ((RV) <= 24) { CALL24; } else { CALL32; }
 
+// Row tiles: the kernels hold up to 32 query rows per block in registers; more rows (3 * B stacked row groups with a per-GPU
+// batch above 10, e.g. the shipped config's videos_per_gpu = 32) run as consecutive 32-row tiles over the same snapshot, each
+// with its own slice of `part` ([tile][blk][rows of the tile][3], tiles before the last are full) -- no limit at the ABI.
+#define NCE_ROW_TILE 32
 extern "C" int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
                             int R, int dim, int K, float inv_T, void* stream) {
   if (!queue || !count || !q || !pos_logit || !part || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
-  if (R > 32 || dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
+  if (dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
-  NCE_DISPATCH(R,
-    hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), 0, st, queue, count, q, pos_logit, part, R, dim, K, inv_T))
-  MSCL_LAUNCH_CHECK();
+  for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {
+    const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
+    const float* qt = q + (size_t)r0 * dim; const float* pt = pos_logit + r0;
+    float* part_t = part + (size_t)nblk * r0 * 3;
+    NCE_DISPATCH(Rt,
+      hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T),
+      hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T),
+      hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T),
+      hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T))
+    MSCL_LAUNCH_CHECK();
+  }
   return 0;
 }
 extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank, int R,
                                int nblk, float inv_T, void* stream) {
   if (!part || !pos_logit || !lse || !loss_rows || !rank || R <= 0 || nblk <= 0) return MSCL_E_ARG;
-  hipLaunchKernelGGL(nce_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, part, pos_logit, lse, loss_rows, rank, R, nblk, inv_T);
-  MSCL_LAUNCH_CHECK();
+  for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {
+    const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
+    hipLaunchKernelGGL(nce_finish_kernel, dim3(Rt), dim3(64), 0, (hipStream_t)stream, part + (size_t)nblk * r0 * 3, pos_logit + r0,
+                       lse + r0, loss_rows + r0, rank + r0, Rt, nblk, inv_T);
+    MSCL_LAUNCH_CHECK();
+  }
   return 0;
 }
 extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
                             float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T, void* stream) {
   if (!queue || !count || !q || !lse || !row_scale || !dq || !ws || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
-  if (R > 32 || dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
+  if (dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int rt = R <= 8 ? 8 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32));
   const int nblk = (K + NCE_COLS * NCE_BWD_CHUNKS - 1) / (NCE_COLS * NCE_BWD_CHUNKS);
-  if ((int64_t)nblk * rt * dim > ws_floats) return MSCL_E_ARG;
-  const size_t lds = ((size_t)dim * rt + (size_t)dim * NCE_WPAD + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -222,14 +232,22 @@ extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const floa
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  NCE_DISPATCH(R,
-    hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T),
-    hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, q, lse, row_scale, ws, R, dim, K, inv_T))
-  MSCL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((R * dim + 255) / 256, 32), dim3(256), 0, st, (const float*)ws, dq, nblk, rt, R, dim);
-  MSCL_LAUNCH_CHECK();
+  for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {      // the tiles share the slab workspace: they run one after the other on `st`
+    const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
+    const int rt = Rt <= 8 ? 8 : (Rt <= 16 ? 16 : (Rt <= 24 ? 24 : 32));
+    if ((int64_t)nblk * rt * dim > ws_floats) return MSCL_E_ARG;
+    const size_t lds = ((size_t)dim * rt + (size_t)dim * NCE_WPAD + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
+    const float* qt = q + (size_t)r0 * dim; const float* lt = lse + r0; const float* st_ = row_scale + r0;
+    NCE_DISPATCH(Rt,
+      hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
+      hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
+      hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
+      hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T))
+    MSCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, 32), dim3(256), 0, st, (const float*)ws,
+                       dq + (size_t)r0 * dim, nblk, rt, Rt, dim);
+    MSCL_LAUNCH_CHECK();
+  }
   return 0;
 }
 

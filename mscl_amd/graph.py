@@ -2,8 +2,9 @@
 
 Why: at ~900 kernel launches per step the eager step is host-bound (10.9 ms of Python + HIP launch calls per step on
 the host for ~10 ms of three-stream GPU work on an MI355X; how fast the host is decides the eager rate).  Everything that changes from step to step is either device state (queues, counters, parameters),
-an input copied into static buffers, or a scalar that travels through a pinned staging word (EMA momentum,
-learning rate, shuffle indices) -- so the captured graph stays valid for the whole run.
+an input copied into static buffers, or a per-step word (EMA momentum, learning rate, shuffle indices) that is uploaded
+to a fixed device address BEFORE each replay, in stream order, through a ring of pinned slots (staging.py) -- so the
+captured graph stays valid for the whole run and step n never sees the words of step n+k although the host runs ahead.
 """
 import torch
 
@@ -32,6 +33,9 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         fk = model.flow_key[0]
         model._pre_step_host(self.B)
+        model._upload_step_words()
+        optimizer.sync_lr()
+        calls = [(g, g.calls) for g in list(model._key_graph) + list(model._query_graph)]
         with torch.cuda.graph(self.graph):
             flips = self.static.get('flip_mask', (None, None))
             rows = self.static.get('aug_params', (None, None))
@@ -41,6 +45,8 @@ class GraphedStep:
             loss.backward()
             optimizer.step()
         self._restore(snap)
+        for g, n in calls:          # the capture pass walked the sub-graph holders' eager branch: not a warm-up call of theirs
+            g.calls = n
         self.loss, self.logs = loss.detach(), logs
 
     def _eager(self):
@@ -68,6 +74,7 @@ class GraphedStep:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self.model._pre_step_host(self.B)
+        self.model._upload_step_words()
         self.opt.sync_lr()
         self.graph.replay()
         self.model._post_step_host()

@@ -46,31 +46,44 @@ def new_stats(C, device):
     return ZEROS.take(STAT_SLOTS * 2 * C, device).view(STAT_SLOTS, 2, C)
 
 
-PROFILE_CONV = None      # bench.py: dict(sig=(N,T,H,W,C,K,kT), events=[]) -> event pairs around matching launches
+PROFILE = None           # bench.py: dict(events=[]) -> (mode, desc fields, event pair) around every conv launch (eager steps)
+_DESC_FIELDS = ('N', 'T', 'H', 'W', 'C', 'To', 'Ho', 'Wo', 'K', 'kT', 'kH', 'kW', 'sT', 'sH', 'sW')
+
+
+def prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def prof_end(e0, mode, d):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE['events'].append((mode, tuple(getattr(d, f) for f in _DESC_FIELDS), e0, e1))
 
 
 def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats = (sum, sumsq) fp32 K-vectors, pre-zeroed."""
     y = torch.empty(out_shape(d), dtype=torch.bfloat16, device=x.device)
     s0, s1 = stats if stats is not None else (None, None)
-    prof = PROFILE_CONV
-    timed = prof is not None and prof['sig'] == (d.N, d.T, d.H, d.W, d.C, d.K, d.kT)
-    if timed:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     ws = _splitk_ws(d.N * d.To * d.Ho * d.Wo, d.K, x.device)
+    e0 = prof_begin()
     call('mscl_conv3d_fwd', ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(addend), int(relu),
          ptr(s0), ptr(s1), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
-    if timed:
-        e1.record()
-        prof['events'].append((e0, e1))
+    prof_end(e0, 'fwd', d)
     return y
 
 
 def conv3d_dgrad(dy, wT, d, addend=None):
     dx = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
     ws = _splitk_ws(d.N * d.T * d.H * d.W, d.C, dy.device)
+    e0 = prof_begin()
     call('mscl_conv3d_dgrad', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dx), ptr(addend), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
+    prof_end(e0, 'dgrad', d)
     return dx
 
 
@@ -95,8 +108,10 @@ def conv3d_wgrad(x, dy, d, dw, dbias=None):
     ws = None
     if (d.C, d.K, d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW) == (64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1):
         ws = torch.empty((WGRAD_HALO_WS,), dtype=torch.float32, device=x.device)
+    e0 = prof_begin()
     call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
          ws.numel() if ws is not None else 0, stream_ptr())
+    prof_end(e0, 'wgrad', d)
 
 
 def weight_transpose(w, wT, Cout, taps, Cin):
@@ -359,7 +374,7 @@ def nce_backward(queue, count, q, lse, row_scale, inv_T):
     R, dim = q.shape
     dq = torch.zeros((R, dim), dtype=torch.float32, device=q.device)
     Kq = queue.shape[1]
-    ws = torch.empty(((Kq + 127) // 128) * ((R + 7) // 8 * 8) * dim, dtype=torch.float32, device=q.device)
+    ws = torch.empty(((Kq + 127) // 128) * ((min(R, 32) + 7) // 8 * 8) * dim, dtype=torch.float32, device=q.device)
     call('mscl_nce_bwd', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), ptr(ws), ws.numel(), R, dim, Kq,
          inv_T, stream_ptr())
     return dq

@@ -18,7 +18,7 @@ def global_pool(x):
 
 @NECKS.register_module()
 class BaseMoCo(nn.Module):
-    def forward(self, feats):
+    def forward(self, feats, target=None, levels=None):
         return (global_pool(feats[-1]), feats), dict()
 
     def init_weights(self):
@@ -90,10 +90,13 @@ class SEPCHip(nn.Module):
         self.in_channels = in_channels
         self.Pconvs = nn.ModuleList(PConv3DHip(in_channels[i], out_channels, stride) for i in range(Pconv_num))
 
-    def forward(self, xs):
+    def forward(self, xs, levels=None):
+        """levels: output levels the caller consumes (None = all).  Only the LAST PConv3D can drop levels: every level of an
+        earlier one feeds its successor (sepc.py:118-135).  The skipped outputs are the ones that receive no gradient in the
+        reference (`Pconvs.1.Pconv.2` has grad None), so parameter gradients are unchanged."""
         assert len(xs) == len(self.in_channels)
-        for p in self.Pconvs:
-            xs = p(xs)
+        for i, p in enumerate(self.Pconvs):
+            xs = p(xs, levels=levels if i == len(self.Pconvs) - 1 else None)
         return xs
 
 
@@ -117,9 +120,11 @@ class TPNSingleHip(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def forward(self, feats):
+    def forward(self, feats, levels=None):
         outs = self.fpn(list(feats[-self.num_tpn_stages:]))
-        return self.sepc(outs) if self.sepc is not None else outs
+        if self.sepc is not None:
+            return self.sepc(outs, levels=levels)
+        return outs if levels is None else [o if i in levels else None for i, o in enumerate(outs)]
 
 
 @NECKS.register_module()
@@ -135,11 +140,20 @@ class TPNMoCo(nn.Module):
     def init_weights(self):
         self.tpn.init_weights()
 
-    def forward(self, feats, target=None):
+    def forward(self, feats, target=None, levels=None):
+        """ref: necks/base.py:167-175.  `levels` (an MI355X-side argument, not in the reference): the pyramid levels the
+        caller reads -- () skips the pyramid altogether when the embedding comes from the backbone (`emb_from_bkb`), which
+        is the key branch of MSCL: its `k_mlvl` is never consumed (recognizers/moco.py:535-545, mscl.py:225-277), 145 GFLOP
+        per step at B=8 that change no output.  Levels not asked for come back as None."""
+        n = self.tpn.num_tpn_stages
+        if levels is not None:
+            levels = tuple(sorted({l % n for l in levels}))
         if self.emb_from_bkb:
             emb = global_pool(feats[-1])
-            outs = self.tpn(feats)
+            if levels is not None and len(levels) == 0:
+                return (emb, [None] * n), {}
+            outs = self.tpn(feats, levels=levels)
         else:
-            outs = self.tpn(feats)
+            outs = self.tpn(feats, levels=None if levels is None else tuple(sorted(set(levels) | {n - 1})))
             emb = global_pool(outs[-1])
         return (emb, outs), {}

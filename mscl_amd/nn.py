@@ -126,18 +126,12 @@ def cba_fwd(conv, bn, x, residual, relu):
     save = torch.empty((2, C), dtype=torch.float32, device=dev)
     ws = torch.empty((ws_n,), dtype=torch.float32, device=dev) if ws_n else None
     st = lib.stream_ptr()
-    prof = K.PROFILE_CONV
-    timed = prof is not None and prof['sig'] == sig
-    if timed:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = K.prof_begin()
     s_ptr = stats.data_ptr()
     lib.call('mscl_conv3d_fwd', dref, x.data_ptr(), rt['w'].data_ptr(), y.data_ptr(),
              rt['bias'].data_ptr() if rt['bias'] is not None else None, None, 0, s_ptr, s_ptr + 4 * C,
              ws.data_ptr() if ws is not None else None, ws_n, st)
-    if timed:
-        e1.record()
-        prof['events'].append((e0, e1))
+    K.prof_end(e0, 'fwd', d)
     bp = bn._bnp
     if bp is None:
         brt = bn._rt

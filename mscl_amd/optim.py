@@ -9,6 +9,7 @@ import torch
 
 from . import kernels as K
 from . import parallel
+from .staging import StagingRing
 
 
 def cosine_lr(base_lr, epoch, max_epochs, min_lr=0.0):
@@ -28,9 +29,11 @@ class ClipSGD:
         self._ranges = None
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay)]
-        # lr travels through a pinned staging word -> device word, so a captured graph sees schedule changes
-        self._lr_host = torch.full((1,), float(lr), dtype=torch.float32).pin_memory()
-        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.arena.device)
+        # lr is read from a device word, so a captured graph sees schedule changes; the word is fed through a ring of
+        # pinned slots (staging.py) so that the host, which runs steps ahead of the GPU, never rewrites a word in flight
+        self._lr = StagingRing((1,), torch.float32, self.arena.device)
+        self._lr_cpu = torch.full((1,), float(lr), dtype=torch.float32)
+        self._lr.push(self._lr_cpu)
 
     @classmethod
     def from_cfg(cls, model, optimizer, optimizer_config=None):
@@ -52,7 +55,6 @@ class ClipSGD:
     def step(self):
         ar = self.arena
         self.model.sync_streams()
-        self.model.flush_padded_grads()
         if getattr(self.model, 'reducer', None) is not None:
             self.model.reducer.finish()         # buckets were launched from backward; wait for them
         else:
@@ -64,14 +66,23 @@ class ClipSGD:
             raise RuntimeError('the set of parameters receiving gradients changed between steps')
         self._sumsq.zero_()
         K.sumsq(ar.G, self._sumsq)
-        self.sync_lr()
-        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():        # a captured step publishes before each replay (graph.py)
+            self.sync_lr()
         for a, b in ranges:     # momentum buffers start at zero: buf = mom*0 + d == torch's first-step buf = d
-            K.sgd_step_dev(ar.Q[a:b], ar.G[a:b], ar.MOM[a:b], ar.Qb[a:b], self._sumsq, self.max_norm, self._lr_dev,
+            K.sgd_step_dev(ar.Q[a:b], ar.G[a:b], ar.MOM[a:b], ar.Qb[a:b], self._sumsq, self.max_norm, self._lr.dev,
                            self.momentum, self.wd)
         self.model.refresh_after_optimizer()
         self.steps += 1
 
     def sync_lr(self):
-        """publish param_groups[0]['lr'] to the pinned staging word (call before a graph replay)"""
-        self._lr_host[0] = float(self.param_groups[0]['lr'])
+        """publish param_groups[0]['lr'] to the device word the SGD kernel reads, in stream order (eager steps: from
+        step(); captured steps: before each graph replay).  Unchanged values are not re-sent."""
+        lr = float(self.param_groups[0]['lr'])
+        if self._lr.pushes and float(self._lr_cpu[0]) == torch.tensor(lr, dtype=torch.float32).item():
+            return
+        self._lr_cpu[0] = lr
+        self._lr.push(self._lr_cpu)
+
+    @property
+    def _lr_dev(self):
+        return self._lr.dev

@@ -166,9 +166,6 @@ class Recognizer3D(nn.Module):
     def sync_streams(self):
         pass
 
-    def flush_padded_grads(self):
-        pass
-
     def load_state_dict(self, state_dict, strict=True):
         out = super().load_state_dict(state_dict, strict=strict)
         if self.arena is not None:

@@ -31,6 +31,7 @@ from .arena import ParamArena
 from .lib import MsclError
 from .nn import BatchNorm3dHip, Conv3dHip, LinearHip, VideoResNetHip, mlp_head, pool
 from .registry import RECOGNIZERS, build_head, build_neck, build_ssl_aug
+from .staging import StagingRing
 
 LOG_KEYS = ('top1_acc', 'top5_acc', 'loss_cls', 'top1_acc_flow', 'top5_acc_flow', 'loss_cls_flow', 'loss_cls_flow_aug',
             'top1_acc_mx', 'top5_acc_mx', 'loss_cls_mx', 'top1_acc_mx_r', 'top5_acc_mx_r', 'loss_cls_mx_r',
@@ -112,14 +113,17 @@ class MoCoV2(nn.Module):
         for fn in self._k_refresh:
             fn()
 
-    def encode_q(self, x):
-        emb_maps, _ = self.neck_q(self.encoder_q(x))
+    def encode_q(self, x, levels=None):
+        """levels: the q_mlvl levels the caller reads (None = all, as moco.py:517-529 returns them)"""
+        emb_maps, _ = self.neck_q(self.encoder_q(x), levels=levels)
         emb, maps = emb_maps
         return mlp_head(self.mlp_q, emb), maps
 
     @torch.no_grad()
-    def encode_k(self, x):
-        emb_maps, _ = self.neck_k(self.encoder_k(x))
+    def encode_k(self, x, levels=()):
+        """key forward (moco.py:535-545).  k_mlvl has no reader on the MSCL path once the dead unshuffle all-gathers are
+        dropped, so by default the key neck computes the embedding only."""
+        emb_maps, _ = self.neck_k(self.encoder_k(x), levels=levels)
         emb, maps = emb_maps
         return mlp_head(self.mlp_k, emb), maps
 
@@ -369,7 +373,7 @@ class MSCLWithAug(nn.Module):
         self.arena = None
         self._log_keys = LOG_KEYS
         self._step = 0
-        self._scal_host = self._scal_dev = None
+        self._scal = self._idx = self._inv = None         # staging.StagingRing: per-step words, host -> device
         self._bg = 0
         self.shuffle_mode = os.environ.get('MSCL_SHUFFLE', 'a2a')      # 'a2a' | 'gather' (shuffle-BN exchange, world size > 1)
         self._a2a = False
@@ -503,12 +507,6 @@ class MSCLWithAug(nn.Module):
                 fn()
         K.weight_transpose_batched(*self._tr_table)
 
-    @torch.no_grad()
-    def flush_padded_grads(self):
-        """the stems' 8-channel gradient staging buffers are folded into the arena inside the stem backward
-        (mscl_amd/nn.py); kept as a no-op for callers of the earlier API."""
-        return None
-
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:
             self.arena.G.zero_()
@@ -571,6 +569,7 @@ class MSCLWithAug(nn.Module):
             raise MsclError('call model.materialize("cuda") before the first step')
         fk = self.flow_key[0]
         self._pre_step_host(im_q.shape[0])
+        self._upload_step_words()
         loss, logs = self._device_step(im_q, im_k, aux_info[f'{fk}_q'], aux_info[f'{fk}_k'],
                                        aux_info.get('flip_q'), aux_info.get('flip_k'),
                                        aux_info.get('color_q'), aux_info.get('color_k'))
@@ -583,32 +582,43 @@ class MSCLWithAug(nn.Module):
         rec, recf = self.recognizer, self.recognizer_flow
         W = parallel.world_size()
         bg = B * W
-        if self._scal_host is None:
+        if self._scal is None or tuple(self._idx.dev.shape) != (18, B) or tuple(self._inv.dev.shape) != (3, bg):
+            # (re)built when the per-GPU batch or the world size changes; the values of a step are assembled in plain host
+            # tensors here and travel through rings of pinned slots in _upload_step_words (staging.py: a pinned word
+            # rewritten while its asynchronous copy is still queued hands step n the permutation of step n+k)
             dev = self.arena.device
-            self._scal_host = torch.zeros(4, dtype=torch.float32).pin_memory()
-            self._scal_dev = torch.zeros(4, dtype=torch.float32, device=dev)
-            self._idx_host = torch.zeros((18, B), dtype=torch.long).pin_memory()
-            self._idx_dev = torch.zeros((18, B), dtype=torch.long, device=dev)
-            self._inv_host = torch.zeros((3, bg), dtype=torch.long).pin_memory()      # argsort(perm): gathered keys -> global order
-            self._inv_dev = torch.zeros((3, bg), dtype=torch.long, device=dev)
+            self._scal = StagingRing((4,), torch.float32, dev)
+            self._idx = StagingRing((18, B), torch.long, dev)
+            self._inv = StagingRing((3, bg), torch.long, dev)               # argsort(perm): gathered keys -> global order
+            self._scal_cpu = torch.zeros(4, dtype=torch.float32)
+            self._idx_cpu = torch.zeros((18, B), dtype=torch.long)
+            self._inv_cpu = torch.zeros((3, bg), dtype=torch.long)
         # all-to-all split sizes change every step, so a captured graph (graph.py) switches to the all-gather formulation
         self._a2a = (not parallel.single()) and self.shuffle_mode == 'a2a'
         rec.m = momentum_at(rec.iters, rec.max_iters, rec.m_base)
         m1 = momentum_at(recf.iters, recf.max_iters, recf.m_base)
         recf.m = momentum_at(recf.iters + (bg if self.training else 0), recf.max_iters, recf.m_base)   # value after the 2nd pass
-        self._scal_host[0], self._scal_host[1], self._scal_host[2] = rec.m, m1, recf.m
+        self._scal_cpu[0], self._scal_cpu[1], self._scal_cpu[2] = rec.m, m1, recf.m
         if not parallel.single():
             r = parallel.rank()
             self._plans = [None] * 3
             for slot in range(3):
                 perm = parallel.shuffle_perm(W * B, self._step, slot)
-                self._inv_host[slot] = torch.argsort(perm)
+                self._inv_cpu[slot] = torch.argsort(perm)
                 if self._a2a:                   # two all-to-alls move B rows per rank instead of gathering W * B
                     plan = self._plans[slot] = parallel.ShufflePlan(W, B, r, perm)
-                    self._idx_host[6 + 4 * slot:10 + 4 * slot] = plan.index_rows()
+                    self._idx_cpu[6 + 4 * slot:10 + 4 * slot] = plan.index_rows()
                 else:
-                    self._idx_host[slot] = perm.view(W, B)[r]
+                    self._idx_cpu[slot] = perm.view(W, B)[r]
         self._bg = bg
+
+    def _upload_step_words(self):
+        """send what _pre_step_host assembled to the device words the kernels read, on the current stream.  Never inside a
+        graph capture: the whole-step graph (graph.py) calls this before each replay."""
+        self._scal.push(self._scal_cpu)
+        if not parallel.single():
+            self._idx.push(self._idx_cpu)
+            self._inv.push(self._inv_cpu)
 
     def _post_step_host(self):
         rec, recf = self.recognizer, self.recognizer_flow
@@ -624,12 +634,10 @@ class MSCLWithAug(nn.Module):
         return self._side[i]
 
     def _pick_streams(self, n):
-        """n side streams that really run next to the current stream.  HIP multiplexes streams onto a few hardware
-        queues (4 by default) in creation order, and two streams that land on one queue serialise: with a process group
-        alive (its own stream plus RCCL's) a freshly created side stream aliased the main stream and the three-chain
-        overlap was gone (13.2 instead of 9.4 ms per step, rocprofv3 kernel trace: both streams on queue 4).  So:
-        create a few candidates and keep those that a spin kernel shows to overlap with everything chosen so far."""
+        """n side streams that really run next to the current stream (and, when a process group is up, next to the
+        communicator): the selection logic and why it exists are in streams.py; here are the timing primitives."""
         import time
+        from .streams import pick_side_streams
         dev = self.arena.device
         prio = int(os.environ.get('MSCL_SIDE_PRIORITY', '0'))          # HIP: larger = lower priority than the main chain
         cand = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n if os.environ.get('MSCL_STREAM_PROBE') == '0' else 12)]
@@ -640,49 +648,34 @@ class MSCLWithAug(nn.Module):
         def spin(streams, cycles):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for st in streams:
+            for st in [main] + list(streams):
                 with torch.cuda.stream(st):
                     torch.cuda._sleep(cycles)
             torch.cuda.synchronize()
             return time.perf_counter() - t0
-        cycles = 200000
-        spin([main] + cand, 1000)                                      # first use of a stream may set up its hardware queue
-        spin([main], cycles)
-        t = spin([main], cycles)
-        cycles = int(cycles * max(1.0, 1.5e-3 / max(t, 1e-5)))         # ~1.5 ms per spin: far above launch latency
-        one = min(spin([main], cycles) for _ in range(2))
-        chosen = []                                                    # one representative per hardware queue other than main's
-        for c in cand:
-            if spin([main] + chosen + [c], cycles) < 1.4 * one:
-                chosen.append(c)
-        comm_free = None
-        if not parallel.single() and dist.get_backend() == 'nccl' and len(chosen) > 1 and os.environ.get('MSCL_STREAM_PROBE') != 'nocomm':
-            # the communicator's stream sits on one of the queues too: a side stream sharing it would stall behind every
-            # gradient bucket.  Same test, with a large all-reduce (issued from the idle main stream) as the other party.
-            buf = torch.zeros(48 << 20, device=dev)
 
-            def comm(streams, cyc):
+        class _Comm:
+            def __init__(self):
+                self.buf = torch.zeros(48 << 20, device=dev)
+
+            def agree_min(self, v):
+                t = torch.tensor([int(v)], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item())
+
+            def timed(self, streams, cyc):
                 dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for st in streams:
                     with torch.cuda.stream(st):
                         torch.cuda._sleep(cyc)
-                dist.all_reduce(buf)
+                dist.all_reduce(self.buf)                               # issued from the idle main stream
                 torch.cuda.synchronize()
                 return time.perf_counter() - t0
-            comm([], 0)
-            t_c = min(comm([], 0) for _ in range(2))
-            cyc = max(1000, int(cycles * t_c / one))                    # spin about as long as the all-reduce
-            t_s = min(spin([main], cyc) for _ in range(2))
-            free = [c for c in chosen if min(comm([c], cyc) for _ in range(2)) < max(t_c, t_s) + 0.5 * min(t_c, t_s)]
-            comm_free = len(free)
-            chosen = free + [c for c in chosen if all(c is not x for x in free)]
-            del buf
-        self.stream_probe = dict(spin_ms=1e3 * one, queues_beside_main=len(chosen), beside_comm=comm_free, wanted=n,
-                                 candidates=len(cand))
-        rest = [c for c in cand if all(c is not x for x in chosen)]
-        return (chosen + rest)[:n]
+        use_comm = (not parallel.single() and dist.get_backend() == 'nccl' and os.environ.get('MSCL_STREAM_PROBE') != 'nocomm')
+        chosen, self.stream_probe = pick_side_streams(cand, n, spin, _Comm() if use_comm else None)
+        return chosen
 
     def sync_streams(self):
         """make the current stream wait for the flow stream (parameter gradients are written by kernels, not by
@@ -695,9 +688,9 @@ class MSCLWithAug(nn.Module):
         if parallel.single():
             return x          # a within-batch permutation does not change per-GPU BN statistics
         if self._a2a:
-            p, ix = self._plans[slot], self._idx_dev
+            p, ix = self._plans[slot], self._idx.dev
             return parallel.exchange_rows(x, ix[6 + 4 * slot], ix[7 + 4 * slot], p.send_splits, p.recv_splits)
-        return parallel.all_gather_cat(x).index_select(0, self._idx_dev[slot])
+        return parallel.all_gather_cat(x).index_select(0, self._idx.dev[slot])
 
     def _shuffle_mask(self, m, slot):
         if m is None or parallel.single():
@@ -733,12 +726,8 @@ class MSCLWithAug(nn.Module):
         Th = T2 // 2
         aug = self.aug_gpu
         K.ZEROS.reset(im_q.device)
-        self._scal_dev.copy_(self._scal_host, non_blocking=True)
         dp = not parallel.single()
-        if dp:
-            self._idx_dev.copy_(self._idx_host, non_blocking=True)
-            self._inv_dev.copy_(self._inv_host, non_blocking=True)
-        sc = self._scal_dev
+        sc = self._scal.dev                         # this step's words: uploaded by _upload_step_words on this stream
         ids = self.sup_head.mlvl_ids
         hw = lambda m: m.shape[2] * m.shape[3]
         # Three independent chains meet only in the loss: RGB query (current stream), RGB key, flow (query + key).
@@ -802,7 +791,7 @@ class MSCLWithAug(nn.Module):
             k_rgb = self._encode_key(0, rec, x_k, sc[0:1])
         # -- RGB query branch
         x_q = aug.pack_rgb(aug.color(im_q, color_q, 0), flip_q)
-        q_rgb, maps_rgb = rec.encode_q(x_q)
+        q_rgb, maps_rgb = rec.encode_q(x_q, levels=(ids[0],))       # LMCL reads one pyramid level (local_cl_head.py:59)
         if side_k is not main:
             main.wait_stream(side_k)
             k_rgb.record_stream(main)
@@ -818,7 +807,7 @@ class MSCLWithAug(nn.Module):
         if dp:
             # keys come back: one all-gather of the three (B,128) blocks, put into global sample order with the inverse
             # permutations; the own rows are this rank's keys (moco.py:174-191), the whole is what the queues enqueue
-            full, (k_rgb, k_fb, k_fa) = parallel.gather_unshuffle([k_rgb, k_fb, k_fa], self._inv_dev)
+            full, (k_rgb, k_fb, k_fa) = parallel.gather_unshuffle([k_rgb, k_fb, k_fa], self._inv.dev)
             self._kglobal = dict(rgb=full[0], fb=full[1], fa=full[2])
         if m_rgb.shape[1] != fmap_shape[1] or m_rgb.shape[1] != self.sup_head.t:
             raise ValueError(f'LMCL needs equal frame-slot counts: rgb {m_rgb.shape[1]}, flow {fmap_shape[1]}, head t={self.sup_head.t}')

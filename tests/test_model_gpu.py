@@ -3,7 +3,10 @@ own Python (tests/golden, tools/oracle/make_golden.py) and (b) the oracle/ resta
 
 The HIP path computes convolutions in bf16 with fp32 accumulation (fp32 masters, fp32 BN statistics,
 fp32 contrastive / optimizer math); the reference is fp32 end to end.  Stated tolerances:
-  losses            |d| <= 0.02 * max(1, |ref|) + 0.03
+  losses            step 0 against the reference goldens / the oracle: |d| <= 2e-3 * max(1, |ref|) (observed ~1e-5: the
+                    InfoNCE terms sit near ln 65537 and move little); top-1 / top-5 accuracies EQUAL (rank counts);
+                    comparisons between two runs of the HIP path that differ by fp32-atomic order, amplified by batch-2
+                    BatchNorm (graph vs eager, host-side vs device-side augmentation): |d| <= 0.02 * max(1, |ref|) + 0.03
   features q, k     cosine >= 0.995 per row
   gradients         global norm within 8 %; per tensor carrying >= 1 % of the norm, cosine vs the fp32 oracle
                     >= min(0.995, c_ref - 0.06) where c_ref is the cosine that PLAIN PyTorch bf16 autocast of the
@@ -14,6 +17,7 @@ fp32 contrastive / optimizer math); the reference is fp32 end to end.  Stated to
 """
 import json
 import os
+from collections import OrderedDict
 
 import numpy as np
 import pytest
@@ -43,6 +47,19 @@ def loss_close(got, ref, what):
     assert abs(got - ref) <= 0.02 * max(1.0, abs(ref)) + 0.03, f'{what}: hip {got} vs ref {ref}'
 
 
+def logs_match(got, ref, what, rows=None, loss_tol=2e-3):
+    """all log entries of a step against the reference / oracle: losses to `loss_tol` relative, accuracies exactly (they are
+    k / rows for an integer k; `rows` given -> at most one row may flip, for full-size batches where a positive sits within
+    bf16 noise of the 5th-largest negative)"""
+    assert list(got.keys()) == list(ref.keys()), (list(got.keys()), list(ref.keys()))
+    for k, v in ref.items():
+        if 'loss' in k:
+            assert abs(got[k] - v) <= loss_tol * max(1.0, abs(v)), f'{what} {k}: hip {got[k]} vs ref {v}'
+        else:
+            slack = 1e-6 if rows is None else 1.0 / rows + 1e-6
+            assert abs(got[k] - v) <= slack, f'{what} {k}: hip {got[k]} vs ref {v}'
+
+
 def _autocast_yardstick(batch, T, Kq, ref_grads):
     """per-tensor gradient cosine of the oracle under torch.autocast(cpu, bfloat16) vs its fp32 run"""
     from oracle import fill as ofill, mscl as om
@@ -56,11 +73,14 @@ def _autocast_yardstick(batch, T, Kq, ref_grads):
             for n, p in o2.named_parameters() if p.grad is not None}
 
 
-def test_step_vs_golden_and_oracle(dev):
+@pytest.mark.parametrize('tag', ['step_b2_t8_h112', 'step_b2_t16_h112'])
+def test_step_vs_golden_and_oracle(tag, dev):
+    """T=8 is the shipped config's clip length, T=16 the benchmark's (BASELINE.json); both goldens come from the reference's
+    own classes (tools/oracle/make_golden.py)."""
     from mscl_amd import ClipSGD
     from mscl_amd.synthetic import synthetic_batch
     from oracle import fill as ofill, mscl as om
-    g = np.load(os.path.join(GOLD, 'step_b2_t8_h112.npz'))
+    g = np.load(os.path.join(GOLD, f'{tag}.npz'))
     meta = json.loads(str(g['meta']))
     B, T, H, Kq = meta['B'], meta['T'], meta['H'], meta['K']
     model, cfg = build(T, Kq, dev)
@@ -72,19 +92,15 @@ def test_step_vs_golden_and_oracle(dev):
         batch = synthetic_batch(B, T, H, H, 0, s)
         out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
         assert list(out['log_vars'].keys()) == keys
-        gold = dict(zip(keys, g[f's{s}_log_vals']))
+        gold = OrderedDict(zip(keys, (float(v) for v in g[f's{s}_log_vals'])))
         if s == 0:          # later steps diverge chaotically even between fp32 implementations; step 0 is pinned
-            for k in keys:
-                if 'loss' in k:
-                    loss_close(out['log_vars'][k], gold[k], f'step{s} {k}')
+            logs_match(out['log_vars'], gold, f'{tag} golden step{s}')
         opt.zero_grad()
         out['loss'].backward()
         torch.manual_seed(100 + s)
         oo = orc.train_step(batch); oopt.zero_grad(); oo['loss'].backward()
         if s == 0:
-            for k in keys:
-                if 'loss' in k:
-                    loss_close(out['log_vars'][k], oo['log_vars'][k], f'oracle step{s} {k}')
+            logs_match(out['log_vars'], oo['log_vars'], f'{tag} oracle step{s}')
             cos = torch.nn.functional.cosine_similarity
             for nm, a, b in (('q_rgb', model._dbg['q_rgb'], orc._features['img']['q']),
                              ('k_rgb', model._dbg['k_rgb'], orc._features['img']['k']),
@@ -93,7 +109,6 @@ def test_step_vs_golden_and_oracle(dev):
                 c = cos(a.float().cpu(), b.detach(), dim=1).min().item()
                 assert c >= 0.995, f'{nm} cosine {c}'
             # gradients
-            model.flush_padded_grads()
             yard = _autocast_yardstick(batch, T, Kq, {n: p.grad for n, p in orc.named_parameters()})
             tot_h, tot_o, bad = 0.0, 0.0, []
             gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
@@ -581,6 +596,96 @@ def test_full_size_step_properties(dev):
             assert float((model.recognizer.queue[:, :B].float().T - first_keys).abs().max()) <= 1e-6
 
 
+def test_full_step_full_size_vs_oracle(dev):
+    """BASELINE.json's configuration itself -- B=8, T=16, 112x112, K=65536 -- against the oracle step on the host (a few
+    seconds on 16 threads): all 23 log entries (losses to 1e-3 relative, accuracies equal up to one row of 8), q / k
+    feature cosines, the global gradient norm, and the per-tensor gradient cosines, which are also written out as a table
+    (gpurun_out/r02_grad_cosine_full_size.md -> profiles/)."""
+    from mscl_amd import ClipSGD
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    B, T, H, Kq = 8, 16, 112, 65536
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    batch = synthetic_batch(B, T, H, H, 0, 0)
+    out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
+    opt.zero_grad(); out['loss'].backward()
+    model.sync_streams(); torch.cuda.synchronize()
+    orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
+    torch.manual_seed(100)
+    oo = orc.train_step(batch)
+    oo['loss'].backward()
+    logs_match(out['log_vars'], oo['log_vars'], 'full size', rows=B, loss_tol=1e-3)
+    cos = torch.nn.functional.cosine_similarity
+    for nm, a, b in (('q_rgb', model._dbg['q_rgb'], orc._features['img']['q']), ('k_rgb', model._dbg['k_rgb'], orc._features['img']['k']),
+                     ('q_flow', model._dbg['q_fb'], orc._features['base']['q']), ('k_flow', model._dbg['k_fb'], orc._features['base']['k']),
+                     ('q_flow_aug', model._dbg['q_fa'], orc._features['aug']['q']), ('k_flow_aug', model._dbg['k_fa'], orc._features['aug']['k'])):
+        c = cos(a.float().cpu(), b.detach(), dim=1).min().item()
+        assert c >= 0.995, f'{nm} cosine {c}'
+    rows, tot_h, tot_o = [], 0.0, 0.0
+    gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
+    for (n, p), (n2, q) in zip(model.named_parameters(), orc.named_parameters()):
+        assert n == n2
+        if not p.requires_grad:
+            continue
+        gh = p.grad.detach().float().cpu()
+        if q.grad is None:
+            assert float(gh.abs().max()) == 0.0, f'{n} must receive no gradient'
+            continue
+        tot_h += float((gh.double() ** 2).sum()); tot_o += float((q.grad.double() ** 2).sum())
+        rows.append((n, float(q.grad.norm()) / gn_o, float(cos(gh.flatten(), q.grad.flatten(), dim=0)),
+                     float(gh.norm()) / max(float(q.grad.norm()), 1e-30)))
+    gn_h = tot_h ** 0.5
+    try:
+        os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'r02_grad_cosine_full_size.md'), 'w') as f:
+            f.write('# Full-size step (B=8, T=16, 112^2, K=65536): HIP (bf16 convs, fp32 accumulate) vs fp32 oracle, per-tensor gradients\n\n')
+            f.write(f'global gradient norm: hip {gn_h:.4f}, oracle {gn_o:.4f} (ratio {gn_h / gn_o:.4f})\n\n')
+            f.write('| tensor | share of oracle norm | cosine | norm ratio |\n|---|---|---|---|\n')
+            for n, share, c, ratio in rows:
+                f.write(f'| `{n}` | {share:.4f} | {c:.4f} | {ratio:.4f} |\n')
+    except OSError:
+        pass
+    assert abs(gn_h - gn_o) <= 0.05 * gn_o, (gn_h, gn_o)
+    bad = [(n, c) for n, share, c, _ in rows if share >= 0.01 and c < 0.90]
+    assert not bad, bad
+    # weighted by gradient energy the direction is much closer than the worst tensor
+    wcos = sum(share ** 2 * c for _, share, c, _ in rows) / sum(share ** 2 for _, share, c, _ in rows)
+    assert wcos >= 0.95, wcos
+
+
+def test_staging_ring_survives_a_host_that_runs_ahead(dev):
+    """The host queues many steps while the GPU is still busy with the first (long sleep kernel ahead): every step must see
+    ITS words.  A single pinned word rewritten per step -- the earlier scheme -- hands all of them the last value."""
+    from mscl_amd.staging import StagingRing
+    ring = StagingRing((4,), torch.float32, dev, slots=3)
+    seen = torch.zeros((8, 4), device=dev)
+    torch.cuda._sleep(int(2e9))                               # ~1 s of GPU time ahead of everything below
+    for i in range(8):
+        ring.push(torch.full((4,), float(i)))
+        seen[i].copy_(ring.dev)                               # a "kernel" of step i reading the device words
+    torch.cuda.synchronize()
+    assert seen[:, 0].tolist() == [float(i) for i in range(8)], seen[:, 0].tolist()
+    # the model's step words: eager steps queued behind a sleep see their own EMA momenta
+    from mscl_amd.synthetic import synthetic_batch
+    model, cfg = build(8, 64, dev)
+    model.key_graphs = model.query_graphs = False
+    batch = synthetic_batch(2, 8, 32, 32, 0, 0, device=dev)
+    model.train_step(batch, sync_logs=False)
+    torch.cuda.synchronize()
+    model.recognizer.max_iters = model.recognizer_flow.max_iters = 64        # make the schedule move visibly per step
+    want, got = [], []
+    torch.cuda._sleep(int(1e9))
+    for s in range(6):
+        model.train_step(batch, sync_logs=False)
+        got.append(model._scal.dev.clone())
+        want.append((model.recognizer.m, model.recognizer_flow.m))
+    torch.cuda.synchronize()
+    for s in range(6):
+        assert abs(float(got[s][0]) - want[s][0]) < 1e-6 and abs(float(got[s][2]) - want[s][1]) < 1e-6, (s, got[s], want[s])
+    assert len({round(w[0], 9) for w in want}) == 6
+
+
 def test_checkpoint_resume_and_lr_schedule(dev, tmp_path):
     """save after 2 steps, resume into a fresh model: every buffer (551 state-dict entries, bf16
     shadows, momentum) is bit-identical, the counters continue, and the next step matches the uninterrupted run
@@ -621,6 +726,81 @@ def test_checkpoint_resume_and_lr_schedule(dev, tmp_path):
     assert int(model.recognizer.queue_ptr) == int(model2.recognizer.queue_ptr)
     assert torch.equal(model.recognizer_flow.count, model2.recognizer_flow.count)
     assert abs(model.recognizer.m - model2.recognizer.m) < 1e-15
+
+
+def test_evaluate_and_log_cadence_vs_oracle(dev, tmp_path):
+    """SURVEY section 8(f)#3, the rest of the runner: (1) the SimpleDistEvalHook pass (eval_hooks.py:471-487) -- eval(),
+    train_step under no_grad per batch, num_samples-weighted averages -- against the oracle run the same way, including its
+    side effects (queues enqueued, key encoders moved, `iters` standing still, BatchNorm statistics untouched);
+    (2) the text logger's cadence: one record per `interval` iterations holding the interval's mean; (3) checkpoints every
+    `checkpoint_config.interval` epochs under mmcv's names, loadable with weights_only=True; (4) a reference-style
+    checkpoint (torch.optim.SGD state dict) resumes with its momentum buffers mapped by parameter order."""
+    from mscl_amd import ClipSGD, train as tr
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    B, T, H, Kq = 2, 8, 64, 64
+    model, cfg = build(T, Kq, dev)
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
+    oopt = om.SGDClip(orc.parameters())
+    host = [synthetic_batch(B, T, H, H, 0, s) for s in range(5)]
+    devb = [{k: [t.to(dev) for t in v] for k, v in b.items()} for b in host]
+    records = []
+    tr.train(model, opt, lambda e: devb[:2], total_epochs=1, base_lr=0.02, log=lambda e, it, lv: records.append((it, lv)),
+             log_interval=2)
+    assert len(records) == 1 and records[0][0] == 1 and list(records[0][1].keys()) == list(model._log_keys)
+    o_logs = []
+    for s in range(2):
+        torch.manual_seed(100 + s)
+        oo = orc.train_step(host[s]); oopt.zero_grad(); oo['loss'].backward(); oopt.step()
+        o_logs.append(oo['log_vars'])
+    for k, v in records[0][1].items():                        # the record is the MEAN over the two iterations
+        want = 0.5 * (o_logs[0][k] + o_logs[1][k])
+        if 'loss' in k:
+            loss_close(v, want, f'log record {k}')
+    # -- evaluation pass
+    rm0 = model.recognizer.encoder_q.stem[1].running_mean.clone()
+    iters0 = (model.recognizer.iters, model.recognizer_flow.iters)
+    res = tr.evaluate(model, devb[2:5])
+    assert model.training and (model.recognizer.iters, model.recognizer_flow.iters) == iters0
+    assert torch.equal(model.recognizer.encoder_q.stem[1].running_mean, rm0)
+    orc.eval()
+    sums, n = None, 0
+    with torch.no_grad():
+        for b in host[2:5]:
+            oo = orc.train_step(b)
+            row = {k: v * oo['num_samples'] for k, v in oo['log_vars'].items()}
+            sums = row if sums is None else {k: sums[k] + row[k] for k in row}
+            n += oo['num_samples']
+    orc.train()
+    assert list(res.keys()) == list(sums.keys())
+    for k, v in sums.items():
+        if 'loss' in k:
+            loss_close(res[k], v / n, f'eval {k}')
+    for nm, rec, orec in (('rgb', model.recognizer, orc.recognizer), ('flow', model.recognizer_flow, orc.recognizer_flow)):
+        assert int(rec.queue_ptr) == int(orec.queue_ptr) and torch.equal(rec.count.cpu(), orec.count), nm
+        assert rec.iters == orec.iters
+    # -- checkpoint cadence + weights_only load
+    wd = str(tmp_path / 'work')
+    tr.train(model, opt, lambda e: devb[:1], total_epochs=4, base_lr=0.02, work_dir=wd, checkpoint_interval=2)
+    assert sorted(os.listdir(wd)) == ['epoch_2.pth', 'epoch_4.pth', 'latest.pth']
+    model2, _ = build(T, Kq, dev)
+    opt2 = ClipSGD.from_cfg(model2, cfg.optimizer, cfg.optimizer_config)
+    meta = tr.resume(os.path.join(wd, 'latest.pth'), model2, opt2)
+    assert meta['epoch'] == 4 and torch.equal(model2.arena.MOM, model.arena.MOM)
+    # -- a reference-style checkpoint: state_dict + torch.optim.SGD state keyed by parameter index
+    ref_opt = {'state': {}, 'param_groups': [{'lr': 0.0123, 'momentum': 0.9, 'params': list(range(len(list(model.parameters()))))}]}
+    for i, p in enumerate(model.parameters()):
+        if p.requires_grad and getattr(p, '_mscl_slot').touched:
+            ref_opt['state'][i] = {'momentum_buffer': model.arena.view('MOM', p._mscl_slot).detach().cpu().clone()}
+    path = str(tmp_path / 'ref_style.pth')
+    torch.save({'meta': {'epoch': 1, 'iter': 3}, 'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                'optimizer': ref_opt}, path)
+    model3, _ = build(T, Kq, dev)
+    opt3 = ClipSGD.from_cfg(model3, cfg.optimizer, cfg.optimizer_config)
+    tr.resume(path, model3, opt3)
+    assert torch.equal(model3.arena.MOM, model.arena.MOM) and opt3.param_groups[0]['lr'] == 0.0123
+    assert model3.arena.active_ranges() == model.arena.active_ranges()
 
 
 def _rccl_forced_worker(port, q):

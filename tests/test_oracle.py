@@ -59,6 +59,11 @@ def test_oracle_matches_reference_step_t8():
     _run('step_b2_t8_h112', 1)
 
 
+def test_oracle_matches_reference_step_t16():
+    """the benchmark's clip length (BASELINE.json: 16 x 112^2)"""
+    _run('step_b2_t16_h112', 1)
+
+
 def test_log_keys_are_the_23_reference_keys():
     g = np.load(os.path.join(GOLD, 'step_b2_t8_h112.npz'))
     from mscl_amd.recognizers import LOG_KEYS

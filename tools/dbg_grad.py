@@ -10,7 +10,7 @@ model, cfg = build(T, Kq, dev)
 orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
 batch = synthetic_batch(B, T, H, H, 0, 0)
 out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
-model.zero_grad(); out['loss'].backward(); model.flush_padded_grads()
+model.zero_grad(); out['loss'].backward()
 oo = orc.train_step(batch)
 f = orc._features
 for nm in ('img', 'base', 'aug'):
