@@ -94,7 +94,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
   // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
   if (stat_sum != nullptr) {
     float* red = reinterpret_cast<float*>(smem);      // [2][BN], tiles are dead after the last barrier
-    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+    for (int i = tid; i < 2 * BN; i += (int)blockDim.x) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
@@ -117,7 +117,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
       }
     }
     __syncthreads();
-    for (int i = tid; i < BN; i += 256) {
+    for (int i = tid; i < BN; i += (int)blockDim.x) {
       if (n0 + i < g.Cr) {
         const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * g.Cr;
         atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
@@ -384,22 +384,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // buffer instruction's SGPR offset and the per-lane VGPR offset of a row never changes.  A K step then costs 3 VALU
 // per A piece (tap-validity test + select of the zero-fill sentinel) and none per B piece, instead of the ~30 the
 // general kernel spends on table lookups and address arithmetic (measured there: 7.8 VALU per MFMA, 22 % MFMA busy).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_fast_kernel(
+// STAGES: depth of the LDS ring.  2 = issue tile k+1, compute tile k, drain, barrier.  3 / 4 = tiles k+1 .. k+STAGES-1 stay
+// in flight across the (raw) barrier behind a counted vmcnt: for grids of about one block per CU, where no second block hides
+// the global -> LDS round trip of every K step.
+// WAVES_M x WAVES_N = 4 (256 threads) or 8 (512 threads, the WIDE tiles 256 x 128 / 128 x 256): global -> LDS staging runs at
+// ~30 B/clk per CU whatever the schedule (MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': 66-73 GB/s per CU from L2;
+// the 128 x 128 tile moved 27 B/clk per CU at 2 blocks per CU and every ring depth measured the same or worse), so what a K
+// step costs is its staged bytes: 128 x 128 stages 32 KB for 2.1 MFLOP (64 FLOP/B), a wide tile 48 KB for 4.2 MFLOP (85).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel(
     const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
     const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
     float* __restrict__ stat_sq, const int relu, float* __restrict__ partial) {
-  constexpr int BK = 64, GPR = 8, RPP = 32;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int BK = 64, GPR = 8, RPP = NT / GPR;
   constexpr int AP = BM / RPP, BP = BN / RPP;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int IM = WM / 16, JN = WN / 16;
   constexpr int A_STAGE = BM * BK * 2, B_STAGE = BN * BK * 2;
   constexpr unsigned OOB = 0x80000000u;       // >= num_records with or without the SGPR offset added
-  static_assert(WAVES_M * WAVES_N == 4 && IM >= 1 && JN >= 1 && AP >= 1 && BP >= 1 && BN % RPP == 0, "tile config");
+  static_assert((WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8) && IM >= 1 && JN >= 1 && AP >= 1 && BP >= 1 && BN % RPP == 0 &&
+                BM % RPP == 0, "tile config");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const As = smem;                       // [2][BM*BK] bf16
-  unsigned char* const Bs = smem + 2 * A_STAGE;         // [2][BN*BK] bf16
+  unsigned char* const As = smem;                       // [STAGES][BM*BK] bf16
+  unsigned char* const Bs = smem + STAGES * A_STAGE;    // [STAGES][BN*BK] bf16
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -508,17 +517,42 @@ __global__ __launch_bounds__(256) void conv_igemm_fast_kernel(
     }
   };
 
-  if (k_beg < k_end) {
-    issue(k_beg, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  for (int kt = k_beg; kt < k_end; ++kt) {
-    const int cur = (kt - k_beg) & 1;
-    if (kt + 1 < k_end) issue(kt + 1, cur ^ 1);
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  if constexpr (STAGES == 2) {
+    if (k_beg < k_end) {
+      issue(k_beg, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    for (int kt = k_beg; kt < k_end; ++kt) {
+      const int cur = (kt - k_beg) & 1;
+      if (kt + 1 < k_end) issue(kt + 1, cur ^ 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // Ring of STAGES slots: iteration i waits until tile i has landed (every wave issues ND = AP + BP DMA instructions per
+    // tile, so "all but the youngest (STAGES-2)*ND" is exactly tile i), passes a raw s_barrier (a __syncthreads() would
+    // drain the DMA queue), refills the slot tile i-1 was read from -- every wave has finished those reads, it is past the
+    // barrier -- and computes tile i while tiles i+1 .. i+STAGES-1 are in flight.
+    constexpr int ND = AP + BP;
+    const int nkt = k_end - k_beg;
+#pragma unroll
+    for (int s_ = 0; s_ < STAGES - 1; ++s_)
+      if (s_ < nkt) issue(k_beg + s_, s_);
+    int buf = 0, nxt = STAGES - 1;
+    for (int i = 0; i < nkt; ++i) {
+      const int rem = nkt - 1 - i;                    // tiles issued after tile i so far: min(rem, STAGES - 2)
+      if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((STAGES - 2) * ND) : "memory");
+      else if (STAGES == 4 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ND) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (i + STAGES - 1 < nkt) issue(k_beg + i + STAGES - 1, nxt);
+      compute(buf);
+      buf = (buf == STAGES - 1) ? 0 : buf + 1;
+      nxt = (nxt == STAGES - 1) ? 0 : nxt + 1;
+    }
+    __builtin_amdgcn_s_barrier();                   // the epilogue reuses the tile memory
   }
   igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, g.dW, g.dH, g.dT, g.Tr, g.Hr, g.Wr, 1, 1, 1,
                                  0, 0, 0, out, bias, addend, stat_sum, stat_sq, relu, partial);
@@ -569,8 +603,16 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------- host side
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
-static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % 32 == 0 && BN % 32 == 0; }
+static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % (8 * WAVES_M * WAVES_N) == 0 && BN % (8 * WAVES_M * WAVES_N) == 0; }
 static bool fast_disabled() { const char* e = getenv("MSCL_IGEMM_FAST"); return e && e[0] == '0'; }
+static bool wide_enabled() { const char* e = getenv("MSCL_IGEMM_WIDE"); return !(e && e[0] == '0'); }     // tuning aid (A/B)
+// ring depth of the uniform-tap kernel for a grid of `nblk` blocks with `stage_bytes` of LDS per stage
+// (MSCL_FAST_STAGES = 2 / 3 / 4 forces it: tuning aid, read per launch)
+static int fast_stages(long nblk, int stage_bytes) {
+  if (const char* e = getenv("MSCL_FAST_STAGES")) { const int v = atoi(e); if (v >= 2 && v <= 4) return v; }
+  (void)nblk; (void)stage_bytes;
+  return 2;
+}
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias,
@@ -589,8 +631,8 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   if (ws != nullptr && blocks <= 256 && nk >= 32) {           // too few tiles for 256 CUs and a long K loop
     // measured on the 6272- and 784-position layers (tools/sweep_ksplit.sh): one round of <= 2 blocks per CU beats more
     // splits (98 tiles x 6 = 588 blocks ran 52 us, x 4 = 392 blocks 44 us), and a block wants >= 12 K steps
-    long want = 448 / blocks;
-    if (want > nk / 12) want = nk / 12;
+    long want = (WAVES_M * WAVES_N == 8 ? 256 : 448) / blocks;      // wide tiles: one 96-KB block per CU
+    if (want > nk / (WAVES_M * WAVES_N == 8 ? 6 : 12)) want = nk / (WAVES_M * WAVES_N == 8 ? 6 : 12);
     if (want > 16) want = 16;
     if (want * out_elems > ws_floats) want = ws_floats / out_elems;
     if (want > 1) g.ksplit = (int)want;
@@ -605,21 +647,29 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
     // uniform-tap kernel: whole 64-channel K steps of one tap, no parity classes, offsets below 2^31
     const long span = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
     if (g.mode != 2 && g.cgs >= 3 && span < (1L << 31) && !fast_disabled()) {
-      auto kern = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N>;
-      static bool attr_done_f = false;
-      if (!attr_done_f) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done_f = true;
-      }
       g.dKW = make_fastdiv(g.kW); g.dKH = make_fastdiv(g.kH);
-      const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(256), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
-                         relu, partial);
+      const long nblk = blocks * g.ksplit;
+      int stages = fast_stages(nblk, (BM + BN) * BK * 2);
+      auto go = [&](auto kern, int nst) {
+        static bool attr_done_f = false;            // (one static per instantiation of this lambda = per kernel)
+        if (!attr_done_f) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_done_f = true;
+        }
+        const size_t lds = (size_t)nst * (BM + BN) * BK * 2;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
+                           relu, partial);
+      };
+      if (stages == 4 && 4 * (BM + BN) * BK * 2 <= 160 * 1024) go(conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 4>, 4);
+      else if (stages >= 3) go(conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 3>, 3);
+      else go(conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 2>, 2);
       MSCL_LAUNCH_CHECK();
       launched = true;
     }
   }
-  if (!launched) {
+  if constexpr (WAVES_M * WAVES_N != 4) {
+    if (!launched) return MSCL_E_SHAPE;              // wide tiles exist in the uniform-tap kernel only (callers check wide_ok first)
+  } else if (!launched) {
     const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2 + (size_t)g.ntaps * 12;
     auto kern = conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, STAGES>;
     static bool attr_done = false;
@@ -665,6 +715,16 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     }
   }
   const bool can_split = ws != nullptr;
+  // wide tiles (uniform-tap kernel only: whole 64-channel steps of one tap, no parity classes, 32-bit offsets)
+  const long span_w = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
+  const bool wide_ok = bk64 && g.mode != 2 && g.cgs >= 3 && span_w < (1L << 31) && !fast_disabled() && wide_enabled();
+  if (wide_ok && Cr >= 128) {
+    const int nk = g.ntaps << (g.cgs - 3);
+    // 128 output channels: 256 positions x 128 (196 tiles on the 50176-position maps: one round of one block per CU)
+    if (Cr == 128 && (blocks(256, 128) >= 160 || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
+    // 256 / 512 output channels on maps of a few thousand positions: 128 positions x 256 channels, K split over the grid
+    if (Cr >= 256 && Cr % 256 == 0 && can_split && nk >= 32 && blocks(128, 256) <= 128) GO(128, 256, 64, 2, 4);
+  }
   if (bk64) {
     if (Cr >= 128) {
       // a few dozen 128 x 128 tiles (784-position maps): 64-row tiles double the tiles per split, so fewer fp32 slabs

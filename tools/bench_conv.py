@@ -49,16 +49,55 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def sweep(a):
+    dev = torch.device('cuda:0')
+    var, vals = a.sweep.split('=')
+    vals = vals.split(',')
+    modes = a.modes.split(',')
+    print(f'# sweep {var} over {vals}: min of {a.rounds} rounds x {a.iters} launches, us per launch')
+    for name, xs, Kc, kern, st, pad in SHAPES:
+        if a.only and not any(o in name for o in a.only.split(',')):
+            continue
+        C = xs[-1]
+        d = K.conv_desc(xs, Kc, kern, st, pad)
+        x = torch.randn(xs, device=dev).to(torch.bfloat16)
+        w = (torch.randn((Kc, *kern, C), device=dev) * 0.05).to(torch.bfloat16)
+        wT = w.permute(4, 1, 2, 3, 0).contiguous()
+        dy = torch.randn(K.out_shape(d), device=dev).to(torch.bfloat16)
+        dw = torch.zeros((Kc, *kern, C), device=dev)
+        stats = torch.zeros((K.STAT_SLOTS, 2, Kc), device=dev)[0]
+        fns = {'fwd': lambda: K.conv3d_fwd(x, w, d, stats=(stats[0], stats[1])), 'dgrad': lambda: K.conv3d_dgrad(dy, wT, d),
+               'wgrad': lambda: K.conv3d_wgrad(x, dy, d, dw)}
+        for m in modes:
+            if m == 'dgrad' and C < 16:
+                continue
+            best = {v: 1e9 for v in vals}
+            for _ in range(a.rounds):
+                for v in vals:
+                    if v == '-':
+                        os.environ.pop(var, None)
+                    else:
+                        os.environ[var] = v
+                    best[v] = min(best[v], timeit(fns[m], a.iters) * 1e3)
+            os.environ.pop(var, None)
+            print(f'{name:16s} {m:6s} ' + '  '.join(f'{v}: {best[v]:7.1f}' for v in vals), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--modes', default='fwd,dgrad,wgrad')
+    ap.add_argument('--sweep', default=None, help='NAME=v1,v2,..: A/B an environment tuning hook that the library reads per '
+                    'launch (e.g. MSCL_FAST_STAGES=2,3,4), variants interleaved per shape in ONE process')
+    ap.add_argument('--rounds', type=int, default=3, help='rounds per variant with --sweep (min is reported)')
     a = ap.parse_args()
+    if a.sweep:
+        return sweep(a)
     dev = torch.device('cuda:0')
     modes = a.modes.split(',')
     for name, xs, Kc, kern, st, pad in SHAPES:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(',')):
             continue
         C = xs[-1]
         d = K.conv_desc(xs, Kc, kern, st, pad)
