@@ -387,10 +387,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // STAGES: depth of the LDS ring.  2 = issue tile k+1, compute tile k, drain, barrier.  3 / 4 = tiles k+1 .. k+STAGES-1 stay
 // in flight across the (raw) barrier behind a counted vmcnt: for grids of about one block per CU, where no second block hides
 // the global -> LDS round trip of every K step.
-// WAVES_M x WAVES_N = 4 (256 threads) or 8 (512 threads, the WIDE tiles 256 x 128 / 128 x 256): global -> LDS staging runs at
-// ~30 B/clk per CU whatever the schedule (MI355X_MICROARCH.md, 'Indexed rows: gather into LDS': 66-73 GB/s per CU from L2;
-// the 128 x 128 tile moved 27 B/clk per CU at 2 blocks per CU and every ring depth measured the same or worse), so what a K
-// step costs is its staged bytes: 128 x 128 stages 32 KB for 2.1 MFLOP (64 FLOP/B), a wide tile 48 KB for 4.2 MFLOP (85).
+// WAVES_M x WAVES_N = 4 (256 threads) or 8 (512 threads, the WIDE tiles 256 x 128 / 128 x 256: 48 KB staged per 4.2 MFLOP
+// instead of 32 KB per 2.1).  Measured round 2 (tools/bench_conv.py --sweep, one process): ring depth 3 / 4 never beats two
+// blocks per CU at depth 2 (128 -> 128 on 50176 positions: 57 us at depth 2, 82 at depth 3 with one block per CU); the
+// 256 x 128 tile ties the 128 x 128 one there (53.8 vs 54.0 us) and loses on small maps; 128 x 256 wins a little where 256 output
+// channels meet a few thousand positions (40.4 -> 37.4 us).  PMC on the 128 x 128 tile: MFMA pipe busy 36 %, waves 34 % parked
+// on vmcnt / barrier, 29 % issue-stalled -- the plateau of the two-barrier-per-K-step structure (cdna_hip_programming.md 5).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel(
     const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
@@ -605,7 +607,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % (8 * WAVES_M * WAVES_N) == 0 && BN % (8 * WAVES_M * WAVES_N) == 0; }
 static bool fast_disabled() { const char* e = getenv("MSCL_IGEMM_FAST"); return e && e[0] == '0'; }
-static bool wide_enabled() { const char* e = getenv("MSCL_IGEMM_WIDE"); return !(e && e[0] == '0'); }     // tuning aid (A/B)
+// MSCL_IGEMM_WIDE: 0 = no 8-wave tiles, 1 (default) = where they measured faster, 2 = wherever they apply (A/B)
+static int wide_level() { const char* e = getenv("MSCL_IGEMM_WIDE"); return e ? atoi(e) : 1; }
 // ring depth of the uniform-tap kernel for a grid of `nblk` blocks with `stage_bytes` of LDS per stage
 // (MSCL_FAST_STAGES = 2 / 3 / 4 forces it: tuning aid, read per launch)
 static int fast_stages(long nblk, int stage_bytes) {
@@ -717,13 +720,15 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   const bool can_split = ws != nullptr;
   // wide tiles (uniform-tap kernel only: whole 64-channel steps of one tap, no parity classes, 32-bit offsets)
   const long span_w = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
-  const bool wide_ok = bk64 && g.mode != 2 && g.cgs >= 3 && span_w < (1L << 31) && !fast_disabled() && wide_enabled();
+  const int wide = wide_level();
+  const bool wide_ok = bk64 && g.mode != 2 && g.cgs >= 3 && span_w < (1L << 31) && !fast_disabled() && wide > 0;
   if (wide_ok && Cr >= 128) {
     const int nk = g.ntaps << (g.cgs - 3);
-    // 128 output channels: 256 positions x 128 (196 tiles on the 50176-position maps: one round of one block per CU)
-    if (Cr == 128 && (blocks(256, 128) >= 160 || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
-    // 256 / 512 output channels on maps of a few thousand positions: 128 positions x 256 channels, K split over the grid
-    if (Cr >= 256 && Cr % 256 == 0 && can_split && nk >= 32 && blocks(128, 256) <= 128) GO(128, 256, 64, 2, 4);
+    // 128 output channels: 256 positions x 128 (196 tiles on the 50176-position maps) -- a tie at best, A/B only
+    if (wide >= 2 && Cr == 128 && (blocks(256, 128) >= 160 || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
+    // 256 output channels on maps of a few thousand positions: 128 positions x 256 channels, K split over the grid
+    if (Cr >= 256 && Cr % 256 == 0 && can_split && nk >= 32 && blocks(128, 256) <= 128 && (wide >= 2 || (Cr == 256 && blocks(128, 256) >= 24)))
+      GO(128, 256, 64, 2, 4);
   }
   if (bk64) {
     if (Cr >= 128) {
