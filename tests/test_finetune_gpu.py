@@ -131,3 +131,41 @@ def test_ssl_pretrain_loading_feature_extraction_and_finetuning(dev):
     assert losses[-1] < 0.5 * losses[0], losses
     with pytest.raises(NotImplementedError):
         build_model(dict(type='Recognizer3D', backbone=dict(type='ResNet3dSlowOnly'), cls_head=None))
+
+
+def test_retrieval_on_extracted_features(dev):
+    """SURVEY section 8(f)#4, retrieval (tools/test_retrival.py:258-303): features of a 'train' and a 'test' split from the HIP
+    trunk in evaluation mode vs the oracle's (cosine >= 0.995 per video), and the k-NN accuracies computed from either agree
+    (a video's rank may move by bf16 noise: at most one test video of 12 may flip per k)."""
+    from mscl_amd import retrieval
+    from oracle import fill as ofill, recognizer3d as orec, retrieval as oret
+    model = build(5, 0.0, dev, test_cfg=dict(average_clips=None, feature_extraction=True))
+    ora = orec.Recognizer3D(5, dropout_ratio=0.0)
+    ofill.fill_module(ora)
+    model.train(); ora.train()
+    g = torch.Generator().manual_seed(3)
+    warm = torch.randn((4, 1, 3, 8, 32, 32), generator=g)               # one training step each: running statistics off their init
+    model.train_step(dict(imgs=warm.to(dev), label=torch.tensor([[0], [1], [2], [3]], device=dev)))
+    ora.train_step(dict(imgs=warm, label=torch.tensor([[0], [1], [2], [3]])))
+    n_train, n_test, classes = 24, 12, 4
+    base = torch.randn((classes, 1, 3, 8, 32, 32), generator=g)
+    tl = torch.arange(n_train) % classes
+    sl = torch.arange(n_test) % classes
+    tr = base[tl] + 0.5 * torch.randn((n_train, 1, 3, 8, 32, 32), generator=g)
+    te = base[sl] + 0.5 * torch.randn((n_test, 1, 3, 8, 32, 32), generator=g)
+    batches = lambda x: [dict(imgs=x[i:i + 8].to(dev)) for i in range(0, len(x), 8)]
+    f_tr, f_te = retrieval.extract_features(model, batches(tr)), retrieval.extract_features(model, batches(te))
+    assert model.training and tuple(f_tr.shape) == (n_train, 512)
+    ora.eval()
+    o_tr, o_te = ora.forward_test(tr, feature_extraction=True), ora.forward_test(te, feature_extraction=True)
+    cos = torch.nn.functional.cosine_similarity
+    assert cos(f_tr.cpu(), o_tr, dim=1).min().item() >= 0.995 and cos(f_te.cpu(), o_te, dim=1).min().item() >= 0.995
+    ks = (1, 5, 10, 20)
+    got = retrieval.knn_accuracy(f_tr, tl, f_te, sl, ks)
+    want = oret.knn_accuracy(o_tr.numpy(), tl.numpy(), o_te.numpy(), sl.numpy(), ks)
+    for k in ks:
+        assert abs(got[k] - want[k]) <= 1.0 / n_test + 1e-6, (k, got, want)
+    assert got[20] >= got[1] and want[1] > 1.0 / classes                 # the clustered clips are retrievable at all
+    plain = build(5, 0.0, dev)
+    with pytest.raises(ValueError):
+        retrieval.extract_features(plain, batches(te))

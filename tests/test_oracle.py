@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from mscl_amd.synthetic import synthetic_batch
@@ -163,3 +164,19 @@ def test_finetune_oracle_vs_reference_golden():
     assert abs(gn - gold['grad_norm']) <= 1e-4 * gold['grad_norm']
     m.eval()
     assert (m.forward_test(test_imgs) - torch.tensor(gold['probs'])).abs().max() < 1e-5
+
+
+def test_retrieval_oracle_and_metric_vs_reference_golden():
+    """G10: tools/test_retrival.py:283-303 executed verbatim on seeded features (tools/oracle/make_golden_retrieval.py); both the
+    numpy restatement and the product's metric function reproduce its accuracies."""
+    from mscl_amd import retrieval
+    from oracle import retrieval as oret
+    gold = json.load(open(os.path.join(GOLD, 'retrieval_g10.json')))
+    for case in gold['cases'].values():
+        tf, tl, sf, sl = oret.clustered_features(case['seed'], noise=case['noise'])
+        ora = oret.knn_accuracy(tf.numpy(), tl.numpy(), sf.numpy(), sl.numpy())
+        got = retrieval.knn_accuracy(tf, tl, sf, sl)
+        for k, v in case['acc'].items():
+            assert abs(ora[int(k)] - v) < 1e-6 and abs(got[int(k)] - v) < 1e-6, (case['seed'], k, ora[int(k)], got[int(k)], v)
+    with pytest.raises(AssertionError):
+        retrieval.knn_accuracy(tf, tl[:-1], sf, sl)
