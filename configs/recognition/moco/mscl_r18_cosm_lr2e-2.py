@@ -46,8 +46,29 @@ model = dict(
              t=(num_frames, num_frames), flow_suffix='flow_imgs', weak_aug=(False, False), visualize=True),
     same_kn=True)
 
-# synthetic data (reference: RedisRawframeDataset on nori/OSS, unavailable outside Megvii)
-data = dict(videos_per_gpu=32, workers_per_gpu=0, train=dict(type='SyntheticClipPairs'))
+# Data: the pipeline sections are the reference's (mscl_r18_cosm_lr2e-2.py:66-87), read by mscl_amd.data.MSCLPipeline.from_cfg;
+# `NoriDecode` (Megvii-internal nori / redis storage) is replaced by the plain-file ClipStore, and the per-pixel steps (flow
+# rotation augmentation, crop, resize, normalise) run on the GPU.  Without a store the benchmark feeds synthetic clips.
+def _pipeline(sampler):
+    return [
+        dict(type='MatchFlow', gap=2, adjacent=8, flow_key='nids_flow'),
+        sampler,
+        dict(type='NoriDecode'),
+        dict(type='NormFlowWithStidedAug', ratios=(0.2, 1.8), num_chunks=8, merge_aug=True),
+        dict(type='MoCoRandomResizedCrop', area_range=(0.2, 1.0), flow_key='flow_imgs'),
+        dict(type='MoCoResize', scale=image_shape, keep_ratio=False, flow_key='flow_imgs', suffix='_q'),
+        dict(type='MoCoResize', scale=image_shape, keep_ratio=False, flow_key='flow_imgs', suffix='_k'),
+        dict(type='MoCoNormalize', ori_flow=True),
+        dict(type='Collect', keys=['imgs', 'flow_imgs'], meta_keys=[]),
+        dict(type='ToTensor', keys=['imgs', 'flow_imgs'], batched=True),
+    ]
+
+
+train_pipeline = _pipeline(dict(type='TemporalShiftChosenSampleFrames', clip_len=num_frames, frame_interval=stride, num_clips=1, shift_range=1))
+val_pipeline = _pipeline(dict(type='ChosenSampleFrames', clip_len=num_frames, frame_interval=stride, num_clips=1))
+data = dict(videos_per_gpu=32, workers_per_gpu=0, train=dict(type='SyntheticClipPairs'),
+            train_dataloader=dict(drop_last=True), val_dataloader=dict(drop_last=True))
+evaluation = dict(interval=5, simple=True)
 
 optimizer = dict(type='SGD', lr=0.02, momentum=0.9, weight_decay=1e-4)
 optimizer_config = dict(grad_clip=dict(max_norm=40, norm_type=2))

@@ -164,6 +164,20 @@ int mscl_color_aug(const float* x, float* out, const float* params, int B, int T
  * ksize odd, <= 33, H and W > ksize / 2. */
 int mscl_gauss_blur(const float* x, float* tmp, float* out, const float* params, int ksize, int B, int frames, int H, int W,
                     void* stream);
+/* ---- input data path: paired crop + resize + normalise of decoded clips, one pass -----------------
+ * replaces datasets/pipelines/moco_augmentations.py:110-163 (the crop of MoCoRandomResizedCrop; the box is drawn on the
+ * host), :236-321 (MoCoResize = mmcv.imresize = cv2.resize INTER_LINEAR) and :324-354 (MoCoNormalize: / 255, HWC -> CTHW).
+ * src: raw frames (B,T,Hs,Ws,3) uint8; boxes: (B,4) int32 {x1, y1, x2, y2} (exclusive ends, inside the frame);
+ * out: (B,3,T,Ho,Wo) fp32 in [0,1].  cv2's fixed-point arithmetic (11-bit coefficients, its 8-bit vertical pass, the 2 x 2
+ * area special case) restated from OpenCV's published resize.cpp; OpenCV is not vendored in the reference: unpinned. */
+int mscl_crop_resize_u8(const uint8_t* src, const int32_t* boxes, float* out, int B, int T, int Hs, int Ws, int Ho, int Wo,
+                        int64_t src_batch_stride, void* stream);
+/* the same for float maps with C <= 16 channels (the (u, v) flow after NormFlowWithStidedAug, ori_flow=True: no / 255):
+ * src (B,T,Hs,Ws,C) fp32 -> out (B,C,T,Ho,Wo) fp32, float bilinear taps in cv2's order (horizontal, then vertical).
+ * src_batch_stride (both): elements between consecutive samples of src, 0 = dense; lets one upload that holds the frames
+ * of both views (or base and rotated flow) be read as two T-frame sources. */
+int mscl_crop_resize_f32(const float* src, const int32_t* boxes, float* out, int B, int T, int Hs, int Ws, int C, int Ho, int Wo,
+                         int64_t src_batch_stride, void* stream);
 /* out = relu?(a + b + c) elementwise bf16 (b, c optional) */
 int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, int relu, void* stream);
 /* din = dout * (out > 0) */

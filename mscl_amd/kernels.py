@@ -281,6 +281,27 @@ def flow_fra_visualize(uv, cid, ratios=(0.2, 1.8), num_chunks=8, flip=None, want
     return (out, lv, nm) if want_debug else out
 
 
+def crop_resize(src, boxes, out_hw):
+    """paired-view crop + cv2-style bilinear resize (+ / 255 for uint8 frames) in one pass.
+    src: (B,T,Hs,Ws,C) uint8 (C = 3) or fp32 (C <= 16), dense in its last four axes (a slice along T of a larger upload is
+    fine); boxes: (B,4) int32 {x1,y1,x2,y2} on the device; returns (B,C,T,Ho,Wo) fp32."""
+    B, T, Hs, Ws, C = src.shape
+    if src.stride()[1:] != (Hs * Ws * C, Ws * C, C, 1) or boxes.dtype != torch.int32 or tuple(boxes.shape) != (B, 4):
+        raise lib.MsclError('crop_resize needs frames dense in (T,H,W,C) and (B,4) int32 boxes')
+    Ho, Wo = out_hw
+    out = torch.empty((B, C, T, Ho, Wo), dtype=torch.float32, device=src.device)
+    bs = src.stride(0)
+    if src.dtype == torch.uint8:
+        if C != 3:
+            raise lib.MsclError('uint8 frames must be RGB')
+        call('mscl_crop_resize_u8', ptr(src), ptr(boxes), ptr(out), B, T, Hs, Ws, Ho, Wo, bs, stream_ptr())
+    elif src.dtype == torch.float32:
+        call('mscl_crop_resize_f32', ptr(src), ptr(boxes), ptr(out), B, T, Hs, Ws, C, Ho, Wo, bs, stream_ptr())
+    else:
+        raise lib.MsclError(f'crop_resize: unsupported dtype {src.dtype}')
+    return out
+
+
 def add_relu(a, b=None, c=None, relu=False):
     out = torch.empty_like(a)
     call('mscl_add_relu', ptr(a), ptr(b), ptr(c), ptr(out), a.numel(), int(relu), stream_ptr())

@@ -46,6 +46,8 @@ _SIGS = {
     'mscl_flow_fra_visualize': [P, P, c_float, c_float, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P, P],
     'mscl_color_aug': [P, P, P, c_int, c_int, c_int, c_int, P],
     'mscl_gauss_blur': [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    'mscl_crop_resize_u8': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, P],
+    'mscl_crop_resize_f32': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, P],
     'mscl_add_relu': [P, P, P, P, c_int64, c_int, P],
     'mscl_relu_bwd': [P, P, P, c_int64, P],
     'mscl_upsample_add': [P, P] + [c_int] * 10 + [P],

@@ -270,3 +270,68 @@ def test_stream_probe_collectives_do_not_depend_on_local_timings():
     # without a process group no collective object is touched at all
     chosen, rep = pick_side_streams(['a', 'b', 'c', 'd'], 3, lambda st, cyc: 1e-9 * cyc, None)
     assert chosen == ['a', 'b', 'c'] and rep['beside_comm'] is None
+
+
+def test_datapath_draws_match_reference_golden():
+    """G11 (tools/oracle/make_golden_datapath.py ran the reference's MatchFlow / TemporalShiftChosenSampleFrames /
+    ChosenSampleFrames / MoCoRandomResizedCrop / NormFlowWithStidedAug with seeded global generators): the product's
+    per-sample draws -- frame indices of the query and key clips, rotation chunk, both crop boxes, both flow boxes -- are
+    the reference's, bit for bit, sample after sample (the generators are consumed in the same order)."""
+    import random
+    import numpy as np
+    from mscl_amd import data
+    from oracle import datapath as odp
+    gold = json.load(open(os.path.join(GOLD, 'datapath_g11.json')))
+    cfg = Config.fromfile(CFG)
+    assert len(gold['cases']) == 5
+    for c in gold['cases']:
+        pipe = data.MSCLPipeline.from_cfg([
+            dict(type='MatchFlow', gap=2, adjacent=8, flow_key='nids_flow'),
+            dict(type='TemporalShiftChosenSampleFrames', clip_len=c['clip_len'], frame_interval=c['frame_interval'], num_clips=1, shift_range=1),
+            dict(type='NoriDecode'), dict(type='NormFlowWithStidedAug', ratios=(0.2, 1.8), num_chunks=8, merge_aug=True),
+            dict(type='MoCoRandomResizedCrop', area_range=(0.2, 1.0), flow_key='flow_imgs'),
+            dict(type='MoCoResize', scale=(112, 112), keep_ratio=False, flow_key='flow_imgs', suffix='_q'),
+            dict(type='MoCoResize', scale=(112, 112), keep_ratio=False, flow_key='flow_imgs', suffix='_k'),
+            dict(type='MoCoNormalize', ori_flow=True), dict(type='Collect', keys=['imgs', 'flow_imgs'], meta_keys=[]),
+            dict(type='ToTensor', keys=['imgs', 'flow_imgs'], batched=True)])
+        rng, pyrng = np.random.RandomState(c['seed']), random.Random(c['seed'])
+        for s in c['samples']:
+            d = pipe.draw(c['n_raw'], c['chosen_idx'], tuple(c['img_hw']), tuple(c['flow_hw']), rng, pyrng)
+            assert [int(i) for i in d['flow_inds']] == s['flow_inds'] and [int(i) for i in d['frame_inds']] == s['frame_inds']
+            assert d['cid'] == s['cid']
+            assert [list(map(int, d['box_q'])), list(map(int, d['box_k']))] == s['boxes']
+            assert [list(d['fbox_q']), list(d['fbox_k'])] == s['fboxes']
+        vrng = np.random.RandomState(c['seed'] + 100)
+        vs = data.ChosenSampleFrames(clip_len=c['clip_len'], frame_interval=c['frame_interval'])
+        total = len(odp.match_flow(list(range(c['n_raw']))))
+        for want in c['val_flow_inds']:
+            assert [int(i) for i in vs(total, c['chosen_idx'], vrng)] == want
+    with pytest.raises(NotImplementedError):
+        data.MSCLPipeline.from_cfg([dict(type='Flip')])
+    # the authored config's pipeline sections are the reference's (mscl_r18_cosm_lr2e-2.py:66-87,104), and load
+    norm = lambda x: {k: norm(v) for k, v in x.items()} if isinstance(x, dict) else ([norm(v) for v in x] if isinstance(x, (list, tuple)) else x)
+    ref = gold['ref_pipelines']
+    assert norm(list(cfg.train_pipeline)) == norm(ref['train_pipeline']) and norm(list(cfg.val_pipeline)) == norm(ref['val_pipeline'])
+    assert norm(cfg.evaluation) == norm(ref['evaluation']) and cfg.data.videos_per_gpu == ref['videos_per_gpu']
+    tp, vp = data.MSCLPipeline.from_cfg(cfg.train_pipeline), data.MSCLPipeline.from_cfg(cfg.val_pipeline)
+    assert tp.sampler.n_views == 2 and vp.sampler.n_views == 1 and tp.out_hw == (112, 112) and tp.num_chunks == 8
+
+
+def test_resize_oracle_properties():
+    """oracle/datapath.resize_* restate cv2.resize(INTER_LINEAR) (OpenCV absent: unpinned); what holds by construction:
+    identity at equal size, constants preserved, the exact 2 x 2 area case, half-pixel symmetry (flipping commutes)."""
+    import numpy as np
+    from oracle import datapath as odp
+    g = np.random.RandomState(0)
+    img = g.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    assert np.array_equal(odp.resize_u8(img, 53, 37), img)
+    assert np.array_equal(odp.resize_u8(np.full((20, 31, 3), 200, np.uint8), 112, 112), np.full((112, 112, 3), 200, np.uint8))
+    even = g.randint(0, 256, (48, 64, 3)).astype(np.int64)
+    want = ((even[0::2, 0::2] + even[0::2, 1::2] + even[1::2, 0::2] + even[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(odp.resize_u8(even.astype(np.uint8), 32, 24), want)
+    a, b = odp.resize_u8(img, 112, 112), odp.resize_u8(img[:, ::-1], 112, 112)[:, ::-1]
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    f = g.randn(37, 53, 2).astype(np.float32)
+    assert np.allclose(odp.resize_f32(f, 53, 37), f) and odp.resize_f32(f, 112, 112).shape == (112, 112, 2)
+    up = odp.resize_f32(f, 112, 112)
+    assert up.min() >= f.min() - 1e-6 and up.max() <= f.max() + 1e-6            # convex combinations
