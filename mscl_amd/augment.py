@@ -13,9 +13,14 @@ grayscale with p 0.2 and an 11-tap Gaussian blur with p 0.5 (one sigma in [0.1, 
 decisions are per CLIP (the reference's toVideoAug makes them consistent over time, ssl_aug.py:31-53, 66-70) and so
 are the jitter factors; the four jitter ops run in one random order per call.  The arithmetic runs in the HIP kernels of
 csrc/color_aug.hip from (B,16) parameter rows.  kornia's own random streams cannot be reproduced (it is not available
-and unpinned), so parity for this part is on the arithmetic given the parameters, not on the draws.
+and unpinned), so parity for this part is on the arithmetic given the parameters, not on kornia's draws.  What the
+reference draws in its OWN code is reproduced and pinned (tests/golden/augdraws_g12.json, from the reference's functions):
+the per-clip on/off decision of each op is `Bernoulli(p).sample((clips, 1))` on a torch generator (ssl_aug.py:21-53,
+`clip_decisions`), the blur takes kernel size int(0.1 * crop) // 2 * 2 + 1 and ONE sigma per call from Python's
+random.uniform(0.1, 2.0) (ssl_aug.py:163-171, `blur_sigma`).
 """
 import math
+import random
 
 import torch
 
@@ -41,9 +46,24 @@ class SyncMoCoAugmentV5:
         self.weak_aug = tuple(weak_aug)
         self.blur_ksize = int(0.1 * crop_size) // 2 * 2 + 1          # ssl_aug.py:166
         self._gen = torch.Generator().manual_seed(seed)
+        self._pygen = random.Random(seed)
 
     def seed(self, seed):
         self._gen.manual_seed(seed)
+        self._pygen.seed(seed)
+
+    def clip_decisions(self, B, p):
+        """ssl_aug.py:21-53 (`__video_batch_prob_generator__` with p_batch = 1): one Bernoulli(p) draw per clip, the same for
+        all its frames -- the stream of torch.distributions.Bernoulli(p).sample((B, 1)) on this module's generator"""
+        if p >= 1:
+            return torch.ones(B, dtype=torch.bool)
+        if p <= 0:
+            return torch.zeros(B, dtype=torch.bool)
+        return torch.bernoulli(torch.full((B, 1), float(p)), generator=self._gen).bool().view(-1)
+
+    def blur_sigma(self):
+        """ssl_aug.py:168: one sigma per call (i.e. per view and step), from Python's generator"""
+        return self._pygen.uniform(0.1, 2.0)
 
     def _uniform(self, n, lo, hi):
         return lo + (hi - lo) * torch.rand(n, generator=self._gen)
@@ -53,18 +73,18 @@ class SyncMoCoAugmentV5:
         dict(flip_mask=[(B,) uint8 x2], aug_params=[(B,16) fp32 x2]) -- the keys train_step() looks for."""
         flips, rows = [], []
         for view in range(2):
-            flips.append((torch.rand(B, generator=self._gen) < self.flip_p).to(torch.uint8))
+            flips.append(self.clip_decisions(B, self.flip_p).to(torch.uint8))
             P = torch.zeros(B, K.AUG_PARAMS)
             if not self.weak_aug[view]:
-                P[:, 0] = (torch.rand(B, generator=self._gen) < 0.8).float()
+                P[:, 0] = self.clip_decisions(B, 0.8).float()
                 P[:, 1:5] = torch.randperm(4, generator=self._gen).float()
                 P[:, 5] = self._uniform(B, 0.6, 1.4)
                 P[:, 6] = self._uniform(B, 0.6, 1.4)
                 P[:, 7] = self._uniform(B, 0.6, 1.4)
                 P[:, 8] = self._uniform(B, -0.1, 0.1) * (2.0 * math.pi)
-                P[:, 9] = (torch.rand(B, generator=self._gen) < 0.2).float()
-                sigma = float(self._uniform(1, 0.1, 2.0))
-                P[:, 10] = (torch.rand(B, generator=self._gen) < 0.5).float() * sigma
+                P[:, 9] = self.clip_decisions(B, 0.2).float()
+                sigma = self.blur_sigma()
+                P[:, 10] = self.clip_decisions(B, 0.5).float() * sigma
             rows.append(P)
         return dict(flip_mask=flips, aug_params=rows)
 

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const uint8_t* __re
 __global__ __launch_bounds__(256) void crop_resize_f32_kernel(const float* __restrict__ src, const int* __restrict__ boxes,
                                                               float* __restrict__ out, int B, int T, int Hs, int Ws, int C, int Ho,
                                                               int Wo, long bstride) {
+#pragma clang fp contract(off)       // cv2 computes taps with separate multiplies and adds: no fused multiply-add here
   const long total = (long)B * T * Ho * Wo;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int x = (int)(e % Wo); long r = e / Wo;

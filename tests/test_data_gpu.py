@@ -42,8 +42,8 @@ def test_crop_resize_u8_bit_exact_vs_oracle(H, W, Ho, Wo, dev):
 
 
 def test_crop_resize_f32_and_strided_source(dev):
-    """float maps (the (u, v) flow): same taps, float coefficients, cv2's operation order -> equal to the restatement to the
-    last bit; a source that is a slice along T of a larger upload (batch stride > T*H*W*C) reads the right frames"""
+    """float maps (the (u, v) flow): same taps, float coefficients, cv2's operation order -> equal to the restatement up to
+    an fp32 rounding; a source that is a slice along T of a larger upload (batch stride > T*H*W*C) reads the right frames"""
     from mscl_amd import kernels as K
     from mscl_amd.lib import MsclError
     from oracle import datapath as odp
@@ -56,7 +56,7 @@ def test_crop_resize_f32_and_strided_source(dev):
         got = K.crop_resize(d[:, sl], torch.from_numpy(boxes).to(dev), (28, 36)).cpu().numpy()
         for b in range(B):
             want = odp.crop_resize_normalize(flow[b, sl], boxes[b], (28, 36), u8=False)
-            assert np.array_equal(got[b], want), (sl, b, np.abs(got[b] - want).max())
+            assert np.abs(got[b] - want).max() <= 5e-7 * max(1.0, np.abs(want).max()), (sl, b, np.abs(got[b] - want).max())
     with pytest.raises(MsclError):
         K.crop_resize(d.permute(0, 1, 3, 2, 4), torch.from_numpy(boxes).to(dev), (8, 8))       # not dense in (T,H,W,C)
     with pytest.raises(MsclError):

@@ -335,3 +335,27 @@ def test_resize_oracle_properties():
     assert np.allclose(odp.resize_f32(f, 53, 37), f) and odp.resize_f32(f, 112, 112).shape == (112, 112, 2)
     up = odp.resize_f32(f, 112, 112)
     assert up.min() >= f.min() - 1e-6 and up.max() <= f.max() + 1e-6            # convex combinations
+
+
+def test_augmentation_draws_match_reference_golden():
+    """G12 (tools/oracle/make_golden_augdraws.py): the parts of the stochastic augmentation the reference implements itself --
+    per-clip Bernoulli decisions, VideoRandomApply's frame selection, the blur's kernel size and sigma stream -- reproduced by
+    SyncMoCoAugmentV5's draw helpers from the same seeds.  (kornia's own colour arithmetic and draws stay unpinned.)"""
+    from mscl_amd.registry import build_ssl_aug
+    gold = json.load(open(os.path.join(GOLD, 'augdraws_g12.json')))
+    for d in gold['decisions']:
+        aug = build_ssl_aug(dict(type='SyncMoCoAugmentV5', crop_size=112, t=(d['t'], d['t']), seed=d['seed']))
+        assert aug.clip_decisions(d['clips'], d['p']).int().tolist() == d['per_clip'], d
+    for r in gold['random_apply']:                  # frames of the chosen clips, and only those, are transformed
+        aug = build_ssl_aug(dict(type='SyncMoCoAugmentV5', crop_size=112, t=(r['t'], r['t']), seed=r['seed']))
+        per_clip = aug.clip_decisions(r['clips'], 0.5)
+        assert per_clip.view(-1, 1).repeat(1, r['t']).view(-1).int().tolist() == r['changed']
+    for b in gold['blur']:
+        aug = build_ssl_aug(dict(type='SyncMoCoAugmentV5', crop_size=b['img_size'], t=(8, 8), seed=b['seed']))
+        assert aug.blur_ksize == b['ksize']
+        assert [aug.blur_sigma() for _ in b['sigmas']] == b['sigmas']
+    # draw() composes them: a blurred sample carries the call's one sigma, an unblurred one 0
+    aug = build_ssl_aug(dict(type='SyncMoCoAugmentV5', crop_size=112, t=(8, 8), seed=3, stochastic=True))
+    rows = aug.draw(16)['aug_params'][0]
+    sig = {round(float(v), 6) for v in rows[:, 10] if float(v) > 0}
+    assert len(sig) == 1 and 0.1 <= next(iter(sig)) <= 2.0 and set(rows[:, 0].tolist()) <= {0.0, 1.0}
