@@ -56,7 +56,7 @@ def fill_value(name, shape):
         fan_in, fan_out = shape[1] * rf, shape[0] * rf
         std = math.sqrt(2.0 / (fan_in + fan_out)) if 'neck' in name else math.sqrt(2.0 / fan_out)
         return w * std
-    if len(shape) == 2:                      # linear
+    if len(shape) in (2, 3):                 # linear / Conv1d with a 1-wide kernel
         return w / math.sqrt(3.0 * shape[1])
     if len(shape) == 1:
         if leaf == 'weight':                 # norm scale

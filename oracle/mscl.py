@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nets import BaseMoCo, TPNMoCo, VideoResNet18
+from .nets import BaseMoCo, TPNMoCo, build_trunk
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -79,7 +79,7 @@ class MoCoV2(nn.Module):
         self.iters, self.max_iters, self.batch_size = 0, max_iters, 0
         self.suffix = ('_' + basename) if basename else ''
         mk_neck = (lambda: TPNMoCo(**neck)) if neck is not None else BaseMoCo
-        self.encoder_q, self.encoder_k = VideoResNet18(kind), VideoResNet18(kind)
+        self.encoder_q, self.encoder_k = build_trunk(kind), build_trunk(kind)
         self.neck_q, self.neck_k = mk_neck(), mk_neck()
         mlp = lambda: nn.Sequential(nn.Linear(dim_in, dim_in), nn.ReLU(), nn.Linear(dim_in, dim))
         self.mlp_q, self.mlp_k = mlp(), mlp()
@@ -173,12 +173,15 @@ def cross_modal_logits(q, k, q_flow, k_flow, w_rgb, w_flow, T, same_kn=True):
     return rf, fr, torch.zeros(rf.shape[0], dtype=torch.long, device=rf.device)
 
 
-def lmcl_scores(rgb_map, flow_base_map, flow_aug_map, T):
-    """LMCL similarity.  ref: heads/local_cl_head.py:57-73 (bkb_channels=(None,None) -> Identity
-    transforms): spatial mean -> L2 normalise over C -> bmm -> /T; labels arange(t) per clip."""
+def lmcl_scores(rgb_map, flow_base_map, flow_aug_map, T, trans_flow=None):
+    """LMCL similarity.  ref: heads/local_cl_head.py:57-73: spatial mean -> (flow: Conv1d 1x1 when bkb_channels[1] is set,
+    :30-33; Identity for mscl_r18) -> L2 normalise over C -> bmm -> /T; labels arange(t) per clip."""
     xf = torch.cat((flow_base_map, flow_aug_map), dim=2)
     xr = F.normalize(F.adaptive_avg_pool3d(rgb_map, (None, 1, 1)).flatten(2), dim=1)   # b,c,t
-    xf = F.normalize(F.adaptive_avg_pool3d(xf, (None, 1, 1)).flatten(2), dim=1)         # b,c,2t
+    xf = F.adaptive_avg_pool3d(xf, (None, 1, 1)).flatten(2)                            # b,c,2t
+    if trans_flow is not None:
+        xf = trans_flow(xf)
+    xf = F.normalize(xf, dim=1)
     sim = torch.bmm(xr.transpose(1, 2), xf)                      # b,t,2t
     t = xr.shape[2]
     labels = torch.arange(t, device=sim.device).unsqueeze(0).repeat(xr.shape[0], 1).flatten()
@@ -189,14 +192,27 @@ class MSCLWithAug(nn.Module):
     """ref: recognizers/mscl.py:158-277 for configs/recognition/moco/mscl_r18_cosm_lr2e-2.py."""
 
     def __init__(self, num_frames=8, K=65536, dim=128, m_base=0.994, max_iters=219136 * 400, T=0.07,
-                 weight_aug_flow=(1.0, 1.0), update_aug_flow=False, same_kn=True, normalize_rgb=True):
+                 weight_aug_flow=(1.0, 1.0), update_aug_flow=False, same_kn=True, normalize_rgb=True, arch='r18'):
+        """arch 'r18': mscl_r18_cosm_lr2e-2.py; 'r50': mscl_r50_cosm_lr3e-2.py:14-61 (SlowOnly-50 + r2d_50, sepc stride (1,2,2),
+        one PConv, a Conv1d(256,128,1) on the flow side of the LMCL head)."""
         super().__init__()
-        neck = dict(in_channels=[128, 256, 512], out_channels=128,
-                    sepc_cfg=dict(in_channels=[128, 128, 128], out_channels=128, stride=(2, 2, 2),
-                                  iBN=False, Pconv_num=2))
-        self.recognizer = MoCoV2('rgb', 512, dim, K, m_base, max_iters, T, neck=neck, basename='')
-        self.recognizer_flow = MoCoV2('flow', 128, dim, K, m_base, max_iters, T, neck=None, basename='flow')
+        if arch == 'r18':
+            neck = dict(in_channels=[128, 256, 512], out_channels=128,
+                        sepc_cfg=dict(in_channels=[128, 128, 128], out_channels=128, stride=(2, 2, 2),
+                                      iBN=False, Pconv_num=2))
+            self.recognizer = MoCoV2('rgb', 512, dim, K, m_base, max_iters, T, neck=neck, basename='')
+            self.recognizer_flow = MoCoV2('flow', 128, dim, K, m_base, max_iters, T, neck=None, basename='flow')
+        elif arch == 'r50':
+            neck = dict(in_channels=[512, 1024, 2048], out_channels=128,
+                        sepc_cfg=dict(in_channels=[128, 128, 128], out_channels=128, stride=(1, 2, 2),
+                                      iBN=False, Pconv_num=1))
+            self.recognizer = MoCoV2('rgb50', 2048, dim, K, m_base, max_iters, T, neck=neck, basename='')
+            self.recognizer_flow = MoCoV2('flow50', 256, dim, K, m_base, max_iters, T, neck=None, basename='flow')
+        else:
+            raise ValueError(arch)
         self.sup_head = nn.Module()
+        if arch == 'r50':
+            self.sup_head.trans_flow = nn.Conv1d(256, 128, 1)
         self.sup_head.register_buffer('labels', torch.arange(num_frames // 2).unsqueeze(0))
         self.T, self.same_kn = T, same_kn
         self.weight_aug_flow, self.update_aug_flow = weight_aug_flow, update_aug_flow
@@ -235,7 +251,8 @@ class MSCLWithAug(nn.Module):
                                              self.T, self.same_kn)
             losses.update(ce_with_topk(rf, lab, '_mx_aug'))
             losses.update(ce_with_topk(fr, lab, '_mx_r_aug'))
-        scores, labels = lmcl_scores(f_img['q_mlvl'][0], f_base['q_mlvl'][-1], f_aug['q_mlvl'][-1], self.T)
+        scores, labels = lmcl_scores(f_img['q_mlvl'][0], f_base['q_mlvl'][-1], f_aug['q_mlvl'][-1], self.T,
+                                     getattr(self.sup_head, 'trans_flow', None))
         losses['loss_pos'] = cross_entropy(scores, labels)
         acc = top_k_accuracy(scores.detach().float().cpu().numpy(), labels.cpu().numpy(), (1, 5))
         losses['top1_acc_pos'] = torch.tensor(acc[0], device=scores.device)

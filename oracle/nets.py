@@ -79,6 +79,114 @@ class VideoResNet18(nn.Module):
         return outs
 
 
+class _ConvModuleBN(nn.Module):
+    """mmcv ConvModule with norm_cfg=BN3d: bias-free conv under `.conv`, BatchNorm3d under `.bn`, optional ReLU
+    (call sites backbones/resnet3d.py:262-296,448-459, resnet3d_slowfast.py:157-166)."""
+
+    def __init__(self, cin, cout, kernel, stride, pad, relu):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel, stride, pad, bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x) if self.relu else x
+
+
+class BottleneckUnit(nn.Module):
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + shortcut(x)), the stride on conv2 ('pytorch' style).
+    flavour 'mmcv': mmaction Bottleneck3d (backbones/resnet3d.py:162-330) -- conv1 is 3x1x1 when the block is inflated
+                    ('3x1x1' style) else 1x1x1, conv2 1x3x3, conv3 1x1x1, sub-modules named conv / bn;
+    flavour 'tv'  : the flow trunk's Bottleneck (backbones/fastonly.py:137-183) -- conv1 1x1x1, conv2 Conv3DNoTemporal
+                    (fastonly.py:61-80), sub-modules are nn.Sequential (names 0 / 1)."""
+
+    def __init__(self, cin, planes, stride, downsample, flavour, inflate=False):
+        super().__init__()
+        cout = 4 * planes
+        s3 = (1, stride, stride)
+        if flavour == 'mmcv':
+            k1, p1 = ((3, 1, 1), (1, 0, 0)) if inflate else ((1, 1, 1), (0, 0, 0))
+            self.conv1 = _ConvModuleBN(cin, planes, k1, 1, p1, True)
+            self.conv2 = _ConvModuleBN(planes, planes, (1, 3, 3), s3, (0, 1, 1), True)
+            self.conv3 = _ConvModuleBN(planes, cout, 1, 1, 0, False)
+            self.downsample = _ConvModuleBN(cin, cout, 1, s3, 0, False) if downsample else None
+        else:
+            self.conv1 = _conv_bn(cin, planes, 1, 1, 0, relu=True)
+            self.conv2 = _conv_bn(planes, planes, (1, 3, 3), s3, (0, 1, 1), relu=True)
+            self.conv3 = _conv_bn(planes, cout, 1, 1, 0, relu=False)
+            self.downsample = _conv_bn(cin, cout, 1, s3, 0, relu=False) if downsample else None
+
+    def forward(self, x):
+        y = self.conv3(self.conv2(self.conv1(x)))
+        sc = x if self.downsample is None else self.downsample(x)
+        return F.relu(y + sc)
+
+
+def _bottleneck_stage(cin, planes, blocks, stride, flavour, inflate):
+    units = [BottleneckUnit(cin, planes, stride, stride != 1 or cin != 4 * planes, flavour, inflate)]
+    units += [BottleneckUnit(4 * planes, planes, 1, False, flavour, inflate) for _ in range(blocks - 1)]
+    return nn.Sequential(*units)
+
+
+class SlowOnly50(nn.Module):
+    """ResNet3dSlowOnly depth 50 as configs/recognition/moco/mscl_r50_cosm_lr3e-2.py:16-26 builds it, returning the four
+    stage maps (out_indices (0,1,2,3)).  ref: backbones/resnet3d_slowonly.py:15-52 (inflate (0,0,1,1), no pool2, lateral off),
+    backbones/resnet3d.py:448-467 (stem conv (5,7,7) / stride (2,2,2) / pad (2,3,3) + BN + ReLU, max-pool (1,3,3) / (1,2,2) /
+    (0,1,1)), :407-415 (depth 50 = Bottleneck3d x (3,4,6,3)), resnet3d_slowfast.py:89-204 (make_res_layer: a 1x1x1 shortcut
+    conv + BN whenever stride != 1 or the width changes), resnet3d.py:845-860 (forward)."""
+
+    def __init__(self, conv1_kernel=(5, 7, 7), conv1_stride_t=2, pool1_stride_t=1):
+        super().__init__()
+        pad = tuple((k - 1) // 2 for k in conv1_kernel)
+        self.conv1 = _ConvModuleBN(3, 64, conv1_kernel, (conv1_stride_t, 2, 2), pad, True)
+        self.maxpool = nn.MaxPool3d((1, 3, 3), (pool1_stride_t, 2, 2), (0, 1, 1))
+        cin = 64
+        for li, (planes, blocks, stride, inflate) in enumerate(((64, 3, 1, False), (128, 4, 2, False), (256, 6, 2, True), (512, 3, 2, True)), 1):
+            setattr(self, f'layer{li}', _bottleneck_stage(cin, planes, blocks, stride, 'mmcv', inflate))
+            cin = 4 * planes
+
+    def forward(self, x):
+        x = self.maxpool(self.conv1(x))
+        outs = []
+        for li in range(1, 5):
+            x = getattr(self, f'layer{li}')(x)
+            outs.append(x)
+        return outs
+
+
+class FlowR2D50(nn.Module):
+    """resnet_flow.r2d_50: fastonly.py:431-441 (Bottleneck x (3,4,6,3), Conv3DNoTemporal), :238-262 (inplanes 8, widths
+    8..64 x 4), :222-235 (BottleneckStem: conv (1,7,7) / (2,2,2) / (0,3,3) to 8 channels + BN + ReLU + max-pool (1,3,3) /
+    (1,2,2) / (0,1,1)), :291-310 (_make_layer); forward == the patched multi-level forward (recognizers/moco.py:12-24)."""
+
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv3d(3, 8, (1, 7, 7), (2, 2, 2), (0, 3, 3), bias=False), nn.BatchNorm3d(8), nn.ReLU(inplace=True),
+                                  nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1)))
+        cin = 8
+        for li, (planes, blocks, stride) in enumerate(((8, 3, 1), (16, 4, 2), (32, 6, 2), (64, 3, 2)), 1):
+            setattr(self, f'layer{li}', _bottleneck_stage(cin, planes, blocks, stride, 'tv', False))
+            cin = 4 * planes
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.fc = nn.Identity()
+
+    def forward(self, x):
+        x = self.stem(x)
+        outs = []
+        for li in range(1, 5):
+            x = getattr(self, f'layer{li}')(x)
+            outs.append(x)
+        return outs
+
+
+def build_trunk(kind):
+    """'rgb' / 'flow': the mscl_r18 pair; 'rgb50' / 'flow50': the mscl_r50 pair"""
+    if kind in ('rgb', 'flow'):
+        return VideoResNet18(kind)
+    return SlowOnly50() if kind == 'rgb50' else FlowR2D50()
+
+
 class _BiasConv(nn.Module):
     """mmcv ConvModule with norm_cfg=None, act_cfg=None: a conv with bias under `.conv`
     (call sites necks/fpn.py:131-149)."""

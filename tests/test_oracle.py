@@ -14,14 +14,14 @@ from oracle import fill, mscl as om
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-def _run(tag, max_steps):
+def _run(tag, max_steps, arch='r18', lr=0.02):
     g = np.load(os.path.join(GOLD, f'{tag}.npz'))
     meta = json.loads(str(g['meta']))
     B, T, H, K = meta['B'], meta['T'], meta['H'], meta['K']
-    orc = om.MSCLWithAug(num_frames=T, K=K)
+    orc = om.MSCLWithAug(num_frames=T, K=K, arch=arch)
     fill.fill_module(orc)
     orc.train()
-    opt = om.SGDClip(orc.parameters())
+    opt = om.SGDClip(orc.parameters(), lr=lr)
     keys = [str(k) for k in g['log_keys']]
     names = [str(n) for n in g['param_names']]
     for s in range(min(max_steps, meta['n_steps'])):
@@ -63,6 +63,19 @@ def test_oracle_matches_reference_step_t8():
 def test_oracle_matches_reference_step_t16():
     """the benchmark's clip length (BASELINE.json: 16 x 112^2)"""
     _run('step_b2_t16_h112', 1)
+
+
+def test_oracle_r50_matches_reference_step():
+    """BASELINE.json configs[4] (mscl_r50_cosm_lr3e-2.py: ResNet3dSlowOnly-50 + r2d_50): the restatement against the reference's
+    own step on the same weights and clips (tools/oracle/make_golden_r50.py)"""
+    _run('r50_step_b2_t8_h64', 1, arch='r50', lr=0.0075)
+
+
+def test_oracle_r50_state_dict_is_the_reference_manifest():
+    man = json.load(open(os.path.join(GOLD, 'state_dict_manifest_r50.json')))
+    sd = om.MSCLWithAug(num_frames=8, K=65536, arch='r50').state_dict()
+    skip = ('moco_head', 'moco_mx_head')        # parameter-free heads the oracle folds into functions
+    assert [(n, list(t.shape), str(t.dtype)) for n, t in sd.items()] == [tuple(m) for m in man if not m[0].startswith(skip)]
 
 
 def test_log_keys_are_the_23_reference_keys():

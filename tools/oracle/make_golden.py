@@ -21,10 +21,13 @@ from oracle import fill, mscl as om                   # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
-def sgd_ref(model):
+CFG_OF = {'r18': 'mscl_r18_cosm_lr2e-2.py', 'r50': 'mscl_r50_cosm_lr3e-2.py'}
+
+
+def sgd_ref(model, arch='r18'):
     """The reference's optimizer stack = mmcv OptimizerHook(grad_clip max_norm 40, L2) around
     torch.optim.SGD built from the reference config's `optimizer` dict."""
-    cfg = rh.load_ref_cfg()
+    cfg = rh.load_ref_cfg(CFG_OF[arch])
     o = dict(cfg['optimizer']); o.pop('type')
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, **o)
@@ -42,14 +45,14 @@ def stats(t):
     return np.array([t.mean().item(), t.norm().item()] + t[idx].tolist())
 
 
-def run_steps(B, T, H, n_steps, K, tag, with_feats=True):
+def run_steps(B, T, H, n_steps, K, tag, with_feats=True, arch='r18'):
     torch.manual_seed(0)
-    ref, _ = rh.build_ref_model(num_frames=T, K=K)
-    orc = om.MSCLWithAug(num_frames=T, K=K)
+    ref, _ = rh.build_ref_model(num_frames=T, K=K, cfg_name=CFG_OF[arch])
+    orc = om.MSCLWithAug(num_frames=T, K=K, arch=arch)
     fill.fill_module(ref); fill.fill_module(orc)
     ref.train(); orc.train()
-    opt_r, step_r = sgd_ref(ref)
-    opt_o = om.SGDClip(orc.parameters())
+    opt_r, step_r = sgd_ref(ref, arch)
+    opt_o = om.SGDClip(orc.parameters(), lr=opt_r.defaults['lr'])
     out = {}
     names = [n for n, p in ref.named_parameters() if p.requires_grad]
     for s in range(n_steps):

@@ -92,30 +92,56 @@ def normal_init(module, mean=0, std=1, bias=0):
 
 
 class ConvModule(nn.Module):
-    """conv (+norm) (+act); only the norm_cfg=None path is exercised by TPNMoCo
-    (fpn.py:131-149 passes norm_cfg=None, act_cfg=None -> conv with bias)."""
+    """mmcv.cnn.ConvModule (mmcv-full 1.3.x, absent here), order conv -> norm -> act.  TPNMoCo uses the norm_cfg=None path
+    (fpn.py:131-149: conv with bias); the ResNet3d family (backbones/resnet3d.py:262-296,448-459) uses norm_cfg=BN3d, where
+    mmcv names the norm layer `bn`, drops the conv bias (bias='auto') and initialises conv by kaiming_init / norm to 1."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
                  groups=1, bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'),
                  inplace=True, **kw):
         super().__init__()
-        assert norm_cfg is None, 'harness ConvModule: norm path not needed by the MSCL hot path'
+        self.with_norm = norm_cfg is not None
         if bias == 'auto':
-            bias = True
+            bias = not self.with_norm
         typ = (conv_cfg or dict(type='Conv2d'))['type']
         conv_cls = {'Conv3d': nn.Conv3d, 'Conv2d': nn.Conv2d, 'Conv1d': nn.Conv1d}[typ]
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
                              dilation=dilation, groups=groups, bias=bias)
-        self.activate = nn.ReLU(inplace=inplace) if act_cfg is not None else None
+        if self.with_norm:
+            assert norm_cfg['type'] == 'BN3d' and typ == 'Conv3d', norm_cfg
+            self.bn = nn.BatchNorm3d(out_channels)
+            for p in self.bn.parameters():
+                p.requires_grad = norm_cfg.get('requires_grad', True)
+        self.activate = nn.ReLU(inplace=(act_cfg or {}).get('inplace', inplace)) if act_cfg is not None else None
         nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
         if bias:
             nn.init.constant_(self.conv.bias, 0)
 
+    @property
+    def norm(self):
+        return self.bn
+
     def forward(self, x):
         x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
         if self.activate is not None:
             x = self.activate(x)
         return x
+
+
+def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+    if getattr(module, 'weight', None) is not None:
+        (nn.init.kaiming_uniform_ if distribution == 'uniform' else nn.init.kaiming_normal_)(
+            module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def build_activation_layer(cfg):
+    cfg = dict(cfg)
+    assert cfg.pop('type') == 'ReLU', cfg
+    return nn.ReLU(**cfg)
 
 
 def auto_fp16(*a, **k):
@@ -152,10 +178,11 @@ def install():
     mm_models = Registry('models')
     _mod('mmcv')
     _mod('mmcv.cnn', MODELS=mm_models, ConvModule=ConvModule, xavier_init=xavier_init,
-         constant_init=constant_init, normal_init=normal_init, kaiming_init=lambda *a, **k: None)
+         constant_init=constant_init, normal_init=normal_init, kaiming_init=kaiming_init,
+         NonLocal3d=None, build_activation_layer=build_activation_layer)
     _mod('mmcv.utils', Registry=Registry, _BatchNorm=nn.modules.batchnorm._BatchNorm,
-         build_from_cfg=build_from_cfg, get_logger=lambda *a, **k: MagicMock())
-    _mod('mmcv.runner', auto_fp16=auto_fp16, _load_checkpoint=None, load_state_dict=None)
+         build_from_cfg=build_from_cfg, get_logger=lambda *a, **k: MagicMock(), print_log=lambda *a, **k: None)
+    _mod('mmcv.runner', auto_fp16=auto_fp16, _load_checkpoint=None, load_state_dict=None, load_checkpoint=None)
     _mod('torchvision')
     _mod('torchvision.models')
     _mod('torchvision.models.utils', load_state_dict_from_url=None)
@@ -197,6 +224,12 @@ def install():
     mscl.forward = moco.forward            # missing symbol
     imp('mmaction.models.heads.moco_head_v2')
     fastonly = imp('mmaction.models.backbones.fastonly')
+    # resnet3d_slowonly.py:2 has a stray, unused `from turtle import forward` (an editor auto-import); the stdlib module needs
+    # tkinter, which this image lacks, so an empty shell satisfies the import
+    _mod('turtle', forward=None)
+    imp('mmaction.models.backbones.resnet3d')
+    imp('mmaction.models.backbones.resnet3d_slowfast')
+    slowonly = imp('mmaction.models.backbones.resnet3d_slowonly')      # registers ResNet3dSlowOnly (mscl_r50 RGB trunk)
 
     # deterministic aug used on both sides (SURVEY.md §8c "OracleAug"): RGB -> ImageNet normalise
     # (ssl_aug_v2.py:66-68); flow views are fed already visualised, flow_normalizer is Identity
@@ -226,7 +259,7 @@ def install():
         dist.init_process_group('gloo', rank=0, world_size=1)
 
     _installed.update(builder=builder, moco=moco, mscl=mscl, r3d=r3d, fastonly=fastonly,
-                      necks=necks, accuracy=acc)
+                      necks=necks, accuracy=acc, slowonly=slowonly)
     return _installed
 
 
@@ -238,11 +271,11 @@ def load_ref_cfg(name='mscl_r18_cosm_lr2e-2.py'):
     return ns
 
 
-def build_ref_model(num_frames=8, K=65536):
+def build_ref_model(num_frames=8, K=65536, cfg_name='mscl_r18_cosm_lr2e-2.py'):
     """Unmodified reference `model` dict, except: deterministic aug, sup_head.t from num_frames
     (the config derives it the same way, mscl_r18_cosm_lr2e-2.py:47), optional small K."""
     h = install()
-    cfg = load_ref_cfg()
+    cfg = load_ref_cfg(cfg_name)
     model = cfg['model']
     model['aug'] = dict(type='OracleAug')
     model['sup_head']['t'] = num_frames // 2
