@@ -47,16 +47,19 @@ def loss_close(got, ref, what):
     assert abs(got - ref) <= 0.02 * max(1.0, abs(ref)) + 0.03, f'{what}: hip {got} vs ref {ref}'
 
 
-def logs_match(got, ref, what, rows=None, loss_tol=2e-3):
+def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None):
     """all log entries of a step against the reference / oracle: losses to `loss_tol` relative, accuracies exactly (they are
     k / rows for an integer k; `rows` given -> at most one row may flip, for full-size batches where a positive sits within
-    bf16 noise of the 5th-largest negative)"""
+    bf16 noise of the 5th-largest negative).  `pos_rows`: row count of the LMCL scores (B * t); with the closed-form weights
+    the frame similarities of a clip sit within bf16 noise of one another at step 0 (top-1 is at chance), so one of those
+    rows may change rank against the fp32 reference (seen: 5/16 vs 4/16 on one box, equal on others)."""
     assert list(got.keys()) == list(ref.keys()), (list(got.keys()), list(ref.keys()))
     for k, v in ref.items():
         if 'loss' in k:
             assert abs(got[k] - v) <= loss_tol * max(1.0, abs(v)), f'{what} {k}: hip {got[k]} vs ref {v}'
         else:
-            slack = 1e-6 if rows is None else 1.0 / rows + 1e-6
+            r = pos_rows if (k.endswith('_pos') and pos_rows) else rows
+            slack = 1e-6 if r is None else 1.0 / r + 1e-6
             assert abs(got[k] - v) <= slack, f'{what} {k}: hip {got[k]} vs ref {v}'
 
 
@@ -94,13 +97,13 @@ def test_step_vs_golden_and_oracle(tag, dev):
         assert list(out['log_vars'].keys()) == keys
         gold = OrderedDict(zip(keys, (float(v) for v in g[f's{s}_log_vals'])))
         if s == 0:          # later steps diverge chaotically even between fp32 implementations; step 0 is pinned
-            logs_match(out['log_vars'], gold, f'{tag} golden step{s}')
+            logs_match(out['log_vars'], gold, f'{tag} golden step{s}', pos_rows=B * (T // 2))
         opt.zero_grad()
         out['loss'].backward()
         torch.manual_seed(100 + s)
         oo = orc.train_step(batch); oopt.zero_grad(); oo['loss'].backward()
         if s == 0:
-            logs_match(out['log_vars'], oo['log_vars'], f'{tag} oracle step{s}')
+            logs_match(out['log_vars'], oo['log_vars'], f'{tag} oracle step{s}', pos_rows=B * (T // 2))
             cos = torch.nn.functional.cosine_similarity
             for nm, a, b in (('q_rgb', model._dbg['q_rgb'], orc._features['img']['q']),
                              ('k_rgb', model._dbg['k_rgb'], orc._features['img']['k']),
