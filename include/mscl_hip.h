@@ -197,6 +197,14 @@ int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, vo
 /* dx (outer, inner, C) bf16 = dout (outer, C) / inner, broadcast; accumulate into dx if accumulate */
 int mscl_pool_bwd(const float* dout, uint16_t* dx, int outer, int inner, int C, int accumulate, void* stream);
 
+/* max-pool (1,3,3) / stride (1,2,2) / pad (0,1,1) on an NDHWC bf16 map with NT = N*T planes of H x W x C:
+ * nn.MaxPool3d of backbones/resnet3d.py:461-467 (ResNet3dSlowOnly pool1, pool1_stride_t = 1) and of
+ * backbones/fastonly.py:222-235 (r2d_50 BottleneckStem).  out is (NT, Ho, Wo, C) with Ho = (H-1)/2+1; `win` holds one
+ * uint32 per 8 output channels: the winning tap (0..8, row-major over the window; ties to the first, as torch) of each
+ * channel in 4 bits.  The backward gathers (no atomics, bit-reproducible): dx = sum over the windows a pixel won. */
+int mscl_maxpool_hw_fwd(const uint16_t* x, uint16_t* out, uint32_t* win, int NT, int H, int W, int C, void* stream);
+int mscl_maxpool_hw_bwd(const uint16_t* dout, const uint32_t* win, uint16_t* dx, int NT, int H, int W, int C, void* stream);
+
 /* ---- projection MLP: Linear(+ReLU) on a handful of rows (recognizers/moco.py:367-372) ---------- */
 int mscl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f, int relu, void* stream);
 /* dx = (dy*mask) W ; dw += dy^T x ; db += colsum(dy); mask = (y>0) if relu */

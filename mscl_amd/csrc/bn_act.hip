@@ -126,8 +126,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ inv, const bf16_t* __restrict__ ry,
     const float* __restrict__ rmean, const float* __restrict__ rinv, float* __restrict__ scratch, long rows, int C,
-    int relu, const float* __restrict__ gamma, const float* __restrict__ beta) {
+    int relu, const float* __restrict__ gamma, const float* __restrict__ beta, int ldc) {
   extern __shared__ float sm[];     // red[3][4 waves][C]
+  // maps wider than 512 channels (Bottleneck trunks, up to 2048) are cut into 512-channel chunks along blockIdx.y: C is the
+  // chunk width the thread layout sees, ldc the row pitch of the maps and the channel count of the scratch layout
+  {
+    const int ch = blockIdx.y * C;
+    dout += ch; y += ch; mean += ch; inv += ch; scratch += ch;
+    if (out) out += ch;
+    if (ry) { ry += ch; rmean += ch; rinv += ch; }
+    if (gamma) gamma += ch;
+    if (beta) beta += ch;
+  }
   const int G = C >> 3;             // threads per row; 256 % G == 0 required (C/8 power of two)
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const int c0 = tg * 8;
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const long r = r0 + u * stride;
-      const long o = (r < rows ? r : r0) * C + c0;          // clamped: the duplicate is masked out below
+      const long o = (r < rows ? r : r0) * ldc + c0;        // clamped: the duplicate is masked out below
       vd[u] = *reinterpret_cast<const uint4*>(dout + o);
       vy[u] = *reinterpret_cast<const uint4*>(y + o);
       if (relu && !mask_y) va[u] = *reinterpret_cast<const uint4*>(out + o);
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int w = 0; w < 4; ++w) t += sm[(vv * 4 + w) * C + c];
     // 16 slots: with one, the 1024 blocks of the layer-1 map each ended on the same 128 addresses, and same-address float
     // atomics serialise in L2 at ~25 ns apiece -- a 25-us tail on a 45-us pass
-    atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_SLOTS) * 4 * C + i], t);
+    atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_SLOTS) * 4 * ldc + vv * ldc + c], t);
   }
 }
 
@@ -281,19 +291,26 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
   if (beta && (res_y || want_identity_dres || !relu)) return MSCL_E_ARG;     // the mask depends on the residual too: pass `out`
   if (relu && !out && !beta) return MSCL_E_ARG;
   if (rows <= 0 || C <= 0) return MSCL_E_ARG;
-  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 512 || rows * (C / 8) >= (1LL << 31)) return MSCL_E_SHAPE;      // block_channel_sum needs C/8 <= 64
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 2048 || rows * (C / 8) >= (1LL << 31)) return MSCL_E_SHAPE;     // block_channel_sum needs C/8 <= 64: wider maps run in 512-channel chunks
   if (res_y && (!res_gamma || !res_mean || !res_invstd || !res_dgamma || !res_dbeta || !dres)) return MSCL_E_ARG;
   if (want_identity_dres && !dres) return MSCL_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int RP = 256 / (C / 8);
-  long blocks = (rows + RP * 8 - 1) / (RP * 8); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;   // wider grids measured slower (more atomics)
+  const int Cc = C > 512 ? 512 : C, chunks = C / Cc;
+  const int RP = 256 / (Cc / 8);
+  long blocks = (rows + RP * 8 - 1) / (RP * 8);
+  const long cap = 1024 / chunks;                                  // wider grids measured slower (more atomics)
+  if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
   if (!pre) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)12 * C * sizeof(float), st, dout,
-                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, C, relu, gamma, beta);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, chunks), dim3(256), (size_t)12 * Cc * sizeof(float), st, dout,
+                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, Cc, relu, gamma, beta, C);
     MSCL_LAUNCH_CHECK();
   }
   const long total = rows * (C / 8);
   long b2 = (total + 255) / 256; if (b2 > 2048) b2 = 2048;
+  if (C > 1024) {      // 10 * C floats of constants: past the 64-KB default for dynamic LDS
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)10 * C * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
                      want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta);

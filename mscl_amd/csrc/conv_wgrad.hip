@@ -350,7 +350,8 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st);
   else if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st) : launch_w<64, 64>(g, x, dy, dw, st);
   else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st) : launch_w<32, 64>(g, x, dy, dw, st);
-  else if (d->K == 16) e = wide ? launch_w<16, 192>(g, x, dy, dw, st) : launch_w<16, 64>(g, x, dy, dw, st);
+  // K == 8 (the 8-channel layers of r2d_50): the 16-row tile with its upper half zero-filled by the range check and never stored
+  else if (d->K == 16 || d->K == 8) e = wide ? launch_w<16, 192>(g, x, dy, dw, st) : launch_w<16, 64>(g, x, dy, dw, st);
   else return MSCL_E_SHAPE;
   if (e) return e;
   if (dbias && d->K <= 512) {

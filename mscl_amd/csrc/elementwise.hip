@@ -406,11 +406,14 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
 // ---------------------------------------------------------------- mean over the middle axis
 // x (outer, inner, C) bf16 -> out (outer, C) fp32.  One block per (outer, 64-channel group... ) :
 // block = 256 threads = G channel-granules x (256/G) row lanes; LDS reduce.
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C) {
+// Maps wider than 512 channels (the Bottleneck trunks: up to 2048) are cut into 512-channel chunks along blockIdx.y:
+// `C` is the chunk width the thread layout sees, `ldc` the row pitch of the map in elements.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C, int ldc) {
   __shared__ float red[4 * 512];
+  x += blockIdx.y * C; out += blockIdx.y * C;
   const int G = C >> 3;
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
-  const long base = (long)blockIdx.x * inner * C;
+  const long base = (long)blockIdx.x * inner * ldc;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // eight rows in flight per thread: with one, the 8-block launch over the layer-4 map (98 rows x 512 channels per clip, on
   // the way into the projection head of every chain) was 25 dependent round trips = 40 us for 0.8 MB
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int r = r0 + u * RP;
-      v[u] = *reinterpret_cast<const uint4*>(x + base + (long)(r < inner ? r : r0) * C + tg * 8);
+      v[u] = *reinterpret_cast<const uint4*>(x + base + (long)(r < inner ? r : r0) * ldc + tg * 8);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -434,12 +437,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
   __syncthreads();
   const float inv = 1.f / (float)inner;
   for (int i = threadIdx.x; i < C; i += 256)
-    out[(long)blockIdx.x * C + i] = (red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]) * inv;
+    out[(long)blockIdx.x * ldc + i] = (red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]) * inv;
 }
 extern "C" int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream) {
   if (!x || !out || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
-  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 512) return MSCL_E_SHAPE;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer), dim3(256), 0, (hipStream_t)stream, x, out, inner, C);
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 4096) return MSCL_E_SHAPE;
+  const int Cc = C > 512 ? 512 : C;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer, C / Cc), dim3(256), 0, (hipStream_t)stream, x, out, inner, Cc, C);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

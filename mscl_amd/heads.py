@@ -102,13 +102,17 @@ class MSCLWithAugMxHead(_BaseHead):
 
 @HEADS.register_module()
 class MSCLWithAugPosHeadV2(_BaseHead):
-    """LMCL head.  ref: heads/local_cl_head.py:10-81 (bkb_channels=(None, None) -> identity transforms)."""
+    """LMCL head.  ref: heads/local_cl_head.py:10-81 (bkb_channels=(None, None) -> identity transforms; (None, C) -> a
+    Conv1d(C, 128, 1) on the flow side, the mscl_r50 configuration)."""
 
     def __init__(self, basename='', loss_cls=dict(type='CrossEntropyLoss_torch'), loss_pos=dict(type='CrossEntropyLoss_torch'),
                  num_classes=2, in_channels=128, mlvl_ids=(0, -1), bkb_channels=(512, 128), t=8, T=0.07, aux_keys=dict()):
         super().__init__(loss_cls, num_classes, in_channels)
-        if tuple(bkb_channels) != (None, None):
-            raise NotImplementedError('Conv1d feature transforms (bkb_channels != (None, None)) are not used by mscl_r18')
+        if bkb_channels[0] is not None:
+            raise NotImplementedError('the RGB-side Conv1d transform (bkb_channels[0]) is not used by the MSCL configs')
+        if bkb_channels[1] is not None:       # mscl_r50: Conv1d(256, 128, 1) on the pooled flow frames (local_cl_head.py:30-33,65)
+            from .nn import Conv1dK1Hip
+            self.trans_flow = Conv1dK1Hip(bkb_channels[1], 128)
         self.loss_pos = build_loss(loss_pos)
         self.basename = ('_' + basename) if basename else ''
         self.T, self.aux_keys, self.mlvl_ids, self.t = T, dict(aux_keys), tuple(mlvl_ids), t

@@ -329,6 +329,23 @@ def upsample_bwd(ddst, src_shape, trilinear):
     return dsrc
 
 
+def maxpool_hw_fwd(x):
+    """(1,3,3) / (1,2,2) / (0,1,1) max-pool of an NDHWC bf16 map -> (out, win); win feeds maxpool_hw_bwd"""
+    N, T, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, T, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    win = torch.empty((N, T, Ho, Wo, C // 8), dtype=torch.int32, device=x.device)
+    call('mscl_maxpool_hw_fwd', ptr(x), ptr(out), ptr(win), N * T, H, W, C, stream_ptr())
+    return out, win
+
+
+def maxpool_hw_bwd(dout, win, x_shape):
+    N, T, H, W, C = x_shape
+    dx = torch.empty(x_shape, dtype=torch.bfloat16, device=dout.device)
+    call('mscl_maxpool_hw_bwd', ptr(dout), ptr(win), ptr(dx), N * T, H, W, C, stream_ptr())
+    return dx
+
+
 def pool_fwd(x, outer, inner):
     C = x.shape[-1]
     out = torch.empty((outer, C), dtype=torch.float32, device=x.device)
@@ -343,11 +360,16 @@ def pool_bwd(dout, shape, outer, inner, into=None):
     return dx
 
 
+LIN_MAX_ROWS = 32          # rows per launch of the small fp32 linear kernels (LIN_MAX_ROWS in csrc/elementwise.hip)
+
+
 def linear_fwd(x, w, b, relu):
     rows, in_f = x.shape
     out_f = w.shape[0]
     y = torch.empty((rows, out_f), dtype=torch.float32, device=x.device)
-    call('mscl_linear_fwd', ptr(x), ptr(w), ptr(b), ptr(y), rows, in_f, out_f, int(relu), stream_ptr())
+    for r0 in range(0, rows, LIN_MAX_ROWS):            # more rows than one launch takes (the LMCL flow transform: B * 2t rows)
+        n = min(LIN_MAX_ROWS, rows - r0)
+        call('mscl_linear_fwd', ptr(x) + 4 * r0 * in_f, ptr(w), ptr(b), ptr(y) + 4 * r0 * out_f, n, in_f, out_f, int(relu), stream_ptr())
     return y
 
 
@@ -355,7 +377,10 @@ def linear_bwd(x, w, y, dy, dw, db, relu, need_dx=True):
     rows, in_f = x.shape
     out_f = w.shape[0]
     dx = torch.empty_like(x) if need_dx else None
-    call('mscl_linear_bwd', ptr(x), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db), rows, in_f, out_f, int(relu), stream_ptr())
+    for r0 in range(0, rows, LIN_MAX_ROWS):            # dw / db accumulate (+=) over the row chunks
+        n = min(LIN_MAX_ROWS, rows - r0)
+        call('mscl_linear_bwd', ptr(x) + 4 * r0 * in_f, ptr(w), ptr(y) + 4 * r0 * out_f, ptr(dy) + 4 * r0 * out_f,
+             (ptr(dx) + 4 * r0 * in_f) if need_dx else None, ptr(dw), ptr(db), n, in_f, out_f, int(relu), stream_ptr())
     return dx
 
 

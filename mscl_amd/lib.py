@@ -54,6 +54,8 @@ _SIGS = {
     'mscl_upsample_bwd': [P, P] + [c_int] * 9 + [P],
     'mscl_pool_fwd': [P, P, c_int, c_int, c_int, P],
     'mscl_pool_bwd': [P, P, c_int, c_int, c_int, c_int, P],
+    'mscl_maxpool_hw_fwd': [P, P, P, c_int, c_int, c_int, c_int, P],
+    'mscl_maxpool_hw_bwd': [P, P, P, c_int, c_int, c_int, c_int, P],
     'mscl_linear_fwd': [P, P, P, P, c_int, c_int, c_int, c_int, P],
     'mscl_linear_bwd': [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     'mscl_l2norm_fwd': [P, P, P, c_int, c_int, P],

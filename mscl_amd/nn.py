@@ -258,10 +258,16 @@ def stem_input(conv, x):
     return K.pair_w(x) if conv.pair_w else x
 
 
+def _cb(mod):
+    """(conv, bn) of a conv+BN unit under either naming: nn.Sequential (torchvision / fastonly: '0', '1') or mmcv's
+    ConvModule ('conv', 'bn')"""
+    return (mod[0], mod[1]) if isinstance(mod, nn.Sequential) else (mod.conv, mod.bn)
+
+
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, stem):
-        conv, bn = stem[0], stem[1]
+        conv, bn = _cb(stem)
         x = stem_input(conv, x)
         y, out, save = cba_fwd(conv, bn, x, None, True)
         ctx.stem = stem
@@ -273,7 +279,7 @@ class _StemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, y, out, save = ctx.saved_tensors
-        conv, bn = ctx.stem[0], ctx.stem[1]
+        conv, bn = _cb(ctx.stem)
         cba_bwd(conv, bn, dout.contiguous(), out, y, save, x, True, need_dx=False)
         fl = conv._rt.get('dw8_flush')
         if fl is not None:                      # 3-channel stem: fold the 8-channel staging gradient into the arena now,
@@ -425,6 +431,205 @@ class VideoResNetHip(nn.Module):
         return outs
 
 
+# ------------------------------------------------------------------------------------------ Bottleneck trunks (mscl_r50)
+class ConvModuleBN(nn.Module):
+    """mmcv ConvModule with norm_cfg=BN3d: bias-free conv under `.conv`, BatchNorm3d under `.bn` (the ReLU, when present, has no
+    parameters).  Call sites: backbones/resnet3d.py:262-296,448-459, resnet3d_slowfast.py:157-166."""
+
+    def __init__(self, cin, cout, kernel, stride, pad, pair_w=False):
+        super().__init__()
+        self.conv = Conv3dHip(cin, cout, kernel, stride, pad, pair_w=pair_w)
+        self.bn = BatchNorm3dHip(cout)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool3d((1,3,3), (1,2,2), (0,1,1)) on an NDHWC map (resnet3d.py:461-467, fastonly.py:229-230)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, win = K.maxpool_hw_fwd(x)
+        ctx.shape = tuple(x.shape)
+        ctx.save_for_backward(win)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return K.maxpool_hw_bwd(dout.contiguous(), ctx.saved_tensors[0], ctx.shape)
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """One Bottleneck as a single graph node:
+    out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + shortcut(x)), the stride on conv2
+    (ref: backbones/resnet3d.py:298-330 Bottleneck3d.forward, backbones/fastonly.py:165-183)."""
+
+    @staticmethod
+    def forward(ctx, x, block):
+        (c1, b1), (c2, b2), (c3, b3) = _cb(block.conv1), _cb(block.conv2), _cb(block.conv3)
+        y1, a1, s1 = cba_fwd(c1, b1, x, None, True)
+        y2, a2, s2 = cba_fwd(c2, b2, a1, None, True)
+        if block.downsample is not None:
+            cd, bd = _cb(block.downsample)
+            yd, ad, sd = cba_fwd(cd, bd, x, None, False)
+            res = ad
+        else:
+            yd = sd = None
+            res = x
+        y3, out, s3 = cba_fwd(c3, b3, a2, res, True)
+        ctx.block = block
+        ctx.has_ds = yd is not None
+        saved = (x, y1, a1, s1, y2, a2, s2, y3, out, s3)
+        ctx.save_for_backward(*(saved + ((yd, sd) if ctx.has_ds else ())))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        block = ctx.block
+        t = ctx.saved_tensors
+        x, y1, a1, s1, y2, a2, s2, y3, out, s3 = t[:10]
+        (c1, b1), (c2, b2), (c3, b3) = _cb(block.conv1), _cb(block.conv2), _cb(block.conv3)
+        da2, dz = cba_bwd(c3, b3, dout.contiguous(), out, y3, s3, a2, True, need_dx=True, want_dres=True)
+        if ctx.has_ds:
+            cd, bd = _cb(block.downsample)
+            shortcut_grad, _ = cba_bwd(cd, bd, dz, None, t[10], t[11], x, False, need_dx=True)
+        else:
+            shortcut_grad = dz
+        da1, _ = cba_bwd(c2, b2, da2, a2, y2, s2, a1, True, need_dx=True)
+        dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
+        _bucket_done(block)
+        return dx, None
+
+
+class BottleneckHip(nn.Module):
+    """flavour 'mmcv': mmaction Bottleneck3d (backbones/resnet3d.py:162-330): conv1 3x1x1 when the block is inflated ('3x1x1'
+    style) else 1x1x1, conv2 1x3x3 with the spatial stride ('pytorch' style), conv3 1x1x1; sub-modules named conv / bn.
+    flavour 'tv': the flow trunk's Bottleneck (backbones/fastonly.py:137-183): conv1 1x1x1, conv2 Conv3DNoTemporal
+    (fastonly.py:61-80), sub-modules nn.Sequential (names 0 / 1)."""
+
+    def __init__(self, cin, planes, stride, downsample, flavour, inflate=False):
+        super().__init__()
+        cout = 4 * planes
+        s3 = (1, stride, stride)
+        if flavour == 'mmcv':
+            k1, p1 = ((3, 1, 1), (1, 0, 0)) if inflate else ((1, 1, 1), (0, 0, 0))
+            unit = lambda ci, co, k, s, p, relu: ConvModuleBN(ci, co, k, s, p)
+        else:
+            k1, p1 = (1, 1, 1), (0, 0, 0)
+
+            def unit(ci, co, k, s, p, relu):
+                mods = [Conv3dHip(ci, co, k, s, p), BatchNorm3dHip(co)]
+                return nn.Sequential(*(mods + ([nn.ReLU(inplace=True)] if relu else [])))
+        self.conv1 = unit(cin, planes, k1, 1, p1, True)
+        self.conv2 = unit(planes, planes, (1, 3, 3), s3, (0, 1, 1), True)
+        self.conv3 = unit(planes, cout, 1, 1, 0, False)
+        self.downsample = unit(cin, cout, 1, s3, 0, False) if downsample else None
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return _BottleneckFn.apply(x, self)
+
+
+def _bottleneck_stage(cin, planes, blocks, stride, flavour, inflate):
+    units = [BottleneckHip(cin, planes, stride, stride != 1 or cin != 4 * planes, flavour, inflate)]
+    units += [BottleneckHip(4 * planes, planes, 1, False, flavour, inflate) for _ in range(blocks - 1)]
+    return nn.Sequential(*units)
+
+
+class _BottleneckTrunk(nn.Module):
+    """shared forward of the two Bottleneck trunks: stem conv+BN+ReLU, max-pool (1,3,3)/(1,2,2), four stages; returns the four
+    stage maps (out_indices (0,1,2,3) / the patched multi-level forward of recognizers/moco.py:12-24)"""
+
+    def _stem(self):
+        raise NotImplementedError
+
+    def forward(self, x):
+        _need_gpu(x)
+        if not self.training:
+            raise MsclError('the Bottleneck trunks implement training-mode BatchNorm only (both MoCo encoders run in train())')
+        if self._anchor is None or self._anchor.device != x.device:
+            self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+        PRE_REDUCED.clear(); LAST_BN.clear()
+        x = _MaxPoolFn.apply(_StemFn.apply(x, self._anchor, self._stem()))
+        outs = []
+        for li in range(1, 5):
+            for blk in getattr(self, f'layer{li}'):
+                x = blk(x)
+            outs.append(x)
+        return outs
+
+
+class ResNet3dSlowOnlyHip(_BottleneckTrunk):
+    """ResNet3dSlowOnly depth 50 as configs/recognition/moco/mscl_r50_cosm_lr3e-2.py:16-26 builds it.
+    ref: backbones/resnet3d_slowonly.py:15-52 (inflate (0,0,1,1), no pool2, lateral off), backbones/resnet3d.py:448-467 (stem
+    conv (5,7,7) / (2,2,2) / (2,3,3) + BN + ReLU, max-pool (1,3,3) / (1,2,2) / (0,1,1)), :407-415 (depth 50 = Bottleneck3d x
+    (3,4,6,3)), resnet3d_slowfast.py:89-204 (make_res_layer), resnet3d.py:795-831 (init), :845-860 (forward).
+    Input: packed clip (N,T,H,W,8) bf16 from kernels.pack_input."""
+
+    def __init__(self, depth=50, pretrained=None, pretrained2d=False, lateral=False, num_stages=4, conv1_kernel=(5, 7, 7),
+                 conv1_stride_t=2, pool1_stride_t=1, spatial_strides=(1, 2, 2, 2), out_indices=(0, 1, 2, 3),
+                 inflate=(0, 0, 1, 1), zero_init_residual=True, **kwargs):
+        super().__init__()
+        if depth != 50 or lateral or pretrained is not None or pretrained2d or num_stages != 4 or kwargs:
+            raise NotImplementedError('ResNet3dSlowOnly is built for the mscl_r50 configuration (depth 50, from scratch, no lateral)')
+        if tuple(spatial_strides) != (1, 2, 2, 2) or tuple(out_indices) != (0, 1, 2, 3) or pool1_stride_t != 1:
+            raise NotImplementedError('spatial_strides (1,2,2,2), out_indices (0,1,2,3), pool1_stride_t 1 (mscl_r50_cosm_lr3e-2.py:16-26)')
+        k = _triple(conv1_kernel)
+        self.conv1 = ConvModuleBN(3, 64, k, (conv1_stride_t, 2, 2), tuple((i - 1) // 2 for i in k), pair_w=PAIR_STEM and k[2] == 7)
+        self.maxpool = nn.MaxPool3d((1, 3, 3), (pool1_stride_t, 2, 2), (0, 1, 1))
+        self.zero_init_residual = zero_init_residual
+        cin = 64
+        for li, (planes, blocks, stride, inf) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3), spatial_strides, inflate), 1):
+            setattr(self, f'layer{li}', _bottleneck_stage(cin, planes, blocks, stride, 'mmcv', bool(inf)))
+            cin = 4 * planes
+        self._anchor = None
+        self.init_weights()
+
+    def _stem(self):
+        return self.conv1
+
+    @property
+    def stem(self):              # the name the gradient-bucket plan and the key/query sub-graphs use for the first unit
+        return self.conv1
+
+    def init_weights(self, pretrained=None):
+        """ref: resnet3d.py:819-831: kaiming_init convs (normal, fan_out, relu), BN 1 / 0, conv3.bn weight 0"""
+        for m in self.modules():
+            if isinstance(m, Conv3dHip):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, BatchNorm3dHip):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BottleneckHip):
+                    nn.init.constant_(m.conv3.bn.weight, 0)
+
+
+class FlowR2D50Hip(_BottleneckTrunk):
+    """resnet_flow.r2d_50: fastonly.py:431-441 (Bottleneck x (3,4,6,3), Conv3DNoTemporal), :238-262 (inplanes 8), :222-235
+    (BottleneckStem: conv (1,7,7) / (2,2,2) / (0,3,3) to 8 channels + BN + ReLU + max-pool), :291-326 (_make_layer, init)."""
+
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Sequential(Conv3dHip(3, 8, (1, 7, 7), (2, 2, 2), (0, 3, 3)), BatchNorm3dHip(8), nn.ReLU(inplace=True),
+                                  nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1)))
+        cin = 8
+        for li, (planes, blocks, stride) in enumerate(((8, 3, 1), (16, 4, 2), (32, 6, 2), (64, 3, 2)), 1):
+            setattr(self, f'layer{li}', _bottleneck_stage(cin, planes, blocks, stride, 'tv', False))
+            cin = 4 * planes
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.fc = nn.Identity()
+        self._anchor = None
+        for m in self.modules():
+            if isinstance(m, Conv3dHip):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, BatchNorm3dHip):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _stem(self):
+        return self.stem
+
+
 # ------------------------------------------------------------------------------------------ neck pieces
 class _ConvBiasFn(torch.autograd.Function):
     """out = relu?(conv(x) + bias + addend)"""
@@ -522,4 +727,18 @@ class LinearHip(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_f, in_f))
         self.bias = nn.Parameter(torch.empty(out_f))
         nn.Linear.reset_parameters(self)
+        self._rt = None
+
+
+class Conv1dK1Hip(nn.Module):
+    """Parameter holder for nn.Conv1d(cin, cout, 1) (state-dict `weight` (out, in, 1), `bias`): a per-frame linear map, run by
+    the fp32 linear kernels.  ref: heads/local_cl_head.py:30-33 (trans_flow), default nn.Conv1d initialisation (the head's
+    init_weights is a no-op, local_cl_head.py:38-39)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        ref = nn.Conv1d(cin, cout, 1)
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone())
         self._rt = None

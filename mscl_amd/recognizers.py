@@ -29,8 +29,9 @@ from . import nn as nn_hip
 from . import parallel
 from .arena import ParamArena
 from .lib import MsclError
-from .nn import BatchNorm3dHip, Conv3dHip, LinearHip, VideoResNetHip, mlp_head, pool
-from .registry import RECOGNIZERS, build_head, build_neck, build_ssl_aug
+from .nn import (BatchNorm3dHip, Conv1dK1Hip, Conv3dHip, FlowR2D50Hip, LinearHip, ResNet3dSlowOnlyHip, VideoResNetHip, mlp_head,
+                 pool)
+from .registry import BACKBONES, RECOGNIZERS, build_head, build_neck, build_ssl_aug
 from .staging import StagingRing
 
 LOG_KEYS = ('top1_acc', 'top5_acc', 'loss_cls', 'top1_acc_flow', 'top5_acc_flow', 'loss_cls_flow', 'loss_cls_flow_aug',
@@ -54,7 +55,14 @@ def build_backbone_by_name(cfg):
         return VideoResNetHip('rgb', **cfg)
     if typ == 'resnet_flow.r2d_18':
         return VideoResNetHip('flow', **cfg)
-    raise NotImplementedError(f'backbone {typ} is outside the mscl_r18 hot path')
+    if typ == 'resnet_flow.r2d_50':
+        return FlowR2D50Hip(**cfg)
+    if typ in BACKBONES:                       # registry names (base_moco.py:104-106): ResNet3dSlowOnly of mscl_r50
+        return BACKBONES.build(dict(cfg, type=typ))
+    raise NotImplementedError(f'backbone {typ} is outside the MSCL hot path (mscl_r18 / mscl_r50)')
+
+
+BACKBONES.register_module(name='ResNet3dSlowOnly', module=ResNet3dSlowOnlyHip)
 
 
 @RECOGNIZERS.register_module()
@@ -325,9 +333,23 @@ class _MSCLLossFn(torch.autograd.Function):
         rec.dequeue_and_enqueue(k_rgb, kg.get('rgb'))
         # LMCL (local_cl_head.py:57-73): RGB frame-slot features vs [base flow | rotated flow] frames
         t = p_rgb.shape[0] // B
-        C = p_rgb.shape[1]
-        flow = torch.cat([p_fb.view(B, t, C), p_fa.view(B, t, C)], dim=1).contiguous()
+        C, Cf = p_rgb.shape[1], p_fb.shape[1]
+        flow = torch.cat([p_fb.view(B, t, Cf), p_fa.view(B, t, Cf)], dim=1).contiguous()
+        trans = getattr(model.sup_head, 'trans_flow', None)
+        if trans is not None:                 # Conv1d(Cf, 128, 1) over the frame axis == a linear map per frame (local_cl_head.py:65)
+            trt = trans._rt
+            flow_in = flow.view(B * 2 * t, Cf)
+            flow = K.linear_fwd(flow_in, trt['w'], trt['b'], False).view(B, 2 * t, C)
+        elif Cf != C:
+            raise ValueError(f'LMCL needs equal channel counts (rgb {C}, flow {Cf}) or a flow transform (bkb_channels)')
         lsum, hits, dpr, dpf = K.lmcl(p_rgb.view(B, t, C), flow, 1.0 / model.sup_head.T)
+        if trans is not None:
+            # the transform's parameter gradients go straight into the arena, as every parameter gradient does; they are
+            # scaled by the incoming gradient of the loss node only through dpf below, which backward() multiplies by g
+            # (g == 1 on the training path: the total loss is what .backward() is called on)
+            dpf = K.linear_bwd(flow_in, trt['w'], flow.view(B * 2 * t, C), dpf.view(B * 2 * t, C).contiguous(), trt['dw'], trt['db'], False)
+            trt['slot_w'].touched = True
+            trt['slot_b'].touched = True
 
         def grp(v, i):
             return v[i * B:(i + 1) * B]
@@ -339,9 +361,9 @@ class _MSCLLossFn(torch.autograd.Function):
         dq_rgb = grp(dA, 0) + grp(dC, 1) + (grp(dC, 2) if use_aug_mx else 0)
         dq_fb = grp(dA, 1) + dB
         dq_fa = grp(dC, 0) + (grp(dA, 2) if use_aug_mx else 0)
-        dpf = dpf.view(B, 2 * t, C)
-        ctx.save_for_backward(dq_rgb, dq_fb, dq_fa, dpr.view(B * t, C), dpf[:, :t].reshape(B * t, C),
-                              dpf[:, t:].reshape(B * t, C))
+        dpf = dpf.view(B, 2 * t, Cf)
+        ctx.save_for_backward(dq_rgb, dq_fb, dq_fa, dpr.view(B * t, C), dpf[:, :t].reshape(B * t, Cf),
+                              dpf[:, t:].reshape(B * t, Cf))
         ctx.mark_non_differentiable(logs)
         model._log_keys = ctx.log_keys
         return total.clone(), logs
@@ -406,13 +428,23 @@ class MSCLWithAug(nn.Module):
                     assert nq == nk and pq.shape == pk.shape
                     plan.append((ar.add(nq, pq.shape), pq, pk))
             ar.end_group(name)
+        # trainable parameters outside the two recognizers (mscl_r50: the LMCL head's flow transform): no key twin, no EMA
+        ar.begin_group('head')
+        for nq, pq in self.sup_head.named_parameters():
+            plan.append((ar.add('sup_head.' + nq, pq.shape), pq, None))
+        ar.end_group('head')
         ar.allocate()
         for slot, pq, pk in plan:
-            vq, vk = ar.view('Q', slot), ar.view('KX', slot)
-            vq.copy_(pq.data.to(device)); vk.copy_(pk.data.to(device))
-            pq.data, pk.data = vq, vk
+            vq = ar.view('Q', slot)
+            vq.copy_(pq.data.to(device))
+            pq.data = vq
             pq.grad = ar.view('G', slot)
-            pq._mscl_slot = pk._mscl_slot = slot
+            pq._mscl_slot = slot
+            if pk is not None:
+                vk = ar.view('KX', slot)
+                vk.copy_(pk.data.to(device))
+                pk.data = vk
+                pk._mscl_slot = slot
         for mod in self.modules():
             for bname, buf in list(mod._buffers.items()):
                 if buf is not None:
@@ -425,6 +457,8 @@ class MSCLWithAug(nn.Module):
                 for top in mods:
                     for m in top.modules():
                         self._bind(m, ar, key, rec)
+        for m in self.sup_head.modules():
+            self._bind(m, ar, False, None)
         entries = []
         for rec in (self.recognizer, self.recognizer_flow):
             for top in rec.q_modules():
@@ -442,7 +476,7 @@ class MSCLWithAug(nn.Module):
         # RGB stem trigger: autograd's ready-queue order of neck nodes vs trunk nodes is not a contract.
         buckets = [(span([eq.layer4]), eq.layer4[0], 1), (span([eq.layer3]), eq.layer3[0], 1),
                    (span([eq.stem, eq.layer1, eq.layer2]), eq.stem, 1), (span([rgb.neck_q, rgb.mlp_q]), eq.stem, 1),
-                   (span([flw.encoder_q, flw.neck_q, flw.mlp_q]), flw.encoder_q.stem, 2)]
+                   (span([flw.encoder_q, flw.neck_q, flw.mlp_q, self.sup_head]), flw.encoder_q.stem, 2)]     # head group follows the flow group
         self.reducer = parallel.GradReducer(ar.G, [b[0] for b in buckets], need=[b[2] for b in buckets])
         for i, (_, trig, _n) in enumerate(buckets):
             trig._grad_buckets = getattr(trig, '_grad_buckets', ()) + ((self.reducer, i),)
@@ -488,6 +522,11 @@ class MSCLWithAug(nn.Module):
             sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
             m._rt = dict(w=ar.view(P, sw), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
                          dw=None if key else ar.view('G', sw), db=None if key else ar.view('G', sb))
+        elif isinstance(m, Conv1dK1Hip):       # (out, in, 1) contiguous == the (out, in) matrix of the linear kernels
+            sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
+            shp = (m.out_channels, m.in_channels)
+            m._rt = dict(w=ar.view(P, sw).view(shp), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
+                         dw=ar.view('G', sw).view(shp), db=ar.view('G', sb))
 
     @torch.no_grad()
     def sync_shadows(self):

@@ -27,11 +27,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-def build(num_frames, K, dev):
+CFG_FILES = {'r18': 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py', 'r50': 'configs/recognition/moco/mscl_r50_cosm_lr3e-2.py'}
+
+
+def build(num_frames, K, dev, arch='r18'):
     import mscl_amd
     from mscl_amd import Config, build_model
     from mscl_amd.fill import fill_module
-    cfg = Config.fromfile(os.path.join(os.path.dirname(GOLD), '..', 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    cfg = Config.fromfile(os.path.join(os.path.dirname(GOLD), '..', CFG_FILES[arch]))
     cfg.model.sup_head.t = num_frames // 2
     cfg.model.recognizer.K = K
     cfg.model.recognizer_flow.K = K
@@ -63,56 +66,89 @@ def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None):
             assert abs(got[k] - v) <= slack, f'{what} {k}: hip {got[k]} vs ref {v}'
 
 
-def _autocast_yardstick(batch, T, Kq, ref_grads):
+def _autocast_yardstick(batch, T, Kq, ref_grads, arch='r18'):
     """per-tensor gradient cosine of the oracle under torch.autocast(cpu, bfloat16) vs its fp32 run"""
     from oracle import fill as ofill, mscl as om
-    o2 = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(o2); o2.train()
+    o2 = om.MSCLWithAug(num_frames=T, K=Kq, arch=arch); ofill.fill_module(o2); o2.train()
     torch.manual_seed(100)
     with torch.autocast('cpu', dtype=torch.bfloat16):
         out = o2.train_step(batch)
     out['loss'].backward()
     cos = torch.nn.functional.cosine_similarity
+    _autocast_yardstick.last = (out['log_vars'], {k: {n: v[n].detach().float() for n in ('q', 'k')} for k, v in o2._features.items()})
     return {n: float(cos(p.grad.flatten().float(), ref_grads[n].flatten(), dim=0))
             for n, p in o2.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize('tag', ['step_b2_t8_h112', 'step_b2_t16_h112'])
+def logs_within_bf16_yardstick(got, ref, auto, what, rows, pos_rows):
+    """mscl_r50 at the goldens' batch of 2: 53 BatchNorm layers on maps of a few dozen elements per channel amplify bf16 rounding
+    until the layer-4 maps of ANY bf16 pipeline sit at cosine 0.91 (RGB) / 0.87 (flow) against fp32 -- measured for plain PyTorch
+    autocast on the oracle (tools/dbg_r50.py prints the HIP path's: 0.9998 / 0.998 / 0.979 / 0.913, autocast 0.9998 / 0.998 /
+    0.978 / 0.911).  So the HIP step is held to the deviation `auto` (the oracle under torch.autocast(cpu, bf16)) shows against
+    the fp32 reference: every loss term within 2 x the largest deviation autocast shows on any term (floor 2e-3 relative), the
+    total within 2 x the sum of them; the InfoNCE accuracies equal; the LMCL accuracies (frame similarities at chance level at
+    step 0) within two rows plus autocast's own change."""
+    assert list(got.keys()) == list(ref.keys()), (list(got.keys()), list(ref.keys()))
+    dev = {k: abs(auto[k] - v) for k, v in ref.items() if 'loss' in k and k != 'loss'}
+    D, S = max(dev.values()), sum(dev.values())
+    for k, v in ref.items():
+        if k == 'loss':
+            assert abs(got[k] - v) <= max(2e-3 * abs(v), 2 * S), f'{what} {k}: hip {got[k]} vs ref {v} (autocast {auto[k]})'
+        elif 'loss' in k:
+            assert abs(got[k] - v) <= max(2e-3 * max(1.0, abs(v)), 2 * D), f'{what} {k}: hip {got[k]} vs ref {v} (autocast {auto[k]})'
+        elif k.endswith('_pos'):
+            assert abs(got[k] - v) <= 2.0 / pos_rows + abs(auto[k] - v) + 1e-6, f'{what} {k}: hip {got[k]} vs ref {v} (autocast {auto[k]})'
+        else:
+            assert abs(got[k] - v) <= 1e-6, f'{what} {k}: hip {got[k]} vs ref {v}'
+
+
+@pytest.mark.parametrize('tag', ['step_b2_t8_h112', 'step_b2_t16_h112', 'r50_step_b2_t8_h64', 'r50_step_b2_t8_h112'])
 def test_step_vs_golden_and_oracle(tag, dev):
     """T=8 is the shipped config's clip length, T=16 the benchmark's (BASELINE.json); both goldens come from the reference's
-    own classes (tools/oracle/make_golden.py)."""
+    own classes (tools/oracle/make_golden.py).  The r50_* tags are BASELINE.json configs[4]: mscl_r50_cosm_lr3e-2.py
+    (ResNet3dSlowOnly-50 + r2d_50, Bottleneck blocks, max-pool stems, the LMCL head's flow transform), goldens from
+    tools/oracle/make_golden_r50.py."""
     from mscl_amd import ClipSGD
     from mscl_amd.synthetic import synthetic_batch
     from oracle import fill as ofill, mscl as om
+    arch = 'r50' if tag.startswith('r50') else 'r18'
     g = np.load(os.path.join(GOLD, f'{tag}.npz'))
     meta = json.loads(str(g['meta']))
     B, T, H, Kq = meta['B'], meta['T'], meta['H'], meta['K']
-    model, cfg = build(T, Kq, dev)
+    model, cfg = build(T, Kq, dev, arch)
     opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
-    orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
-    oopt = om.SGDClip(orc.parameters())
+    orc = om.MSCLWithAug(num_frames=T, K=Kq, arch=arch); ofill.fill_module(orc); orc.train()
+    oopt = om.SGDClip(orc.parameters(), lr=cfg.optimizer.lr)
     keys = [str(k) for k in g['log_keys']]
     for s in range(min(2, meta['n_steps'])):
         batch = synthetic_batch(B, T, H, H, 0, s)
         out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
         assert list(out['log_vars'].keys()) == keys
         gold = OrderedDict(zip(keys, (float(v) for v in g[f's{s}_log_vals'])))
-        if s == 0:          # later steps diverge chaotically even between fp32 implementations; step 0 is pinned
+        if s == 0 and arch == 'r18':   # later steps diverge chaotically even between fp32 implementations; step 0 is pinned
             logs_match(out['log_vars'], gold, f'{tag} golden step{s}', pos_rows=B * (T // 2))
         opt.zero_grad()
         out['loss'].backward()
         torch.manual_seed(100 + s)
         oo = orc.train_step(batch); oopt.zero_grad(); oo['loss'].backward()
         if s == 0:
-            logs_match(out['log_vars'], oo['log_vars'], f'{tag} oracle step{s}', pos_rows=B * (T // 2))
+            yard = _autocast_yardstick(batch, T, Kq, {n: p.grad for n, p in orc.named_parameters()}, arch)
+            auto_logs, auto_feat = _autocast_yardstick.last
             cos = torch.nn.functional.cosine_similarity
-            for nm, a, b in (('q_rgb', model._dbg['q_rgb'], orc._features['img']['q']),
-                             ('k_rgb', model._dbg['k_rgb'], orc._features['img']['k']),
-                             ('q_flow', model._dbg['q_fb'], orc._features['base']['q']),
-                             ('q_flow_aug', model._dbg['q_fa'], orc._features['aug']['q'])):
-                c = cos(a.float().cpu(), b.detach(), dim=1).min().item()
-                assert c >= 0.995, f'{nm} cosine {c}'
+            if arch == 'r18':
+                logs_match(out['log_vars'], oo['log_vars'], f'{tag} oracle step{s}', pos_rows=B * (T // 2))
+            else:
+                pos_rows = B * cfg.model.sup_head.t
+                logs_within_bf16_yardstick(out['log_vars'], gold, auto_logs, f'{tag} golden step{s}', B, pos_rows)
+                logs_within_bf16_yardstick(out['log_vars'], oo['log_vars'], auto_logs, f'{tag} oracle step{s}', B, pos_rows)
+            for nm, a, grp, w in (('q_rgb', model._dbg['q_rgb'], 'img', 'q'), ('k_rgb', model._dbg['k_rgb'], 'img', 'k'),
+                                  ('q_flow', model._dbg['q_fb'], 'base', 'q'), ('q_flow_aug', model._dbg['q_fa'], 'aug', 'q')):
+                b = orc._features[grp][w].detach()
+                c = cos(a.float().cpu(), b, dim=1).min().item()
+                # r18: 0.995 flat; r50: what autocast reaches on the same rows, less 0.01 (see logs_within_bf16_yardstick)
+                bar = 0.995 if arch == 'r18' else min(0.995, cos(auto_feat[grp][w], b, dim=1).min().item() - 0.01)
+                assert c >= bar, f'{nm} cosine {c} (bar {bar})'
             # gradients
-            yard = _autocast_yardstick(batch, T, Kq, {n: p.grad for n, p in orc.named_parameters()})
             tot_h, tot_o, bad = 0.0, 0.0, []
             gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
             for (n, p), (n2, q) in zip(model.named_parameters(), orc.named_parameters()):
@@ -128,6 +164,9 @@ def test_step_vs_golden_and_oracle(tag, dev):
                 if float(go.norm()) >= 0.01 * gn_o:
                     c = float(cos(gh.flatten(), go.flatten(), dim=0))
                     y = yard[n] if yard[n] == yard[n] else 0.97       # CPU autocast itself can produce NaN gradients
+                    if y < 0.5:
+                        continue        # a tensor whose direction PyTorch's own bf16 run cannot resolve at this batch size
+                                        # (r2d_50's 8-channel layers at B = 2: yardstick 0.12-0.27); the norm check covers it
                     if c < min(0.995, y - 0.06):
                         bad.append((n, c, yard[n]))
             assert not bad, bad
@@ -139,8 +178,11 @@ def test_step_vs_golden_and_oracle(tag, dev):
             assert int(rec.queue_ptr) == int(g[f's{s}_{nm}_ptr'])
             assert rec.iters == int(g[f's{s}_{nm}_iters']) and rec.batch_size == int(g[f's{s}_{nm}_bs'])
             assert abs(rec.m - float(g[f's{s}_{nm}_m'])) < 1e-12
-            vals, cnts = np.unique(rec.count.cpu().numpy(), return_counts=True)
-            assert np.array_equal(np.stack([vals, cnts]), g[f's{s}_{nm}_count_hist'])
+            if f's{s}_{nm}_count' in g:                 # small queues are stored whole, K = 65536 as a histogram
+                assert np.array_equal(rec.count.cpu().numpy(), g[f's{s}_{nm}_count'])
+            else:
+                vals, cnts = np.unique(rec.count.cpu().numpy(), return_counts=True)
+                assert np.array_equal(np.stack([vals, cnts]), g[f's{s}_{nm}_count_hist'])
 
 
 def test_bookkeeping_40_steps_small_queue(dev):
@@ -956,6 +998,58 @@ def test_r3d18_single_stream_full_size(dev):
     for li, (a, b) in enumerate(zip(maps, omaps)):
         a = a.detach().float().cpu().permute(0, 4, 1, 2, 3)          # NDHWC -> NCDHW
         c = float(cos(a.flatten(), b.detach().flatten(), dim=0))
+        assert c >= 0.995, f'layer{li + 1} map cosine {c}'
+    assert abs(float(loss) - float(oloss)) <= 0.02 * abs(float(oloss)) + 1e-3
+    gp = dict(model.recognizer.encoder_q.named_parameters())
+    go = dict(orc.recognizer.encoder_q.named_parameters())
+    tot_h = sum(float(p.grad.double().pow(2).sum()) for p in gp.values()) ** 0.5
+    tot_o = sum(float(p.grad.double().pow(2).sum()) for p in go.values() if p.grad is not None) ** 0.5
+    assert abs(tot_h - tot_o) <= 0.08 * tot_o, (tot_h, tot_o)
+    bad = []
+    for n, p in go.items():
+        if p.grad is None or float(p.grad.norm()) < 0.01 * tot_o:
+            continue
+        c = float(cos(gp[n].grad.float().cpu().flatten(), p.grad.flatten(), dim=0))
+        if c < 0.90:
+            bad.append((n, c))
+    assert not bad, bad
+
+
+def test_slowonly50_trunk_32x224(dev):
+    """BASELINE.json configs[4]: the ResNet3dSlowOnly-50 trunk (Bottleneck blocks, (5,7,7) stem, max-pool) forward + backward on
+    a (2, 3, 32, 224, 224) batch -- the clip size of the deep / large-activation case -- against the oracle trunk on the host
+    (fp32; the oracle is pinned to the reference's own step by tests/golden/r50_step_*.npz).  Same bf16 tolerances as the
+    R3D-18 trunk test: stage maps cosine >= 0.995, gradient norm within 8 %, per-tensor gradient cosine >= 0.90 on tensors
+    carrying >= 1 % of the norm."""
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    B, T, H = 2, 32, 224
+    model, _ = build(8, 64, dev, 'r50')
+    orc = om.MSCLWithAug(num_frames=8, K=64, arch='r50'); ofill.fill_module(orc); orc.train()
+    # The closed-form fill gives every BatchNorm a weight of order one; 16 Bottleneck blocks with full-strength residual
+    # branches at batch 2 are then chaotic in bf16: PyTorch's own autocast run of the oracle keeps a gradient cosine of only
+    # 0.12-0.2 against fp32 on EVERY tensor, so no bf16 implementation could be told right from wrong.  Damping the last
+    # BatchNorm of each block (x 0.1, on both sides) is the regime the reference initialises into (zero_init_residual,
+    # resnet3d.py:826-829); there autocast reaches >= 0.975 per tensor and 0.9999 per map, and the flat bars below bind.
+    with torch.no_grad():
+        for net in (model.recognizer.encoder_q, orc.recognizer.encoder_q):
+            for n, p in net.named_parameters():
+                if n.endswith('conv3.bn.weight'):
+                    p.mul_(0.1)
+    x = synthetic_batch(B, T, H, H, 0, 0)['imgs'][0]
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1, 1); std = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1, 1)
+    model.zero_grad()
+    maps = model.recognizer.encoder_q(model.aug_gpu.pack_rgb(x.to(dev)))
+    loss = maps[-1].float().mean() + maps[1].float().mean()
+    loss.backward()
+    omaps = orc.recognizer.encoder_q((x - mean) / std)
+    oloss = omaps[-1].mean() + omaps[1].mean()
+    oloss.backward()
+    cos = torch.nn.functional.cosine_similarity
+    assert [tuple(m.shape) for m in maps] == [(B, 16, 56, 56, 256), (B, 16, 28, 28, 512), (B, 16, 14, 14, 1024), (B, 16, 7, 7, 2048)]
+    for li, (a, b) in enumerate(zip(maps, omaps)):
+        a = a.detach().double().cpu().permute(0, 4, 1, 2, 3)          # NDHWC -> NCDHW
+        c = float(cos(a.flatten(), b.detach().double().flatten(), dim=0))
         assert c >= 0.995, f'layer{li + 1} map cosine {c}'
     assert abs(float(loss) - float(oloss)) <= 0.02 * abs(float(oloss)) + 1e-3
     gp = dict(model.recognizer.encoder_q.named_parameters())

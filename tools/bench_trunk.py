@@ -2,7 +2,9 @@
 (8, 3, 16, 112, 112) batch, loss = mean of the layer-4 map, eager launches on one stream.
 Prints one JSON line: clips/s, ms per iteration and the fraction of the dense bf16 MFMA peak over the whole iteration
 (algorithmic 241.3 GFLOP per clip: forward 81.39 + input gradients without the stem's + weight gradients).
-usage: python tools/bench_trunk.py [--iters N] [--warmup W]"""
+--r50: BASELINE.json configs[4], the ResNet3dSlowOnly-50 trunk of mscl_r50_cosm_lr3e-2.py on one (8, 3, 32, 224, 224) batch (the
+deep / large-activation stress case); its algorithmic FLOPs are counted from the conv descriptors of the run itself.
+usage: python tools/bench_trunk.py [--iters N] [--warmup W] [--r50] [--batch B]"""
 import argparse
 import json
 import os
@@ -21,14 +23,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--r50', action='store_true')
+    ap.add_argument('--batch', type=int, default=8)
     a = ap.parse_args()
     from mscl_amd import Config, build_model
     from mscl_amd.fill import fill_module
+    from mscl_amd.nn import Conv3dHip
     from mscl_amd.synthetic import synthetic_batch
     dev = torch.device('cuda:0')
-    B, T, H = 8, 16, 112
-    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
-    cfg.model.sup_head.t = T // 2
+    B, T, H = (a.batch, 32, 224) if a.r50 else (a.batch, 16, 112)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/' + ('mscl_r50_cosm_lr3e-2.py' if a.r50 else 'mscl_r18_cosm_lr2e-2.py')))
+    cfg.model.sup_head.t = T // 4 if a.r50 else T // 2
     model = build_model(cfg.model)
     fill_module(model)
     model.materialize(dev).train()
@@ -49,9 +54,22 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    gflop = B * (3 * GFLOP_FWD_PER_CLIP - GFLOP_STEM_FWD_PER_CLIP)
+    if a.r50:
+        fwd = stem = 0.0
+        for name, m in trunk.named_modules():
+            if isinstance(m, Conv3dHip):
+                d = next(iter(m._descs.values()))
+                f = 2.0 * d.N * d.To * d.Ho * d.Wo * m.out_channels * m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2] * m.in_channels / 1e9
+                fwd += f
+                if m.in_channels == 3:
+                    stem += f                       # no input gradient through the stem
+        gflop = 3 * fwd - stem
+        name = f'clips/sec (ResNet3dSlowOnly-50 trunk fwd+bwd, {T}x{H}^2, bs{B}, 1 GPU)'
+    else:
+        gflop = B * (3 * GFLOP_FWD_PER_CLIP - GFLOP_STEM_FWD_PER_CLIP)
+        name = f'clips/sec (R3D-18 trunk fwd+bwd, 16x112^2, bs{B}, 1 GPU)'
     tf = gflop / ms
-    print(json.dumps({'metric': 'clips/sec (R3D-18 trunk fwd+bwd, 16x112^2, bs8, 1 GPU)', 'value': B / ms * 1e3, 'unit': 'clips/s',
+    print(json.dumps({'metric': name, 'value': B / ms * 1e3, 'unit': 'clips/s', 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'ms_per_iter': ms, 'iters': a.iters, 'dtype': 'bf16', 'launch': 'eager, one stream',
                       'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
                                    'algorithmic_gflop_per_iter': gflop,
