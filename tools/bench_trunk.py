@@ -56,24 +56,36 @@ def main():
     ms = e0.elapsed_time(e1) / a.iters
     if a.r50:
         fwd = stem = 0.0
+        hbm = 0.0       # bytes the passes of this implementation must move when nothing stays in cache between kernels: per
+                        # conv + BatchNorm unit with X input and Y output elements (bf16): forward conv X + Y, BN apply 2Y (+Y
+                        # residual); backward BN reduce 2Y, BN apply 3Y, weight gradient X + Y, input gradient Y + X = 3X + 10Y
         for name, m in trunk.named_modules():
             if isinstance(m, Conv3dHip):
                 d = next(iter(m._descs.values()))
                 f = 2.0 * d.N * d.To * d.Ho * d.Wo * m.out_channels * m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2] * m.in_channels / 1e9
                 fwd += f
+                X = d.N * d.T * d.H * d.W * d.C
+                Y = d.N * d.To * d.Ho * d.Wo * m.out_channels
+                hbm += 2.0 * (3 * X + 10 * Y)
                 if m.in_channels == 3:
                     stem += f                       # no input gradient through the stem
         gflop = 3 * fwd - stem
+        extra = {'hbm_roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': 8000.0, 'pass_bytes_per_iter_gb': hbm / 1e9,
+                                  'achieved': hbm / 1e9 / (ms / 1e3), 'frac': hbm / 1e9 / (ms / 1e3) / 8000.0,
+                                  'note': 'sum over conv+BatchNorm units of 3X + 10Y bf16 elements (the passes as implemented, every '
+                                          'map read from / written to HBM once per pass): the 205-MB maps of layers 1-2 make this '
+                                          'configuration HBM-bound, not MFMA-bound'}}
         name = f'clips/sec (ResNet3dSlowOnly-50 trunk fwd+bwd, {T}x{H}^2, bs{B}, 1 GPU)'
     else:
         gflop = B * (3 * GFLOP_FWD_PER_CLIP - GFLOP_STEM_FWD_PER_CLIP)
         name = f'clips/sec (R3D-18 trunk fwd+bwd, 16x112^2, bs{B}, 1 GPU)'
+        extra = {}
     tf = gflop / ms
     print(json.dumps({'metric': name, 'value': B / ms * 1e3, 'unit': 'clips/s', 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
                       'ms_per_iter': ms, 'iters': a.iters, 'dtype': 'bf16', 'launch': 'eager, one stream',
                       'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
                                    'algorithmic_gflop_per_iter': gflop,
-                                   'note': 'whole iteration incl. BatchNorm passes and launch gaps, not one kernel'}}))
+                                   'note': 'whole iteration incl. BatchNorm passes and launch gaps, not one kernel'}, **extra}))
 
 
 if __name__ == '__main__':
