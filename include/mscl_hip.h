@@ -46,6 +46,13 @@ int mscl_abi_version(void);
 int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w_bf16, uint16_t* y,
                     const float* bias, const uint16_t* addend, int relu,
                     float* stat_sum, float* stat_sq, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
+/* The same with `stat_groups` BatchNorm statistics groups: the batch holds stat_groups calls of the reference's module
+ * (the base and the rotated flow clips of recognizers/mscl.py:239-240, which the reference feeds through the flow encoder
+ * one after the other, each with its own batch statistics); samples [k*N/G, (k+1)*N/G) feed the k-th [slot][2][C] block of
+ * stat_sum / stat_sq (G * MSCL_STAT_SLOTS * 2 * K floats).  One launch instead of G for the convolution itself. */
+int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w_bf16, uint16_t* y,
+                           const float* bias, const uint16_t* addend, int relu, float* stat_sum, float* stat_sq,
+                           int stat_groups, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
 /* splitk_ws: optional fp32 scratch of splitk_ws_floats floats; when it holds >= 2 copies of the output and
  * the layer has too few position tiles to fill 256 CUs, the K loop is split over the grid (one fp32 slab
  * per split, then a summing finalize pass that also applies the epilogue and the BN statistics). */
@@ -106,6 +113,14 @@ int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn,
                     const uint16_t* residual, const mscl_bn_params* res_bn,
                     uint16_t* out, int64_t rows, int C, float eps, float momentum, int relu, void* stream);
 
+/* The same over `groups` (1 or 2) BatchNorm statistics groups (see mscl_conv3d_fwd_groups): rows [k*rows/G, (k+1)*rows/G)
+ * are normalised with the k-th [slot][2][C] block of bn->sum / bn->sumsq; save_mean / save_invstd hold [G][C] floats; the
+ * running statistics take the groups' momentum updates one after the other in group order and num_batches_tracked grows
+ * by G -- exactly what the reference's G consecutive calls of the module do (recognizers/mscl.py:239-240). */
+int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* bn,
+                           const uint16_t* residual, const mscl_bn_params* res_bn,
+                           uint16_t* out, int64_t rows, int C, float eps, float momentum, int relu, int groups, void* stream);
+
 /* backward of the above.  dz = dout * (out > 0 if relu).  Pass 1 reduces dgamma/dbeta (accumulated
  * into the fp32 gradient buffers, caller-zeroed) and keeps the sums in `scratch` (MSCL_STAT_SLOTS * 4*C
  * floats, caller-zeroed: blocks spread their partial sums over the slots); pass 2 writes dy (and dres: dz itself for an identity residual, the BN input
@@ -122,6 +137,16 @@ int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y
                     float* res_dgamma, float* res_dbeta,
                     uint16_t* dy, uint16_t* dres, int want_identity_dres,
                     float* scratch, int64_t rows, int C, int relu, void* stream);
+
+/* with statistics groups: save_mean / save_invstd (and the residual's) are [G][C], scratch is [G][MSCL_STAT_SLOTS][4*C];
+ * dgamma / dbeta receive the sum over the groups (relu = 2 is not available with G > 1) */
+int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out, const uint16_t* y,
+                           const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                           float* dgamma, float* dbeta,
+                           const uint16_t* res_y, const float* res_gamma, const float* res_mean, const float* res_invstd,
+                           float* res_dgamma, float* res_dbeta,
+                           uint16_t* dy, uint16_t* dres, int want_identity_dres,
+                           float* scratch, int64_t rows, int C, int relu, int groups, void* stream);
 
 /* ---- layout / elementwise ---------------------------------------------------------------------
  * frames [t_off, t_off+T) of (B,Cin<=3,T_total,H,W) fp32 NCTHW -> (B,T,H,W,8) bf16 NDHWC, channels Cin..7

@@ -97,16 +97,16 @@ class SyncMoCoAugmentV5:
     def pack_rgb(self, x, flip=None):
         return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, flip=flip)
 
-    def pack_flow(self, x, t_off, T, flip=None):
+    def pack_flow(self, x, t_off, T, flip=None, out=None):
         if x.shape[1] == 2:                     # raw (u, v): FlowVisualizer fused into the packing pass
             if not self.visualize:
                 raise NotImplementedError('visualize=False with 2-channel flow: the flow trunk takes 3 input channels')
             if self.normalize_flow:
                 raise NotImplementedError('normalize_flow=True on raw uv flow (the shipped config uses False)')
-            return K.flow_visualize(x.contiguous(), t_off=t_off, T=T, flip=flip)
+            return K.flow_visualize(x.contiguous(), t_off=t_off, T=T, flip=flip, out=out)
         if self.normalize_flow:
-            return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, t_off=t_off, T=T, flip=flip)
-        return K.pack_input(x.contiguous(), t_off=t_off, T=T, flip=flip)
+            return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, t_off=t_off, T=T, flip=flip, out=out)
+        return K.pack_input(x.contiguous(), t_off=t_off, T=T, flip=flip, out=out)
 
 
 @SSL_AUGS.register_module()
@@ -125,7 +125,7 @@ class IdentityAug:
     def pack_rgb(self, x, flip=None):
         return K.pack_input(x.contiguous(), flip=flip)
 
-    def pack_flow(self, x, t_off, T, flip=None):
+    def pack_flow(self, x, t_off, T, flip=None, out=None):
         if x.shape[1] == 2:
-            return K.flow_visualize(x.contiguous(), t_off=t_off, T=T, flip=flip)
-        return K.pack_input(x.contiguous(), t_off=t_off, T=T, flip=flip)
+            return K.flow_visualize(x.contiguous(), t_off=t_off, T=T, flip=flip, out=out)
+        return K.pack_input(x.contiguous(), t_off=t_off, T=T, flip=flip, out=out)

@@ -9,47 +9,56 @@ struct BnDev {
   float* rmean; float* rvar; int64_t* nbt; float* smean; float* sinv;
 };
 
+// `groups` statistics groups (see mscl_conv3d_fwd_groups): scale / shift are [groups][C]; the running statistics take the
+// groups' updates one after the other, in group order -- what the reference's consecutive module calls do
 __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* shift, int C, float inv_n,
-                                           float unbias, float eps, float momentum, bool writer) {
+                                           float unbias, float eps, float momentum, bool writer, int groups) {
   if (b.sum == nullptr) {           // evaluation mode (nn.BatchNorm3d.eval()): running statistics, nothing is written
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const float sc = b.gamma[c] * rsqrtf(b.rvar[c] + eps);
-      scale[c] = sc; shift[c] = b.beta[c] - b.rmean[c] * sc;
+      for (int gi = 0; gi < groups; ++gi) { scale[gi * C + c] = sc; shift[gi * C + c] = b.beta[c] - b.rmean[c] * sc; }
     }
     return;
   }
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s1 = 0.f, s2 = 0.f;
+    for (int gi = 0; gi < groups; ++gi) {
+      const float* gs = b.sum + (long)gi * MSCL_STAT_SLOTS * 2 * C;
+      const float* gq = b.sumsq + (long)gi * MSCL_STAT_SLOTS * 2 * C;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) { s1 += b.sum[sl * 2 * C + c]; s2 += b.sumsq[sl * 2 * C + c]; }
-    const float mean = s1 * inv_n;
-    const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
-    const float inv = rsqrtf(var + eps);
-    const float sc = b.gamma[c] * inv;
-    scale[c] = sc; shift[c] = b.beta[c] - mean * sc;
-    if (writer) {
-      b.smean[c] = mean; b.sinv[c] = inv;
-      b.rmean[c] = (1.f - momentum) * b.rmean[c] + momentum * mean;
-      b.rvar[c] = (1.f - momentum) * b.rvar[c] + momentum * var * unbias;
+      for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) { s1 += gs[sl * 2 * C + c]; s2 += gq[sl * 2 * C + c]; }
+      const float mean = s1 * inv_n;
+      const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+      const float inv = rsqrtf(var + eps);
+      const float sc = b.gamma[c] * inv;
+      scale[gi * C + c] = sc; shift[gi * C + c] = b.beta[c] - mean * sc;
+      if (writer) {
+        b.smean[gi * C + c] = mean; b.sinv[gi * C + c] = inv;
+        b.rmean[c] = (1.f - momentum) * b.rmean[c] + momentum * mean;
+        b.rvar[c] = (1.f - momentum) * b.rvar[c] + momentum * var * unbias;
+      }
     }
   }
-  if (writer && threadIdx.x == 0 && b.nbt) *b.nbt += 1;
+  if (writer && threadIdx.x == 0 && b.nbt) *b.nbt += groups;
 }
 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, BnDev bn,
                                                          const bf16_t* __restrict__ res, BnDev rbn, int res_is_bn,
                                                          bf16_t* __restrict__ out, long rows, int C, float eps,
-                                                         float momentum, int relu) {
-  extern __shared__ float sm[];          // scale[C], shift[C], rscale[C], rshift[C]
-  float* scale = sm; float* shift = sm + C; float* rscale = sm + 2 * C; float* rshift = sm + 3 * C;
-  const float inv_n = 1.f / (float)rows;
-  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+                                                         float momentum, int relu, int groups) {
+  extern __shared__ float sm[];          // scale[groups][C], shift, rscale, rshift
+  const int GC = groups * C;
+  float* scale = sm; float* shift = sm + GC; float* rscale = sm + 2 * GC; float* rshift = sm + 3 * GC;
+  const long rows_g = rows / groups;     // rows of one statistics group (groups <= 2: rows below rows_g are group 0)
+  const float inv_n = 1.f / (float)rows_g;
+  const float unbias = rows_g > 1 ? (float)rows_g / (float)(rows_g - 1) : 1.f;
   const bool writer = blockIdx.x == 0;
-  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer);
-  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer);
+  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer, groups);
+  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer, groups);
   __syncthreads();
   const int G = C >> 3;
   const long total = rows * G;
+  const unsigned ebound = groups > 1 ? (unsigned)(rows_g * G) : 0xFFFFFFFFu;     // first granule of group 1
   // channel granule of an element: a 64-bit modulo by a runtime value costs ~100 instructions per 16 bytes moved, so the
   // index is kept in 32 bits (the launcher guarantees it fits) and G, a power of two on this path, becomes a mask
   const unsigned gmask = ((G & (G - 1)) == 0) ? (unsigned)(G - 1) : 0xFFFFFFFFu;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
       if (e >= total32) break;
       const int gq = gmask != 0xFFFFFFFFu ? (int)(e & gmask) : (int)(e % (unsigned)G);
       float f[8]; unpack8(v[u], f);
-      const int c0 = gq * 8;
+      const int c0 = gq * 8 + (e >= ebound ? C : 0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] = f[i] * scale[c0 + i] + shift[c0 + i];
       if (res != nullptr) {
@@ -97,7 +106,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 extern "C" int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn, const uint16_t* residual,
                                const mscl_bn_params* res_bn, uint16_t* out, int64_t rows, int C, float eps,
                                float momentum, int relu, void* stream) {
+  return mscl_bn_act_fwd_groups(y, bn, residual, res_bn, out, rows, C, eps, momentum, relu, 1, stream);
+}
+
+extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* bn, const uint16_t* residual,
+                                      const mscl_bn_params* res_bn, uint16_t* out, int64_t rows, int C, float eps,
+                                      float momentum, int relu, int groups, void* stream) {
   if (!y || !bn || !out || rows <= 0 || C <= 0) return MSCL_E_ARG;
+  if (groups < 1 || groups > 2 || rows % groups != 0) return MSCL_E_SHAPE;
   if (C % 8 || C > 2048 || rows * (C / 8) >= (1LL << 31)) return MSCL_E_SHAPE;
   if (!bn->gamma || !bn->beta || !bn->running_mean || !bn->running_var) return MSCL_E_ARG;
   if ((bn->sum == nullptr) != (bn->sumsq == nullptr)) return MSCL_E_ARG;
@@ -114,8 +130,8 @@ extern "C" int mscl_bn_act_fwd(const uint16_t* y, const mscl_bn_params* bn, cons
   }
   const long total = rows * (C / 8);
   long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C * sizeof(float),
-                     (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * groups * C * sizeof(float),
+                     (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu, groups);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -137,6 +153,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     if (ry) { ry += ch; rmean += ch; rinv += ch; }
     if (gamma) gamma += ch;
     if (beta) beta += ch;
+    // statistics groups along blockIdx.z: `rows` is the row count of ONE group; group z owns rows [z * rows, (z + 1) * rows),
+    // the z-th [ldc] block of mean / invstd and the z-th [slots][4 * ldc] block of the scratch sums
+    const long ro = (long)blockIdx.z * rows * ldc;
+    dout += ro; y += ro;
+    if (out) out += ro;
+    if (ry) { ry += ro; rmean += blockIdx.z * ldc; rinv += blockIdx.z * ldc; }
+    mean += blockIdx.z * ldc; inv += blockIdx.z * ldc;
+    scratch += (long)blockIdx.z * MSCL_STAT_SLOTS * 4 * ldc;
   }
   const int G = C >> 3;             // threads per row; 256 % G == 0 required (C/8 power of two)
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
@@ -216,35 +240,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ rinv, const float* __restrict__ scratch, bf16_t* __restrict__ dy,
     bf16_t* __restrict__ dres, int identity_dres, long rows, int C, int relu,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rdgamma, float* __restrict__ rdbeta,
-    const float* __restrict__ beta) {
-  extern __shared__ float sm[];   // k0[C] (gamma*inv), k1[C] (mean), k2[C] (inv), a[C], b[C]; then res: 4*C more; mask shift[C]
-  float* gi = sm; float* mu = sm + C; float* iv = sm + 2 * C; float* ca = sm + 3 * C; float* cb = sm + 4 * C;
-  float* rgi = sm + 5 * C; float* rmu = sm + 6 * C; float* riv = sm + 7 * C; float* rcb = sm + 8 * C;
-  float* msh = sm + 9 * C;        // mask from y: bn(y) = y * gi + msh  (see the reduce pass)
+    const float* __restrict__ beta, int groups) {
+  extern __shared__ float sm[];   // [10][groups][C]: gamma*inv, mean, inv, a, b; the residual's four; mask shift
+  const int GC = groups * C;
+  float* gi = sm; float* mu = sm + GC; float* iv = sm + 2 * GC; float* ca = sm + 3 * GC; float* cb = sm + 4 * GC;
+  float* rgi = sm + 5 * GC; float* rmu = sm + 6 * GC; float* riv = sm + 7 * GC; float* rcb = sm + 8 * GC;
+  float* msh = sm + 9 * GC;       // mask from y: bn(y) = y * gi + msh  (see the reduce pass)
   const bool mask_y = relu && beta != nullptr;
-  const float inv_n = 1.f / (float)rows;
+  const long rows_g = rows / groups;         // statistics groups (<= 2): rows below rows_g are group 0
+  const float inv_n = 1.f / (float)rows_g;
   for (int c = threadIdx.x; c < C; c += 256) {
-    gi[c] = gamma[c] * inv[c]; mu[c] = mean[c]; iv[c] = inv[c];
-    msh[c] = mask_y ? beta[c] - mean[c] * (gamma[c] * inv[c]) : 0.f;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    for (int gq = 0; gq < groups; ++gq) {
+      const int k = gq * C + c;
+      const float* sc = scratch + (long)gq * MSCL_STAT_SLOTS * 4 * C;
+      gi[k] = gamma[c] * inv[k]; mu[k] = mean[k]; iv[k] = inv[k];
+      msh[k] = mask_y ? beta[c] - mean[k] * (gamma[c] * inv[k]) : 0.f;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) {
-      t0 += scratch[sl * 4 * C + c]; t1 += scratch[sl * 4 * C + C + c];
-      if (ry) t2 += scratch[sl * 4 * C + 2 * C + c];
+      for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) {
+        t0 += sc[sl * 4 * C + c]; t1 += sc[sl * 4 * C + C + c];
+        if (ry) t2 += sc[sl * 4 * C + 2 * C + c];
+      }
+      ca[k] = t0 * inv_n; cb[k] = t1 * inv_n;
+      if (ry) { rgi[k] = rgamma[c] * rinv[k]; rmu[k] = rmean[k]; riv[k] = rinv[k]; rcb[k] = t2 * inv_n; }
+      p0 += t0; p1 += t1; p2 += t2;
     }
-    ca[c] = t0 * inv_n; cb[c] = t1 * inv_n;
-    if (ry) { rgi[c] = rgamma[c] * rinv[c]; rmu[c] = rmean[c]; riv[c] = rinv[c]; rcb[c] = t2 * inv_n; }
-    if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step)
-      atomicAdd(&dgamma[c], t1); atomicAdd(&dbeta[c], t0);
-      if (ry) { atomicAdd(&rdgamma[c], t2); atomicAdd(&rdbeta[c], t0); }
+    if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step, or once with two groups)
+      atomicAdd(&dgamma[c], p1); atomicAdd(&dbeta[c], p0);
+      if (ry) { atomicAdd(&rdgamma[c], p2); atomicAdd(&rdbeta[c], p0); }
     }
   }
   __syncthreads();
   const int G = C >> 3;                      // a power of two (checked by the launcher)
   const unsigned total32 = (unsigned)(rows * G), step32 = gridDim.x * blockDim.x, gmask = (unsigned)(G - 1);
+  const unsigned ebound = groups > 1 ? (unsigned)(rows_g * G) : 0xFFFFFFFFu;
   for (unsigned e32 = blockIdx.x * blockDim.x + threadIdx.x; e32 < total32; e32 += step32) {
     const long e = (long)e32;
-    const int c0 = (int)(e32 & gmask) * 8;
+    const int c0 = (int)(e32 & gmask) * 8 + (e32 >= ebound ? C : 0);
     float d[8], yy[8], o8[8];
     unpack8(*reinterpret_cast<const uint4*>(dout + e * 8), d);
     unpack8(*reinterpret_cast<const uint4*>(y + e * 8), yy);
@@ -282,7 +315,19 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
                                const float* res_invstd, float* res_dgamma, float* res_dbeta, uint16_t* dy,
                                uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
                                void* stream) {
+  return mscl_bn_act_bwd_groups(dout, out, y, gamma, beta, save_mean, save_invstd, dgamma, dbeta, res_y, res_gamma, res_mean,
+                                res_invstd, res_dgamma, res_dbeta, dy, dres, want_identity_dres, scratch, rows, C, relu, 1, stream);
+}
+
+extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out, const uint16_t* y, const float* gamma,
+                                      const float* beta, const float* save_mean, const float* save_invstd, float* dgamma,
+                                      float* dbeta, const uint16_t* res_y, const float* res_gamma, const float* res_mean,
+                                      const float* res_invstd, float* res_dgamma, float* res_dbeta, uint16_t* dy,
+                                      uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
+                                      int groups, void* stream) {
   if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
+  if (groups < 1 || groups > 2 || rows % groups != 0) return MSCL_E_SHAPE;
+  if (groups > 1 && relu == 2) return MSCL_E_ARG;
   // relu == 2: `dout` is dz already (masked by the producer) and `scratch` already holds the two sums -- the fused epilogue of
   // mscl_conv_halo64_dgrad_bn did this pass's work; only the apply pass runs
   const bool pre = relu == 2;
@@ -297,23 +342,24 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
   hipStream_t st = (hipStream_t)stream;
   const int Cc = C > 512 ? 512 : C, chunks = C / Cc;
   const int RP = 256 / (Cc / 8);
-  long blocks = (rows + RP * 8 - 1) / (RP * 8);
-  const long cap = 1024 / chunks;                                  // wider grids measured slower (more atomics)
+  const long rows_g = rows / groups;
+  long blocks = (rows_g + RP * 8 - 1) / (RP * 8);
+  const long cap = 1024 / (chunks * groups);                       // wider grids measured slower (more atomics)
   if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
   if (!pre) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, chunks), dim3(256), (size_t)12 * Cc * sizeof(float), st, dout,
-                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows, Cc, relu, gamma, beta, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, chunks, groups), dim3(256), (size_t)12 * Cc * sizeof(float), st, dout,
+                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C);
     MSCL_LAUNCH_CHECK();
   }
   const long total = rows * (C / 8);
   long b2 = (total + 255) / 256; if (b2 > 2048) b2 = 2048;
-  if (C > 1024) {      // 10 * C floats of constants: past the 64-KB default for dynamic LDS
+  if (C * groups > 1024) {      // 10 * C floats of constants per group: past the 64-KB default for dynamic LDS
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)10 * C * sizeof(float), st, dout, out, y,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)10 * groups * C * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
-                     want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta);
+                     want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

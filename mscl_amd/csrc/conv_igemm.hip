@@ -38,6 +38,7 @@ struct IGemmGeom {
   int lsT, lsH, lsW;
   int mode;                // 0 forward gather, 1 dgrad stride-1 (linear), 2 dgrad strided (parity classes)
   int mtiles, ntiles, ksplit, nclass;
+  int grp_rows;            // BatchNorm statistics groups (forward only): rows [k*grp_rows, (k+1)*grp_rows) feed group k; 0 = one group
   FastDiv dW, dH, dT;      // dense launches: division by Wr, Hr, Tr
   FastDiv dKW, dKH;        // tap index -> (kt, kh, kw) (uniform-tap kernel)
   ClassInfo cls[8];
@@ -94,34 +95,47 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
   // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
   if (stat_sum != nullptr) {
     float* red = reinterpret_cast<float*>(smem);      // [2][BN], tiles are dead after the last barrier
-    for (int i = tid; i < 2 * BN; i += (int)blockDim.x) red[i] = 0.f;
-    __syncthreads();
+    // statistics groups (a batch that holds two BatchNorm calls of the reference, e.g. base || rotated flow clips): rows below
+    // `bound` feed group g_lo, the rest (a tile that straddles the boundary; there are at most two groups) group g_lo + 1
+    int g_lo = 0, bound = 0x7fffffff, npass = 1;
+    if (g.grp_rows > 0) {
+      g_lo = m0 / g.grp_rows;
+      bound = (g_lo + 1) * g.grp_rows;
+      npass = (min(m0 + BM, Mc) > bound) ? 2 : 1;
+    }
+    for (int pass = 0; pass < npass; ++pass) {
+      for (int i = tid; i < 2 * BN; i += (int)blockDim.x) red[i] = 0.f;
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < JN; ++j) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < JN; ++j) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < IM; ++i)
+        for (int i = 0; i < IM; ++i) {
+          const bool mine = ((m0 + wm0 + i * 16 + fr) < bound) == (pass == 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
-      }
-      if (fr == 0) {
+          for (int r = 0; r < 4; ++r) { const float v = mine ? acc[j][i][r] : 0.f; s[r] += v; q[r] += v * v; }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int nl = wn0 + j * 16 + fq * 4 + r;
-          atomicAdd(&red[nl], s[r]);
-          atomicAdd(&red[BN + nl], q[r]);
+          s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
+        }
+        if (fr == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nl = wn0 + j * 16 + fq * 4 + r;
+            atomicAdd(&red[nl], s[r]);
+            atomicAdd(&red[BN + nl], q[r]);
+          }
         }
       }
-    }
-    __syncthreads();
-    for (int i = tid; i < BN; i += (int)blockDim.x) {
-      if (n0 + i < g.Cr) {
-        const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * g.Cr;
-        atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
+      __syncthreads();
+      for (int i = tid; i < BN; i += (int)blockDim.x) {
+        if (n0 + i < g.Cr) {
+          const int so = ((g_lo + pass) * MSCL_STAT_SLOTS + (int)(blockIdx.x % MSCL_STAT_SLOTS)) * 2 * g.Cr;
+          atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
+        }
       }
+      if (npass > 1) __syncthreads();
     }
   }
 
@@ -564,13 +578,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
                                                               const float* __restrict__ bias, const bf16_t* __restrict__ addend,
                                                               int relu, float* __restrict__ ssum, float* __restrict__ ssq,
-                                                              long rows, int C, int nslab) {
+                                                              long rows, int C, int nslab, long grp_rows) {
   __shared__ float red[8 * 512];
   const int G = C >> 3;                       // requires 256 % G == 0 and C <= 512
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const int c0 = tg * 8;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long r = (long)blockIdx.x * RP + tr; r < rows; r += (long)gridDim.x * RP) {
+  // statistics groups: blockIdx.y owns rows [y * grp_rows, (y + 1) * grp_rows) and the y-th [slots][2][C] block of sums
+  const long rbeg = grp_rows > 0 ? (long)blockIdx.y * grp_rows : 0, rend = grp_rows > 0 ? rbeg + grp_rows : rows;
+  if (ssum != nullptr) { ssum += (long)blockIdx.y * MSCL_STAT_SLOTS * 2 * C; ssq += (long)blockIdx.y * MSCL_STAT_SLOTS * 2 * C; }
+  for (long r = rbeg + (long)blockIdx.x * RP + tr; r < rend; r += (long)gridDim.x * RP) {
     const long o = r * C + c0;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int sl = 0; sl < nslab; ++sl) {
@@ -687,9 +704,10 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   if (g.ksplit > 1) {
     const long rows = out_elems / g.Cr;
     const int RP = 256 / (g.Cr / 8);
-    long fb = (rows + RP - 1) / RP; if (fb > 2048) fb = 2048; if (fb < 1) fb = 1;
-    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
-                       rows, g.Cr, g.ksplit);
+    const int ngrp = g.grp_rows > 0 ? (int)(rows / g.grp_rows) : 1;
+    long fb = (rows / ngrp + RP - 1) / RP; if (fb > 2048 / ngrp) fb = 2048 / ngrp; if (fb < 1) fb = 1;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb, ngrp), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
+                       rows, g.Cr, g.ksplit, (long)g.grp_rows);
     MSCL_LAUNCH_CHECK();
   }
   return 0;
@@ -783,10 +801,18 @@ static bool halo_enabled(const mscl_conv_desc* d) {
 extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w, uint16_t* y,
                                const float* bias, const uint16_t* addend, int relu, float* ssum, float* ssq,
                                float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
+  return mscl_conv3d_fwd_groups(d, x, w, y, bias, addend, relu, ssum, ssq, 1, splitk_ws, splitk_ws_floats, stream);
+}
+
+extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w, uint16_t* y,
+                                      const float* bias, const uint16_t* addend, int relu, float* ssum, float* ssq,
+                                      int stat_groups, float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!x || !w || !y) return MSCL_E_ARG;
   if ((ssum == nullptr) != (ssq == nullptr)) return MSCL_E_ARG;
-  if (bias == nullptr && !relu && halo_enabled(d)) {           // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
+  if (stat_groups < 1 || d->N % stat_groups != 0) return MSCL_E_ARG;
+  if (stat_groups > 2) return MSCL_E_SHAPE;         // the epilogue splits a tile over two statistics groups at most
+  if (stat_groups == 1 && bias == nullptr && !relu && halo_enabled(d)) {   // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
     const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
@@ -797,6 +823,7 @@ extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const
   g.pT = d->pT; g.pH = d->pH; g.pW = d->pW;
   g.M = d->N * d->To * d->Ho * d->Wo; g.ntaps = d->kT * d->kH * d->kW;
   g.cgs = ilog2_exact(d->C / 8); g.KG = g.ntaps * (d->C / 8); g.mode = 0; g.nclass = 0;
+  g.grp_rows = (stat_groups > 1 && ssum != nullptr) ? (d->N / stat_groups) * d->To * d->Ho * d->Wo : 0;
   g.dW = make_fastdiv(g.Wr); g.dH = make_fastdiv(g.Hr); g.dT = make_fastdiv(g.Tr);
   return launch_igemm(g, x, w, y, bias, addend, ssum, ssq, relu, splitk_ws, (long)splitk_ws_floats, (hipStream_t)stream);
 }

@@ -41,9 +41,11 @@ def _splitk_ws(rows, chans, device):
 STAT_SLOTS = 16         # = MSCL_STAT_SLOTS (include/mscl_hip.h): BN statistics buffers are [slots][2][C]
 
 
-def new_stats(C, device):
-    """zeroed [slots][2][C] statistics buffer; pass (buf[0, 0], buf[0, 1]) as the conv's stats / to _bnp"""
-    return ZEROS.take(STAT_SLOTS * 2 * C, device).view(STAT_SLOTS, 2, C)
+def new_stats(C, device, groups=1):
+    """zeroed [groups][slots][2][C] statistics buffer (groups: mscl_conv3d_fwd_groups); element [0, 0] / [0, 1] of group 0 is
+    what the conv's stats arguments and the BatchNorm parameter block point at"""
+    buf = ZEROS.take(groups * STAT_SLOTS * 2 * C, device)
+    return buf.view(STAT_SLOTS, 2, C) if groups == 1 else buf.view(groups, STAT_SLOTS, 2, C)
 
 
 PROFILE = None           # bench.py: dict(events=[]) -> (mode, desc fields, event pair) around every conv launch (eager steps)
@@ -182,29 +184,34 @@ def bn_act_fwd(y, bn, residual=None, res_bn=None, relu=True, eps=1e-5, momentum=
     return out
 
 
-def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, res=None, want_identity_dres=False, beta=None):
+def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, res=None, want_identity_dres=False, beta=None,
+               groups=1):
     """res = None | dict(y=, gamma=, mean=, invstd=, dgamma=, dbeta=).  Returns (dy, dres|None).
-    beta (no residual, relu): ReLU mask recomputed from y instead of read from `out`."""
+    beta (no residual, relu): ReLU mask recomputed from y instead of read from `out`.
+    groups: BatchNorm statistics groups (smean / sinv [groups][C], scratch [groups][STAT_SLOTS][4C])."""
     C = y.shape[-1]
     rows = y.numel() // C
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if (res is not None or want_identity_dres) else None
     r = res or {}
-    call('mscl_bn_act_bwd', ptr(dout), ptr(out), ptr(y), ptr(gamma), ptr(beta), ptr(smean), ptr(sinv), ptr(dgamma), ptr(dbeta),
+    call('mscl_bn_act_bwd_groups', ptr(dout), ptr(out), ptr(y), ptr(gamma), ptr(beta), ptr(smean), ptr(sinv), ptr(dgamma), ptr(dbeta),
          ptr(r.get('y')), ptr(r.get('gamma')), ptr(r.get('mean')), ptr(r.get('invstd')), ptr(r.get('dgamma')),
          ptr(r.get('dbeta')), ptr(dy), ptr(dres), int(want_identity_dres and res is None), ptr(scratch), rows, C,
-         int(relu), stream_ptr())
+         int(relu), groups, stream_ptr())
     return dy, dres
 
 
-def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None):
+def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None, out=None):
     """frames [t_off, t_off+T) of (B,C<=3,Ttot,H,W) fp32 -> (B,T,H,W,8) bf16, optional (x-mean)/std, optional
     per-sample horizontal flip (uint8 mask of B entries on the device)."""
     B, C, Ttot, H, W = x.shape
     T = Ttot - t_off if T is None else T
     if not x.is_contiguous():
         raise lib.MsclError('pack_input needs a contiguous NCTHW tensor')
-    out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    if out is None:            # `out`: a (B,T,H,W,8) slice of a larger batch (base || rotated flow clips in one trunk pass)
+        out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    elif tuple(out.shape) != (B, T, H, W, 8) or not out.is_contiguous():
+        raise lib.MsclError('pack_input: `out` must be a contiguous (B,T,H,W,8) bf16 tensor')
     m = (ctypes.c_float * 3)(*mean) if mean is not None else None
     s = (ctypes.c_float * 3)(*std) if std is not None else None
     call('mscl_pack_input', ptr(x), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, ptr(flip), stream_ptr())
@@ -252,14 +259,17 @@ def color_aug(x, params, blur_ksize=0):
     return out
 
 
-def flow_visualize(uv, t_off=0, T=None, flip=None, want_levels=False):
+def flow_visualize(uv, t_off=0, T=None, flip=None, want_levels=False, out=None):
     """(B,2,Ttot,H,W) fp32 optical flow -> colour-wheel image (B,T,H,W,8) bf16 (ssl_aug.py:87-136);
     with want_levels also the quantised bytes (B,T,H,W,3)."""
     B, C, Ttot, H, W = uv.shape
     T = Ttot - t_off if T is None else T
     if C != 2 or not uv.is_contiguous():
         raise lib.MsclError('flow_visualize needs a contiguous (B,2,T,H,W) tensor')
-    out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=uv.device)
+    if out is None:
+        out = torch.empty((B, T, H, W, 8), dtype=torch.bfloat16, device=uv.device)
+    elif tuple(out.shape) != (B, T, H, W, 8) or not out.is_contiguous():
+        raise lib.MsclError('flow_visualize: `out` must be a contiguous (B,T,H,W,8) bf16 tensor')
     lv = torch.empty((B, T, H, W, 3), dtype=torch.uint8, device=uv.device) if want_levels else None
     call('mscl_flow_visualize', ptr(uv), ptr(out), ptr(lv), B, T, H, W, Ttot, t_off, ptr(flip), stream_ptr())
     return (out, lv) if want_levels else out

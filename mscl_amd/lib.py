@@ -32,6 +32,7 @@ P = c_void_p
 _SIGS = {
     'mscl_abi_version': [],
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
+    'mscl_conv3d_fwd_groups': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, c_int, P, c_int64, P],
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
     'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_conv_halo64_dgrad_bn': [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P],
@@ -40,6 +41,8 @@ _SIGS = {
     'mscl_weight_transpose_batched': [P, c_int, c_int, P],
     'mscl_bn_act_fwd': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, P],
     'mscl_bn_act_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P],
+    'mscl_bn_act_fwd_groups': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, c_int, P],
+    'mscl_bn_act_bwd_groups': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, c_int, P],
     'mscl_pack_input': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P],
     'mscl_pair_w': [P, P, c_int64, c_int, P],
     'mscl_flow_visualize': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P],

@@ -99,9 +99,16 @@ class BatchNorm3dHip(nn.Module):
         return f'{self.num_features}, eps={self.eps}, momentum={self.momentum}'
 
 
+# BatchNorm statistics groups of the trunk pass being recorded (VideoResNetHip.forward(bn_groups=...)): a batch that holds
+# the inputs of G consecutive calls of the reference's module -- the base and the rotated flow clips of one step
+# (recognizers/mscl.py:239-240) -- runs every conv / weight-gradient / input-gradient kernel ONCE while BatchNorm keeps one set
+# of batch statistics per call.  The backward reads the group count off the saved statistics' shape.
+BN_GROUPS = [1]
+
+
 def cba_fwd(conv, bn, x, residual, relu):
     """conv -> BN(batch stats fused into the conv epilogue) -> (+residual) -> (ReLU).
-    Returns (y raw conv output, out, save[2,C] = mean/invstd).
+    Returns (y raw conv output, out, save[2,C] = mean/invstd; [2,G,C] with G = BN_GROUPS[0] > 1 statistics groups).
 
     The eager step is host-bound (~900 launches), so this path avoids per-call Python work: descriptor, split-K
     workspace size and the constant half of the BatchNorm parameter block are cached per (module, input shape)."""
@@ -120,16 +127,17 @@ def cba_fwd(conv, bn, x, residual, relu):
     d, dref, oshape, ws_n, sig = plan
     C = conv.out_channels
     dev = x.device
-    stats = K.new_stats(C, dev)[0]                 # slot 0 of [slots][2][C]
+    G = BN_GROUPS[0]
+    stats = K.new_stats(C, dev, G)                 # [G][slots][2][C]; the pointers address group 0, slot 0
     buf = torch.empty((2,) + oshape, dtype=torch.bfloat16, device=dev)
     y, out = buf[0], buf[1]
-    save = torch.empty((2, C), dtype=torch.float32, device=dev)
+    save = torch.empty((2, C) if G == 1 else (2, G, C), dtype=torch.float32, device=dev)
     ws = torch.empty((ws_n,), dtype=torch.float32, device=dev) if ws_n else None
     st = lib.stream_ptr()
     e0 = K.prof_begin()
     s_ptr = stats.data_ptr()
-    lib.call('mscl_conv3d_fwd', dref, x.data_ptr(), rt['w'].data_ptr(), y.data_ptr(),
-             rt['bias'].data_ptr() if rt['bias'] is not None else None, None, 0, s_ptr, s_ptr + 4 * C,
+    lib.call('mscl_conv3d_fwd_groups', dref, x.data_ptr(), rt['w'].data_ptr(), y.data_ptr(),
+             rt['bias'].data_ptr() if rt['bias'] is not None else None, None, 0, s_ptr, s_ptr + 4 * C, G,
              ws.data_ptr() if ws is not None else None, ws_n, st)
     K.prof_end(e0, 'fwd', d)
     bp = bn._bnp
@@ -139,9 +147,9 @@ def cba_fwd(conv, bn, x, residual, relu):
                                     bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), None, None)
         bn._bnp_ref = ctypes.byref(bp)
     sv = save.data_ptr()
-    bp.sum, bp.sumsq, bp.save_mean, bp.save_invstd = s_ptr, s_ptr + 4 * C, sv, sv + 4 * C
-    lib.call('mscl_bn_act_fwd', y.data_ptr(), bn._bnp_ref, residual.data_ptr() if residual is not None else None, None,
-             out.data_ptr(), y.numel() // C, C, bn.eps, bn.momentum, int(relu), st)
+    bp.sum, bp.sumsq, bp.save_mean, bp.save_invstd = s_ptr, s_ptr + 4 * C, sv, sv + 4 * G * C
+    lib.call('mscl_bn_act_fwd_groups', y.data_ptr(), bn._bnp_ref, residual.data_ptr() if residual is not None else None, None,
+             out.data_ptr(), y.numel() // C, C, bn.eps, bn.momentum, int(relu), G, st)
     return y, out, save
 
 
@@ -184,7 +192,8 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
     is registered in PRE_REDUCED and the consumer's cba_bwd runs the apply pass only."""
     rt = bn._rt
     C = conv.out_channels
-    pre = PRE_REDUCED.pop(dout.data_ptr(), None) if relu else None
+    G = save.shape[1] if save.dim() == 3 else 1                # statistics groups of the forward pass
+    pre = PRE_REDUCED.pop(dout.data_ptr(), None) if (relu and G == 1) else None
     if pre is not None and (pre[1].shape != dout.shape or pre[1].data_ptr() != dout.data_ptr()):
         pre = None
     if pre is not None:
@@ -193,15 +202,16 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
         dy, _ = K.bn_act_bwd(dout, None, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], 2, pre)
         dres = dout if want_dres else None
     else:
-        scratch = K.ZEROS.take(K.STAT_SLOTS * 4 * C, dout.device)
+        scratch = K.ZEROS.take(G * K.STAT_SLOTS * 4 * C, dout.device)
         dy, dres = K.bn_act_bwd(dout, out, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], relu, scratch,
-                                want_identity_dres=want_dres, beta=rt['beta'] if (relu and not want_dres and y.numel() >= MASK_FROM_Y_MIN) else None)
+                                want_identity_dres=want_dres, beta=rt['beta'] if (relu and not want_dres and y.numel() >= MASK_FROM_Y_MIN) else None,
+                                groups=G)
     rt['slot_g'].touched = True
     rt['slot_b'].touched = True
     _wgrad(conv, x, dy)
     dx = None
     if need_dx:
-        if next_bn is not None and FUSE_BN_REDUCE and conv.halo_shape and conv._rt.get('wT') is not None:
+        if next_bn is not None and FUSE_BN_REDUCE and G == 1 and conv.halo_shape and conv._rt.get('wT') is not None:
             ny, nout, nsave = next_bn
             nscr = K.ZEROS.take(K.STAT_SLOTS * 4 * conv.in_channels, dout.device)
             dx = K.conv_halo64_dgrad_bn(dy, conv._rt['wT'], conv.desc(x.shape), ny, nout, nsave[0], nsave[1], nscr, addend=dx_addend)
@@ -415,19 +425,28 @@ class VideoResNetHip(nn.Module):
             outs.append(x)
         return outs
 
-    def forward(self, x):
+    def forward(self, x, bn_groups=1):
+        """bn_groups > 1: the batch holds the inputs of that many consecutive calls of the reference's module (equal shares
+        along N, in call order); every BatchNorm keeps one set of batch statistics per call and updates its running
+        statistics once per call, in order -- the results of the separate calls, with each conv kernel launched once."""
         _need_gpu(x)
         if not self.training:
-            return self.forward_eval(x)
+            return self.forward_eval(x)        # running statistics: the groups of a batch are normalised alike
+        if x.shape[0] % bn_groups:
+            raise ValueError(f'batch of {x.shape[0]} does not split into {bn_groups} BatchNorm groups')
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
         PRE_REDUCED.clear(); LAST_BN.clear()       # entries only live inside one forward / one backward
-        x = _StemFn.apply(x, self._anchor, self.stem)
-        outs = []
-        for li in range(1, 5):
-            for blk in getattr(self, f'layer{li}'):
-                x = blk(x)
-            outs.append(x)
+        BN_GROUPS[0] = bn_groups
+        try:
+            x = _StemFn.apply(x, self._anchor, self.stem)
+            outs = []
+            for li in range(1, 5):
+                for blk in getattr(self, f'layer{li}'):
+                    x = blk(x)
+                outs.append(x)
+        finally:
+            BN_GROUPS[0] = 1
         return outs
 
 
@@ -541,19 +560,25 @@ class _BottleneckTrunk(nn.Module):
     def _stem(self):
         raise NotImplementedError
 
-    def forward(self, x):
+    def forward(self, x, bn_groups=1):
         _need_gpu(x)
         if not self.training:
             raise MsclError('the Bottleneck trunks implement training-mode BatchNorm only (both MoCo encoders run in train())')
+        if x.shape[0] % bn_groups:
+            raise ValueError(f'batch of {x.shape[0]} does not split into {bn_groups} BatchNorm groups')
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
         PRE_REDUCED.clear(); LAST_BN.clear()
-        x = _MaxPoolFn.apply(_StemFn.apply(x, self._anchor, self._stem()))
-        outs = []
-        for li in range(1, 5):
-            for blk in getattr(self, f'layer{li}'):
-                x = blk(x)
-            outs.append(x)
+        BN_GROUPS[0] = bn_groups               # see VideoResNetHip.forward
+        try:
+            x = _MaxPoolFn.apply(_StemFn.apply(x, self._anchor, self._stem()))
+            outs = []
+            for li in range(1, 5):
+                for blk in getattr(self, f'layer{li}'):
+                    x = blk(x)
+                outs.append(x)
+        finally:
+            BN_GROUPS[0] = 1
         return outs
 
 

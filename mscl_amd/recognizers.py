@@ -121,9 +121,10 @@ class MoCoV2(nn.Module):
         for fn in self._k_refresh:
             fn()
 
-    def encode_q(self, x, levels=None):
-        """levels: the q_mlvl levels the caller reads (None = all, as moco.py:517-529 returns them)"""
-        emb_maps, _ = self.neck_q(self.encoder_q(x), levels=levels)
+    def encode_q(self, x, levels=None, bn_groups=1):
+        """levels: the q_mlvl levels the caller reads (None = all, as moco.py:517-529 returns them).
+        bn_groups: x holds the inputs of that many consecutive calls (nn.VideoResNetHip.forward)."""
+        emb_maps, _ = self.neck_q(self.encoder_q(x) if bn_groups == 1 else self.encoder_q(x, bn_groups=bn_groups), levels=levels)
         emb, maps = emb_maps
         return mlp_head(self.mlp_q, emb), maps
 
@@ -406,6 +407,9 @@ class MSCLWithAug(nn.Module):
         self.query_graphs = os.environ.get('MSCL_QUERY_GRAPHS', '1') == '1'      # flow query passes (fwd + bwd) likewise
         self._query_graph = [QueryGraph(), QueryGraph()]                         # flow base, flow rotated
         self._graph_anchor = None
+        # base || rotated flow query clips in ONE trunk pass with two BatchNorm statistics groups (halves the ~250 launches of the
+        # two query passes, forward and backward); needs a flow neck without parameters of its own (BaseMoCo)
+        self.flow_batch = os.environ.get('MSCL_FLOW_BATCH', '1') == '1'
         self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0') == '1'     # measured 13 % slower: two MFMA-heavy kernels thrash     # MSCL_STREAMS=1: everything on the current stream
         self._side = None
 
@@ -476,7 +480,8 @@ class MSCLWithAug(nn.Module):
         # RGB stem trigger: autograd's ready-queue order of neck nodes vs trunk nodes is not a contract.
         buckets = [(span([eq.layer4]), eq.layer4[0], 1), (span([eq.layer3]), eq.layer3[0], 1),
                    (span([eq.stem, eq.layer1, eq.layer2]), eq.stem, 1), (span([rgb.neck_q, rgb.mlp_q]), eq.stem, 1),
-                   (span([flw.encoder_q, flw.neck_q, flw.mlp_q, self.sup_head]), flw.encoder_q.stem, 2)]     # head group follows the flow group
+                   (span([flw.encoder_q, flw.neck_q, flw.mlp_q, self.sup_head]), flw.encoder_q.stem,
+                    1 if self.flow_batch else 2)]            # head group follows the flow group
         self.reducer = parallel.GradReducer(ar.G, [b[0] for b in buckets], need=[b[2] for b in buckets])
         for i, (_, trig, _n) in enumerate(buckets):
             trig._grad_buckets = getattr(trig, '_grad_buckets', ()) + ((self.reducer, i),)
@@ -743,19 +748,31 @@ class MSCLWithAug(nn.Module):
         rec.momentum_update(m_dev)
         return rec.encode_k(x)[0]
 
+    def active_query_graphs(self):
+        """the QueryGraph holders the step uses: one (base || rotated in one pass) with flow_batch, else one per pass"""
+        return self._query_graph[:1] if self.flow_batch else self._query_graph
+
     def _flow_query_body(self, x):
         q, maps = self.recognizer_flow.encode_q(x)
         m = maps[self.sup_head.mlvl_ids[1]]
         return q, pool(m, m.shape[0] * m.shape[1], m.shape[2] * m.shape[3]), tuple(m.shape)
 
+    def _flow_query_body2(self, x):
+        """base || rotated clips (2B samples) in one pass: two BatchNorm statistics groups, rows [0, B) are the base call"""
+        q, maps = self.recognizer_flow.encode_q(x, bn_groups=2)
+        m = maps[self.sup_head.mlvl_ids[1]]
+        return q, pool(m, m.shape[0] * m.shape[1], m.shape[2] * m.shape[3]), tuple(m.shape)
+
     def _flow_query(self, slot, x):
         """one flow query pass (moco.py:517-529 on the flow recognizer) + the LMCL pooling of its layer-4 map
-        (local_cl_head.py:57-62); replayed from a forward and a backward sub-graph in eager training steps"""
+        (local_cl_head.py:57-62); replayed from a forward and a backward sub-graph in eager training steps.
+        slot 0 / 1: the base / rotated pass alone; slot 2: both in one pass over 2B samples (flow_batch)"""
+        body = self._flow_query_body2 if slot == 2 else self._flow_query_body
         if not (self.query_graphs and self.training):
-            return self._flow_query_body(x)
+            return body(x)
         if self._graph_anchor is None:
             self._graph_anchor = torch.zeros(1, device=x.device, requires_grad=True)
-        return self._query_graph[slot].run(self._flow_query_body, x, self.recognizer_flow.encoder_q.stem, self._graph_anchor)
+        return self._query_graph[0 if slot == 2 else slot].run(body, x, self.recognizer_flow.encoder_q.stem, self._graph_anchor)
 
     def _device_step(self, im_q, im_k, flow_q, flow_k, flip_q=None, flip_k=None, color_q=None, color_k=None):
         rec, recf = self.recognizer, self.recognizer_flow
@@ -811,8 +828,19 @@ class MSCLWithAug(nn.Module):
                     if tns is not None:
                         tns.record_stream(side_k if tns is im_k_x or tns is flip_k0 else s_fk)
         with torch.cuda.stream(s_fq):
-            q_fb, p_fb, fmap_shape = self._flow_query(0, aug.pack_flow(flow_q, 0, Th, flip_q))
-            q_fa, p_fa, _ = self._flow_query(1, aug.pack_flow(flow_q, Th, Th, flip_q))
+            if self.flow_batch:
+                Bq = flow_q.shape[0]
+                xq = torch.empty((2 * Bq, Th, flow_q.shape[3], flow_q.shape[4], 8), dtype=torch.bfloat16, device=flow_q.device)
+                aug.pack_flow(flow_q, 0, Th, flip_q, out=xq[:Bq])
+                aug.pack_flow(flow_q, Th, Th, flip_q, out=xq[Bq:])
+                q_f, p_f, fs = self._flow_query(2, xq)
+                tq = fs[1]
+                q_fb, q_fa = q_f[:Bq], q_f[Bq:]
+                p_fb, p_fa = p_f[:Bq * tq], p_f[Bq * tq:]
+                fmap_shape = (Bq,) + tuple(fs[1:])
+            else:
+                q_fb, p_fb, fmap_shape = self._flow_query(0, aug.pack_flow(flow_q, 0, Th, flip_q))
+                q_fa, p_fa, _ = self._flow_query(1, aug.pack_flow(flow_q, Th, Th, flip_q))
         with torch.cuda.stream(s_fk):
             # two EMA updates, two BN-statistics passes (App. E-5)
             if dp:

@@ -330,7 +330,7 @@ def _two_rank_worker(rank, world, port, q):
                 assert rec.batch_size == orec.batch_size == world * B
                 assert torch.equal(rec.count.cpu(), orec.count), nm
                 assert abs(rec.m - orec.m) < 1e-12
-        assert all(g.graph is not None for g in model._key_graph) and all(g.fwd is not None for g in model._query_graph)
+        assert all(g.graph is not None for g in model._key_graph) and all(g.fwd is not None for g in model.active_query_graphs())
         # replicas stay bit-identical: masters, momentum, both queues
         blob = torch.cat([model.arena.Q.flatten(), model.arena.MOM.flatten(), model.arena.KX.flatten(),
                           model.recognizer.queue.flatten().float(), model.recognizer_flow.queue.flatten().float()]).cpu()
@@ -525,7 +525,7 @@ def test_flow_query_subgraphs_equal_eager(dev):
         torch.cuda.synchronize()
         return out['log_vars'], model.arena.G[a:b].clone(), model.arena.G.clone()
     e1, e2, g1, g2 = run(False), run(False), run(True), run(True)
-    assert all(g.fwd is not None and not g.failed for g in model._query_graph)
+    assert all(g.fwd is not None and not g.failed for g in model.active_query_graphs())
     cos = lambda x, y: torch.nn.functional.cosine_similarity(x.double(), y.double(), dim=0).item()
     noise = 1 - cos(e1[1], e2[1])
     print('1-cos flow grads: eager/eager %.2e, graph/eager %.2e %.2e; all grads: %.2e, %.2e %.2e' % (
@@ -554,7 +554,7 @@ def test_whole_step_graph_after_subgraph_steps(dev):
     for s in range(4):
         out = model.train_step(synthetic_batch(B, T, H, H, 0, s, device=dev))
         opt.zero_grad(); out['loss'].backward(); opt.step()
-    assert all(g.graph is not None for g in model._key_graph) and all(g.fwd is not None for g in model._query_graph)
+    assert all(g.graph is not None for g in model._key_graph) and all(g.fwd is not None for g in model.active_query_graphs())
     batch = synthetic_batch(B, T, H, H, 0, 9, device=dev)
     gs = GraphedStep(model, opt, batch, warmup=1)
     before = {k: v.clone() for k, v in model.state_dict().items()}
@@ -1013,6 +1013,49 @@ def test_r3d18_single_stream_full_size(dev):
         if c < 0.90:
             bad.append((n, c))
     assert not bad, bad
+
+
+def test_flow_batch_equals_two_passes(dev):
+    """The base and the rotated flow query clips in ONE trunk pass with two BatchNorm statistics groups (the default,
+    MSCLWithAug.flow_batch) against the reference's two consecutive passes (recognizers/mscl.py:239-240, flow_batch = False):
+    same 23 log entries, same query features, same gradients, and the SAME BatchNorm running statistics / batch counters (two
+    momentum updates in call order).  The two runs differ by fp32 summation order only."""
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H = 4, 8, 64
+    batch = synthetic_batch(B, T, H, H, 0, 0, device=dev)
+    res = []
+    for fb in (True, False, False):      # the second two-pass run calibrates the run-to-run noise of the fp32 atomics
+        model, _ = build(T, 256, dev)
+        model.flow_batch = fb
+        out = model.train_step(batch)
+        model.zero_grad(); out['loss'].backward()
+        model.sync_streams(); torch.cuda.synchronize()
+        enc = model.recognizer_flow.encoder_q
+        res.append(dict(logs=out['log_vars'], q=(model._dbg['q_fb'].float().clone(), model._dbg['q_fa'].float().clone()),
+                        grads={n: p.grad.detach().float().clone() for n, p in model.recognizer_flow.named_parameters() if p.requires_grad},
+                        bufs={n: b.detach().clone() for n, b in enc.named_buffers()}))
+    a, b, b2 = res
+    for k, v in b['logs'].items():
+        if 'loss' in k:
+            assert abs(a['logs'][k] - v) <= 2e-3 * max(1.0, abs(v)), (k, a['logs'][k], v)
+        else:
+            assert abs(a['logs'][k] - v) <= 1.0 / (B * (T // 2)) + 1e-6, (k, a['logs'][k], v)
+    cos = torch.nn.functional.cosine_similarity
+    for qa, qb in zip(a['q'], b['q']):
+        assert cos(qa, qb, dim=1).min().item() >= 0.9995
+    for n, bb in b['bufs'].items():
+        if n.endswith('num_batches_tracked'):
+            assert int(a['bufs'][n]) == int(bb) == 2, n           # two calls of the module per step
+        else:
+            assert torch.allclose(a['bufs'][n], bb, rtol=5e-3, atol=1e-3), (n, (a['bufs'][n] - bb).abs().max().item())
+    tot = sum(float(g.double().pow(2).sum()) for g in b['grads'].values()) ** 0.5
+    tot_a = sum(float(g.double().pow(2).sum()) for g in a['grads'].values()) ** 0.5
+    assert abs(tot_a - tot) <= 0.03 * tot, (tot_a, tot)
+    for n, g in b['grads'].items():
+        if float(g.norm()) >= 0.01 * tot:
+            c = float(cos(a['grads'][n].flatten(), g.flatten(), dim=0))
+            noise = float(cos(b2['grads'][n].flatten(), g.flatten(), dim=0))       # two-pass vs two-pass (batch-4 BatchNorm amplifies
+            assert c >= min(0.98, noise - 0.03), (n, c, noise)                    # the atomics' order: ~0.97 on the stem kernel)
 
 
 def test_slowonly50_trunk_32x224(dev):
