@@ -70,6 +70,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of one captured HIP graph per step')
+    p.add_argument('--deterministic', action='store_true',
+                   help='variant: the library\'s deterministic mode (fixed-order sums instead of float atomics; the reference\'s --deterministic)')
     p.add_argument('--stochastic-aug', action='store_true',
                    help='variant (not the BASELINE.json workload): random flip / colour jitter / grayscale / blur per step')
     return p.parse_args()
@@ -150,6 +152,9 @@ def main():
     model = build_model(cfg.model)
     fill_module(model)
     model.materialize(dev).train()
+    if args.deterministic:
+        from mscl_amd import lib as _lib
+        _lib.set_deterministic(True)
     if args.stochastic_aug:
         model.aug_gpu.stochastic = True
         model.aug_gpu.seed(1234 + rank)
@@ -245,8 +250,10 @@ def main():
                        'clip': f'{T_FRAMES}x{SIDE}x{SIDE}', 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
                        'parallelism': f'dp{world}' + (' (collectives forced on a 1-rank RCCL group)' if forced else ''), 'weights': 'closed-form fill, fp32 masters + bf16 shadows',
                        'launch': 'one captured HIP graph per step' if graphed is not None
-                                 else 'eager launches, %d of 5 collective-free branches replayed from HIP sub-graphs' % (
-                                     sum(g.graph is not None for g in model._key_graph) + sum(g.fwd is not None for g in model._query_graph)),
+                                 else 'eager launches, %d of %d collective-free branches replayed from HIP sub-graphs' % (
+                                     sum(g.graph is not None for g in model._key_graph) + sum(g.fwd is not None for g in model.active_query_graphs()),
+                                     len(model._key_graph) + len(model.active_query_graphs())),
+                       **({'deterministic': 'fixed-order sums instead of float atomics (variant, not the headline line)'} if args.deterministic else {}),
                        'aug': 'stochastic flip+jitter+grayscale+blur (variant)' if args.stochastic_aug
                               else 'normalise only (BASELINE.json workload)'},
             'final_loss': loss,

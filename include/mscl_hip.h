@@ -37,6 +37,21 @@ typedef struct {
 
 int mscl_abi_version(void);
 
+/* Deterministic mode (the reference's documented launch is `tools/train.py --deterministic`, README.md:19, tools/train.py:55-57,
+ * 149): while on, every sum that is otherwise taken by float atomics in hardware order -- BatchNorm statistics in the conv
+ * epilogues, the BatchNorm-backward sums, weight / bias gradients over position splits, the small linear layers' input
+ * gradient, the InfoNCE gradient, the LMCL loss -- is taken in a fixed order (per-block partials in slots or slabs, added in
+ * index order), so two runs on the same inputs give bit-identical results.  Costs one extra read of each conv output (the
+ * statistics pass, mscl_bn_stats) and a slab pass per weight gradient.  Process-wide; set it before the first step.
+ * Not covered: mscl_conv_halo64 called directly with statistics pointers, mscl_conv_halo64_dgrad_bn (both opt-in paths). */
+int mscl_set_deterministic(int on);
+int mscl_get_deterministic(void);
+/* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order:
+ * block x of MSCL_STAT_SLOTS plain-stores the sums of its row share into slot x of ssum / ssq ([group][slot][2][C]) */
+int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, void* stream);
+/* floats of workspace mscl_conv3d_wgrad needs for this layer in deterministic mode (0 otherwise) */
+int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias);
+
 /* ---- Conv3d as implicit GEMM on MFMA (bf16 in, fp32 accumulate) --------------------------------
  * replaces nn.Conv3d forward in r3d.py:16-34,176-184,285-288 / fastonly.py:61-80,185-193 /
  * necks/fpn.py:131-149 / necks/sepc.py:74-104.

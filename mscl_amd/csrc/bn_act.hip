@@ -136,13 +136,62 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
   return 0;
 }
 
+// ---- BatchNorm statistics of a stored map in a fixed summation order (deterministic mode; also a stand-alone entry point) ----
+// grid (MSCL_STAT_SLOTS, channel chunks, groups): block x of a group reduces the x-th contiguous share of the group's rows and
+// plain-stores its sums into slot x; bn_prepare adds the slots in slot order.  No atomics anywhere.
+__global__ __launch_bounds__(256) void bn_stats_det_kernel(const bf16_t* __restrict__ y, float* __restrict__ ssum,
+                                                           float* __restrict__ ssq, long rows, int C, int ldc) {
+  extern __shared__ float sm[];     // red[2][4 waves][C]
+  const int ch = blockIdx.y * C;
+  y += ch + (long)blockIdx.z * rows * ldc;
+  const long go = ((long)blockIdx.z * MSCL_STAT_SLOTS + blockIdx.x) * 2 * ldc + ch;
+  const int G = C >> 3;
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long rbeg = (long)blockIdx.x * per, rend = rbeg + per < rows ? rbeg + per : rows;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int UNR = 4;
+  for (long r0 = rbeg + tr; r0 < rend; r0 += (long)RP * UNR) {
+    uint4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long r = r0 + (long)u * RP;
+      v[u] = *reinterpret_cast<const uint4*>(y + (r < rend ? r : r0) * ldc + tg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (r0 + (long)u * RP >= rend) break;
+      float f[8]; unpack8(v[u], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] += f[i] * f[i]; }
+    }
+  }
+  block_channel_sum(s, sm, G, C, 2, 0);
+  block_channel_sum(q, sm, G, C, 2, 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    ssum[go + i] = (sm[i] + sm[C + i]) + (sm[2 * C + i] + sm[3 * C + i]);
+    ssq[go + i] = (sm[4 * C + i] + sm[5 * C + i]) + (sm[6 * C + i] + sm[7 * C + i]);
+  }
+}
+
+extern "C" int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, void* stream) {
+  if (!y || !ssum || !ssq || rows <= 0 || C <= 0 || groups < 1 || rows % groups) return MSCL_E_ARG;
+  if (C % 8 || ilog2_exact(C / 8) < 0 || C > 4096) return MSCL_E_SHAPE;
+  const int Cc = C > 512 ? 512 : C;
+  hipLaunchKernelGGL(bn_stats_det_kernel, dim3(MSCL_STAT_SLOTS, C / Cc, groups), dim3(256), (size_t)8 * Cc * sizeof(float),
+                     (hipStream_t)stream, y, ssum, ssq, (long)(rows / groups), Cc, C);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- backward pass 1: per-channel sum(dz), sum(dz*xhat) [and the same against the residual's xhat] ----
 // scratch layout: [0:C) sum dz, [C:2C) sum dz*xhat, [2C:3C) sum dz*xhat_res
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ inv, const bf16_t* __restrict__ ry,
     const float* __restrict__ rmean, const float* __restrict__ rinv, float* __restrict__ scratch, long rows, int C,
-    int relu, const float* __restrict__ gamma, const float* __restrict__ beta, int ldc) {
+    int relu, const float* __restrict__ gamma, const float* __restrict__ beta, int ldc, int det) {
   extern __shared__ float sm[];     // red[3][4 waves][C]
   // maps wider than 512 channels (Bottleneck trunks, up to 2048) are cut into 512-channel chunks along blockIdx.y: C is the
   // chunk width the thread layout sees, ldc the row pitch of the maps and the channel count of the scratch layout
@@ -228,7 +277,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int w = 0; w < 4; ++w) t += sm[(vv * 4 + w) * C + c];
     // 16 slots: with one, the 1024 blocks of the layer-1 map each ended on the same 128 addresses, and same-address float
     // atomics serialise in L2 at ~25 ns apiece -- a 25-us tail on a 45-us pass
-    atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_SLOTS) * 4 * ldc + vv * ldc + c], t);
+    // deterministic mode: at most MSCL_STAT_SLOTS blocks per group, block x owns slot x (plain store; the apply pass adds the
+    // slots in slot order)
+    if (det) scratch[blockIdx.x * 4 * ldc + vv * ldc + c] = t;
+    else atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_SLOTS) * 4 * ldc + vv * ldc + c], t);
   }
 }
 
@@ -346,9 +398,11 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   long blocks = (rows_g + RP * 8 - 1) / (RP * 8);
   const long cap = 1024 / (chunks * groups);                       // wider grids measured slower (more atomics)
   if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
+  const int det = mscl_det() ? 1 : 0;
+  if (det && blocks > MSCL_STAT_SLOTS) blocks = MSCL_STAT_SLOTS;
   if (!pre) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, chunks, groups), dim3(256), (size_t)12 * Cc * sizeof(float), st, dout,
-                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C);
+                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C, det);
     MSCL_LAUNCH_CHECK();
   }
   const long total = rows * (C / 8);

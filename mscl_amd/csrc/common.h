@@ -106,6 +106,11 @@ static inline FastDiv make_fastdiv(int d) {
 }
 __device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((uint64_t)(uint32_t)n * f.magic) >> f.shift); }
 
+// Deterministic mode (mscl_set_deterministic, include/mscl_hip.h): every fp32 sum whose order the hardware would otherwise pick
+// (float atomics between blocks) is taken in a fixed order instead, so two runs on the same inputs are bit-identical.
+extern int g_mscl_deterministic;
+static inline bool mscl_det() { return g_mscl_deterministic != 0; }
+
 #define MSCL_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 static inline int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

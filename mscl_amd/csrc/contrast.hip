@@ -244,7 +244,8 @@ extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const floa
       hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
       hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T))
     MSCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, 32), dim3(256), 0, st, (const float*)ws,
+    // (deterministic mode: one block column, so every element receives ONE add of a sum taken in slab order)
+    hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, mscl_det() ? 1 : 32), dim3(256), 0, st, (const float*)ws,
                        dq + (size_t)r0 * dim, nblk, rt, Rt, dim);
     MSCL_LAUNCH_CHECK();
   }
@@ -339,7 +340,7 @@ extern "C" int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, co
 __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb, const float* __restrict__ flow,
                                                    float* __restrict__ loss_sum, int32_t* __restrict__ hits,
                                                    float* __restrict__ drgb, float* __restrict__ dflow, int B, int t, int C,
-                                                   float inv_T) {
+                                                   float inv_T, int b0) {
   extern __shared__ float sm[];
   const int t2 = 2 * t;
   float* xr = sm;                    // [t][C] normalised
@@ -349,7 +350,8 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
   float* sim = nf + t2;              // [t][2t] -> dlogits
   float* gr = sim + t * t2;          // [t][C]  grad wrt normalised rgb
   float* gf = gr + t * C;            // [2t][C]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* lrow = gf + t2 * C;          // [t] per-frame loss terms of this clip, added up in frame order by one thread
   const float* rb = rgb + (long)b * t * C; const float* fb = flow + (long)b * t2 * C;
   for (int row = wave; row < t + t2; row += 4) {
     const float* src = row < t ? rb + row * C : fb + (row - t) * C;
@@ -380,12 +382,17 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
     const float lse = m + logf(s), pos = sim[i * t2 + i];
     int rank = 0;
     for (int j = 0; j < t2; ++j) rank += (sim[i * t2 + j] > pos) ? 1 : 0;
-    atomicAdd(loss_sum, lse - pos);
+    lrow[i] = lse - pos;
     if (rank == 0) atomicAdd(&hits[0], 1);
     if (rank < 5) atomicAdd(&hits[1], 1);
     for (int j = 0; j < t2; ++j) sim[i * t2 + j] = (expf(sim[i * t2 + j] - lse) - (j == i ? 1.f : 0.f)) * scale * inv_T;
   }
   __syncthreads();
+  if (tid == 0) {                     // one float add per clip: the clips' order is the launch order in deterministic mode
+    float s = 0.f;
+    for (int i = 0; i < t; ++i) s += lrow[i];
+    atomicAdd(loss_sum, s);
+  }
   for (int e = tid; e < t * C; e += 256) {
     const int i = e / C, c = e % C;
     float s = 0.f;
@@ -415,11 +422,18 @@ extern "C" int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, i
                          int t, int C, float inv_T, void* stream) {
   if (!rgb || !flow || !loss_sum || !hits || !drgb || !dflow || B <= 0 || t <= 0 || C <= 0) return MSCL_E_ARG;
   if (t > LMCL_MAX_T) return MSCL_E_SHAPE;
-  const size_t lds = ((size_t)6 * t * C + 3 * t + 2 * t * t) * sizeof(float);
+  const size_t lds = ((size_t)6 * t * C + 4 * t + 2 * t * t) * sizeof(float);
   if (lds > 150 * 1024) return MSCL_E_SHAPE;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lmcl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T);
+  if (mscl_det()) {                   // clip by clip: the one float add per clip lands in clip order
+    for (int b = 0; b < B; ++b) {
+      hipLaunchKernelGGL(lmcl_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, b);
+      MSCL_LAUNCH_CHECK();
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, 0);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

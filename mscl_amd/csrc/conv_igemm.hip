@@ -812,6 +812,13 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
   if ((ssum == nullptr) != (ssq == nullptr)) return MSCL_E_ARG;
   if (stat_groups < 1 || d->N % stat_groups != 0) return MSCL_E_ARG;
   if (stat_groups > 2) return MSCL_E_SHAPE;         // the epilogue splits a tile over two statistics groups at most
+  if (ssum != nullptr && mscl_det()) {
+    // deterministic mode: no statistics in the epilogue (LDS and global float atomics); a fixed-order pass over the stored map
+    // fills the slots instead (one block per slot, plain stores) -- the statistics of the bf16 values the next layer reads
+    e = mscl_conv3d_fwd_groups(d, x, w, y, bias, addend, relu, nullptr, nullptr, 1, splitk_ws, splitk_ws_floats, stream);
+    if (e) return e;
+    return mscl_bn_stats(y, ssum, ssq, (int64_t)d->N * d->To * d->Ho * d->Wo, d->K, stat_groups, stream);
+  }
   if (stat_groups == 1 && bias == nullptr && !relu && halo_enabled(d)) {   // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
     const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
     if (h != 0) return h == 1 ? 0 : h;
@@ -940,3 +947,7 @@ extern "C" int mscl_weight_transpose_batched(const void* table, int n, int total
 }
 
 extern "C" int mscl_abi_version(void) { return 1; }
+
+int g_mscl_deterministic = 0;
+extern "C" int mscl_set_deterministic(int on) { g_mscl_deterministic = on ? 1 : 0; return 0; }
+extern "C" int mscl_get_deterministic(void) { return g_mscl_deterministic; }

@@ -55,7 +55,8 @@ __device__ __forceinline__ auto wg_rsrc(const void* p, unsigned bytes) {
 // 2: a 2 x 2 arrangement, used with the 128 x 128 tile where each wave then owns 64 x 64 and one LDS byte feeds 2.5x the MFMAs)
 template <int CO, int NCOL, int WCO>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ dy, float* __restrict__ dw) {
+                                                         const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                         float* __restrict__ slab) {
   constexpr int PB = 64;                        // positions per step
   constexpr int GA = CO / 8, GB = NCOL / 8;     // granules per tile row
   constexpr int NA = (PB * GA + 255) / 256;     // dy DMA passes (one 1-KiB chunk per wave per pass)
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
   const int mbeg = split * g.per_split;
   const int mend = min(g.M, mbeg + g.per_split);
   const int nsteps = (mend > mbeg) ? (mend - mbeg + PB - 1) / PB : 0;
-  if (nsteps == 0) return;
+  if (nsteps == 0 && slab == nullptr) return;      // (deterministic mode: an empty split still stores its zeros)
 
   const unsigned x_bytes = (unsigned)((long)g.N * g.T * g.H * g.W * g.C * 2);
   const unsigned dy_bytes = (unsigned)((long)g.M * g.K * 2);
@@ -248,8 +249,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco * WM + i * 16 + (lane >> 4) * 4 + r;
         const int col = n0 + wcol * WN + j * 16 + (lane & 15);
-        if (co < g.K && col < g.ncols) atomicAdd(&dw[(long)co * g.ncols + col], acc[i][j][r]);
+        if (co < g.K && col < g.ncols) {
+          // deterministic mode: this split's tile goes to its own slab with plain stores; wgrad_slab_reduce_kernel adds the
+          // slabs to dw in split order
+          if (slab != nullptr) slab[((long)split * g.K + co) * g.ncols + col] = acc[i][j][r];
+          else atomicAdd(&dw[(long)co * g.ncols + col], acc[i][j][r]);
+        }
       }
+}
+
+// dw[e] += slab[0][e] + slab[1][e] + ... in split order (deterministic mode)
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long n, int nslab) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slab[(long)k * n + e];
+    dw[e] += s;
+  }
+}
+
+// column sums, deterministic form: block x plain-stores the sums of its row share into part[x][C]; colsum_finish adds them in order
+__global__ __launch_bounds__(256) void colsum_det_kernel(const bf16_t* __restrict__ xx, float* __restrict__ part, long rows, int C) {
+  const int G = C / 8;
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long rbeg = (long)blockIdx.x * per, rend = rbeg + per < rows ? rbeg + per : rows;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long r = rbeg + tr; r < rend; r += RP) {
+    float f[8]; unpack8(*reinterpret_cast<const uint4*>(xx + r * C + tg * 8), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] += f[i];
+  }
+  __shared__ float red[4 * 512];
+  block_channel_sum(s, red, G, C, 1, 0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) part[(long)blockIdx.x * C + i] = (red[i] + red[C + i]) + (red[2 * C + i] + red[3 * C + i]);
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += part[(long)k * C + i];
+  out[i] += s;
 }
 
 // column sums of a bf16 (rows, C) matrix into fp32 out[C] (+=): conv bias gradient
@@ -284,7 +324,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 template <int CO, int NCOL, int WCO = 1>
-static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipStream_t st) {
+static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipStream_t st, float* det_ws = nullptr, long det_floats = 0) {
   g.co_tiles = (g.K + CO - 1) / CO;
   g.col_tiles = (g.ncols + NCOL - 1) / NCOL;
   const long tiles = (long)g.co_tiles * g.col_tiles;
@@ -298,6 +338,18 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   long per = ((g.M + want - 1) / want + 63) / 64 * 64;
   g.per_split = (int)per;
   g.splits = (int)((g.M + per - 1) / per);
+  float* slab = nullptr;
+  const long dwn = (long)g.K * g.ncols;
+  if (mscl_det() && g.splits > 1) {                       // one fp32 slab per split, added to dw in split order afterwards
+    if (det_ws == nullptr || det_floats < dwn) return MSCL_E_ARG;
+    long fit = det_floats / dwn;
+    if (fit < g.splits) {                                 // fewer, longer splits when the workspace is short
+      per = ((g.M + fit - 1) / fit + 63) / 64 * 64;
+      g.per_split = (int)per;
+      g.splits = (int)((g.M + per - 1) / per);
+    }
+    slab = det_ws;
+  }
   const size_t lds = (size_t)2 * 64 * (CO + NCOL) * 2 + (size_t)8 * 64 * sizeof(int2);
   auto kern = conv_wgrad_kernel<CO, NCOL, WCO>;
   static bool attr_done = false;
@@ -305,8 +357,13 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * g.splits)), dim3(256), lds, st, g, x, dy, dw);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * g.splits)), dim3(256), lds, st, g, x, dy, dw, slab);
   MSCL_LAUNCH_CHECK();
+  if (slab != nullptr) {
+    long rb = (dwn + 255) / 256; if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)slab, dw, dwn, g.splits);
+    MSCL_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -344,21 +401,50 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   int e;
   const int hres = ws != nullptr ? mscl_wgrad_halo64(d, x, dy, dw, ws, ws_floats, st) : 0;   // layer-1 shape, window-resident
   if (hres < 0 || hres > 1) return hres;
+  // deterministic mode: `ws` doubles as the slab workspace of the general kernel ([splits][K][ncols] floats) and, behind it,
+  // the partial column sums of the bias gradient ([MSCL_STAT_SLOTS][K]); mscl_conv3d_wgrad_ws() gives the size to pass
+  float* dws = nullptr; long dfl = 0;
+  if (mscl_det() && hres == 0 && ws != nullptr) {
+    const long tail = dbias ? (long)MSCL_STAT_SLOTS * d->K : 0;
+    dws = ws; dfl = ws_floats - tail;
+    if (dfl < 0) return MSCL_E_ARG;
+  }
   bool wide = false;     // NCOL = 192 (three taps share one dy tile) measured slower than 64: fewer blocks per CU
   if (const char* f = getenv("MSCL_WGRAD_NCOL")) wide = atoi(f) == 192;
   if (hres == 1) e = 0;
-  else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st);
-  else if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st) : launch_w<64, 64>(g, x, dy, dw, st);
-  else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st) : launch_w<32, 64>(g, x, dy, dw, st);
+  else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st, dws, dfl);
+  else if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<64, 64>(g, x, dy, dw, st, dws, dfl);
+  else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<32, 64>(g, x, dy, dw, st, dws, dfl);
   // K == 8 (the 8-channel layers of r2d_50): the 16-row tile with its upper half zero-filled by the range check and never stored
-  else if (d->K == 16 || d->K == 8) e = wide ? launch_w<16, 192>(g, x, dy, dw, st) : launch_w<16, 64>(g, x, dy, dw, st);
+  else if (d->K == 16 || d->K == 8) e = wide ? launch_w<16, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<16, 64>(g, x, dy, dw, st, dws, dfl);
   else return MSCL_E_SHAPE;
   if (e) return e;
   if (dbias && d->K <= 512) {
+    if (mscl_det()) {
+      if (ws == nullptr || ws_floats < (long)MSCL_STAT_SLOTS * d->K) return MSCL_E_ARG;
+      float* part = ws + (ws_floats - (long)MSCL_STAT_SLOTS * d->K);
+      hipLaunchKernelGGL(colsum_det_kernel, dim3(MSCL_STAT_SLOTS), dim3(256), 0, st, dy, part, M, d->K);
+      MSCL_LAUNCH_CHECK();
+      hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->K + 255) / 256), dim3(256), 0, st, (const float*)part, dbias, MSCL_STAT_SLOTS, d->K);
+      MSCL_LAUNCH_CHECK();
+      return 0;
+    }
     const int RPc = 256 / (d->K / 8);
     long blocks = (M + RPc * 4 - 1) / (RPc * 4); if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, dbias, M, d->K);
     MSCL_LAUNCH_CHECK();
   }
   return 0;
+}
+
+// floats of `ws` mscl_conv3d_wgrad wants for this layer in deterministic mode (at most 64 slabs of the weight gradient plus
+// the bias partials); 0 outside deterministic mode for layers that do not use the window-resident kernel
+extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) {
+  if (!d) return 0;
+  if (!mscl_det()) return 0;
+  const int64_t dwn = (int64_t)d->K * d->kT * d->kH * d->kW * d->C;
+  int64_t slabs = ((int64_t)1 << 28) / (dwn > 0 ? dwn : 1);          // cap the slab workspace at 1 GiB
+  if (slabs > 64) slabs = 64;
+  if (slabs < 2) slabs = 2;
+  return slabs * dwn + (with_bias ? (int64_t)MSCL_STAT_SLOTS * d->K : 0);
 }

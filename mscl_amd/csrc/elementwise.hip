@@ -524,33 +524,43 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
                                                             const float* __restrict__ dy, float* __restrict__ dx, int rows,
                                                             int in_f, int out_f, int relu) {
   __shared__ float g[LIN_OCHUNK * ROWS];             // [oo][r]: a thread reads its ROWS values of one oo as float4s
-  const int o0 = blockIdx.y * LIN_OCHUNK;
-  for (int e = threadIdx.x; e < ROWS * LIN_OCHUNK; e += 256) {
-    const int r = e / LIN_OCHUNK, oo = e % LIN_OCHUNK, o = o0 + oo;
-    float v = 0.f;
-    if (r < rows && o < out_f) { v = dy[(long)r * out_f + o]; if (relu && !(y[(long)r * out_f + o] > 0.f)) v = 0.f; }
-    g[oo * ROWS + r] = v;                             // rows beyond the real count and features beyond out_f hold zeros
-  }
-  __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= in_f) return;
+  const int ic = i < in_f ? i : in_f - 1;
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  float wv[LIN_OCHUNK];
+  // gridDim.y blocks share the output features chunk by chunk and add their parts atomically; with gridDim.y == 1
+  // (deterministic mode) one block walks every chunk in order and stores plainly
+  for (int o0 = blockIdx.y * LIN_OCHUNK; o0 < out_f; o0 += gridDim.y * LIN_OCHUNK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < ROWS * LIN_OCHUNK; e += 256) {
+      const int r = e / LIN_OCHUNK, oo = e % LIN_OCHUNK, o = o0 + oo;
+      float v = 0.f;
+      if (r < rows && o < out_f) { v = dy[(long)r * out_f + o]; if (relu && !(y[(long)r * out_f + o] > 0.f)) v = 0.f; }
+      g[oo * ROWS + r] = v;                           // rows beyond the real count and features beyond out_f hold zeros
+    }
+    __syncthreads();
+    float wv[LIN_OCHUNK];
 #pragma unroll
-  for (int oo = 0; oo < LIN_OCHUNK; ++oo) wv[oo] = w[(long)(o0 + oo < out_f ? o0 + oo : out_f - 1) * in_f + i];
+    for (int oo = 0; oo < LIN_OCHUNK; ++oo) wv[oo] = w[(long)(o0 + oo < out_f ? o0 + oo : out_f - 1) * in_f + ic];
 #pragma unroll
-  for (int oo = 0; oo < LIN_OCHUNK; ++oo) {
+    for (int oo = 0; oo < LIN_OCHUNK; ++oo) {
 #pragma unroll
-    for (int r4 = 0; r4 < ROWS; r4 += 4) {
-      const float4 gv = *reinterpret_cast<const float4*>(&g[oo * ROWS + r4]);
-      acc[r4] = fmaf(gv.x, wv[oo], acc[r4]); acc[r4 + 1] = fmaf(gv.y, wv[oo], acc[r4 + 1]);
-      acc[r4 + 2] = fmaf(gv.z, wv[oo], acc[r4 + 2]); acc[r4 + 3] = fmaf(gv.w, wv[oo], acc[r4 + 3]);
+      for (int r4 = 0; r4 < ROWS; r4 += 4) {
+        const float4 gv = *reinterpret_cast<const float4*>(&g[oo * ROWS + r4]);
+        acc[r4] = fmaf(gv.x, wv[oo], acc[r4]); acc[r4 + 1] = fmaf(gv.y, wv[oo], acc[r4 + 1]);
+        acc[r4 + 2] = fmaf(gv.z, wv[oo], acc[r4 + 2]); acc[r4 + 3] = fmaf(gv.w, wv[oo], acc[r4 + 3]);
+      }
     }
   }
+  if (i >= in_f) return;
+  if (gridDim.y == 1) {
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) if (r < rows) atomicAdd(&dx[(long)r * in_f + i], acc[r]);
+    for (int r = 0; r < ROWS; ++r) if (r < rows) dx[(long)r * in_f + i] = acc[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) if (r < rows) atomicAdd(&dx[(long)r * in_f + i], acc[r]);
+  }
 }
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dw,
@@ -583,7 +593,7 @@ extern "C" int mscl_linear_bwd(const float* x, const float* w, const float* y, c
     const long nz = (long)rows * in_f;
     hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, dx, nz);
     MSCL_LAUNCH_CHECK();
-    const dim3 grid((in_f + 255) / 256, (out_f + LIN_OCHUNK - 1) / LIN_OCHUNK);
+    const dim3 grid((in_f + 255) / 256, mscl_det() ? 1 : (out_f + LIN_OCHUNK - 1) / LIN_OCHUNK);
     if (rows <= 8) hipLaunchKernelGGL(linear_bwd_dx_kernel<8>, grid, dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
     else if (rows <= 16) hipLaunchKernelGGL(linear_bwd_dx_kernel<16>, grid, dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);
     else hipLaunchKernelGGL(linear_bwd_dx_kernel<32>, grid, dim3(256), 0, st, w, y, dy, dx, rows, in_f, out_f, relu);

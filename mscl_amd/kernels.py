@@ -110,6 +110,8 @@ def conv3d_wgrad(x, dy, d, dw, dbias=None):
     ws = None
     if (d.C, d.K, d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW) == (64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1):
         ws = torch.empty((WGRAD_HALO_WS,), dtype=torch.float32, device=x.device)
+    elif lib.deterministic():          # per-split slabs (+ bias partials), added in a fixed order
+        ws = torch.empty((lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(dbias is not None)),), dtype=torch.float32, device=x.device)
     e0 = prof_begin()
     call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
          ws.numel() if ws is not None else 0, stream_ptr())

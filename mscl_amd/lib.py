@@ -31,6 +31,10 @@ class BnParams(Structure):
 P = c_void_p
 _SIGS = {
     'mscl_abi_version': [],
+    'mscl_set_deterministic': [c_int],
+    'mscl_get_deterministic': [],
+    'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P],
+    'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
     'mscl_conv3d_fwd_groups': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, c_int, P, c_int64, P],
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
@@ -78,6 +82,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
+_INT64_RESULT = ('mscl_conv3d_wgrad_ws',)
 EXPORTS = tuple(_SIGS)
 
 _lib = None
@@ -95,7 +100,7 @@ def load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = c_int
+        fn.restype = c_int64 if name in _INT64_RESULT else c_int
     _lib = lib
     return lib
 
@@ -144,3 +149,13 @@ def call(name, *args):
     code = fn(*args)
     if code != 0:
         check(code, name)
+
+
+def set_deterministic(on=True):
+    """the reference's `--deterministic` (tools/train.py:55-57,149): fixed-order sums in place of float atomics (include/mscl_hip.h,
+    mscl_set_deterministic); two runs on the same inputs are then bit-identical.  Process-wide, set before the first step."""
+    call('mscl_set_deterministic', int(bool(on)))
+
+
+def deterministic():
+    return bool(call_raw('mscl_get_deterministic'))

@@ -147,6 +147,21 @@ def broadcast_bn_buffers(model):
             dist.broadcast(m.running_mean, 0)
 
 
+def set_random_seed(seed, deterministic=False):
+    """ref: apis/train.py `set_random_seed` as tools/train.py:145-150 calls it: seeds Python / NumPy / torch and, with
+    `--deterministic`, asks for reproducible kernels -- here the library's deterministic mode (fixed-order sums in place of float
+    atomics, lib.set_deterministic) in place of cudnn.deterministic."""
+    import random
+
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if deterministic:
+        from . import lib
+        lib.set_deterministic(True)
+
+
 def train(model, optimizer, batches, total_epochs, base_lr=None, min_lr=0.0, start_epoch=0, log=None, step_fn=None,
           log_interval=None, work_dir=None, checkpoint_interval=None, val_batches=None, eval_interval=1, cfg=None):
     """`batches`: callable epoch -> iterable of data_batch dicts (device tensors).  Returns the last log_vars.

@@ -45,4 +45,4 @@ if (os.environ.get('MSCL_FORCE_DIST') != '1' or os.environ.get('MSCL_GRAPH_DP') 
         loss, _ = gs.step(batches[i % 8])
         losses.append(loss.clone())
     report('whole-step graph', losses, t0)
-print('queue_ptr', int(m.recognizer.queue_ptr), 'iters', m.recognizer.iters, 'sub-graphs', sum(g.graph is not None for g in m._key_graph) + sum(g.fwd is not None for g in m._query_graph))
+print('queue_ptr', int(m.recognizer.queue_ptr), 'iters', m.recognizer.iters, 'sub-graphs', sum(g.graph is not None for g in m._key_graph) + sum(g.fwd is not None for g in m.active_query_graphs()))
