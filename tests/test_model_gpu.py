@@ -269,6 +269,41 @@ def test_graphed_step_matches_eager(dev):
         assert abs(a - b) <= 3.0 * lnoise + 1e-3 * max(1.0, abs(a)), (l0, l0b, l0c, l1)
 
 
+def test_graphed_step_equals_eager_bitwise_in_deterministic_mode(dev):
+    """With lib.set_deterministic the captured-graph step and the eager step are the same arithmetic in the same order: three
+    optimizer steps give bit-identical losses, parameters and queue state (no noise yardstick needed)."""
+    from mscl_amd import ClipSGD, lib
+    from mscl_amd.graph import GraphedStep
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H, Kq = 2, 8, 32, 64
+    lib.set_deterministic(True)
+    try:
+        runs = []
+        for mode in ('eager', 'graph'):
+            model, cfg = build(T, Kq, dev)
+            opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+            batches = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(3)]
+            losses = []
+            if mode == 'graph':
+                gs = GraphedStep(model, opt, batches[0], warmup=2)
+                for s in range(3):
+                    losses.append(float(gs.step(batches[s])[0]))
+            else:
+                for s in (0, 0, 0, 1, 2):
+                    out = model.train_step(batches[s], sync_logs=False)
+                    opt.zero_grad(); out['loss'].backward(); opt.step()
+                    losses.append(float(out['loss'].detach()))
+                losses = losses[2:]
+            torch.cuda.synchronize()
+            runs.append((losses, model.arena.Q.clone(), model.recognizer.queue.clone(), model.recognizer_flow.queue.clone()))
+    finally:
+        lib.set_deterministic(False)
+    (l0, q0, a0, b0), (l1, q1, a1, b1) = runs
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(q0, q1), float((q0 - q1).abs().max())
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+
+
 # ----------------------------------------------------------------------------- 2 ranks on one GPU
 def _two_rank_worker(rank, world, port, q):
     """Both ranks drive cuda:0 through gloo (RCCL refuses two ranks on one device).  The oracle runs the
