@@ -82,7 +82,7 @@ def test_c_abi_exports_every_declared_symbol():
         g.build()
     handle = lib.load()
     header = open(os.path.join(ROOT, 'include', 'mscl_hip.h')).read()
-    declared = set(re.findall(r'^\s*int\s+(mscl_\w+)\s*\(', header, re.M))
+    declared = set(re.findall(r'^\s*(?:int|int64_t)\s+(mscl_\w+)\s*\(', header, re.M))
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
     for n in declared:
         assert hasattr(handle, n), n
