@@ -26,6 +26,28 @@ def test_config_equals_reference_dicts():
     assert cfg.dist_params.backend == 'nccl' and cfg.model.recognizer.K == 65536      # _base_ merge + attribute access
 
 
+def test_r50_config_equals_reference_dicts_and_state_dict_manifest():
+    """BASELINE.json configs[4]: the authored mscl_r50 config against the reference's dump (tests/golden/ref_config_r50.json) and
+    the built model's state dict against the reference's 1333-entry manifest (names, shapes, dtypes, order)"""
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r50_cosm_lr3e-2.py'))
+    ref = json.load(open(os.path.join(GOLD, 'ref_config_r50.json')))
+    norm = lambda x: {k: norm(v) for k, v in x.items()} if isinstance(x, dict) else ([norm(v) for v in x] if isinstance(x, (list, tuple)) else x)
+    for k in ('model', 'optimizer', 'optimizer_config', 'lr_config', 'total_epochs', 'dataset_size', 'num_frames', 'find_unused_parameters'):
+        assert norm(cfg[k]) == norm(ref[k]), k
+    m = build_model(cfg.model)
+    man = json.load(open(os.path.join(GOLD, 'state_dict_manifest_r50.json')))
+    assert [(n, list(v.shape), str(v.dtype)) for n, v in m.state_dict().items()] == [tuple(e) for e in man]
+    assert type(m.recognizer.encoder_q).__name__ == 'ResNet3dSlowOnlyHip' and type(m.recognizer_flow.encoder_q).__name__ == 'FlowR2D50Hip'
+    # zero_init_residual (resnet3d.py:826-829): the last BatchNorm of every Bottleneck3d starts at zero; r2d_50 keeps ones
+    assert float(m.recognizer.encoder_q.layer2[1].conv3.bn.weight.abs().max()) == 0.0
+    assert float(m.recognizer_flow.encoder_q.layer2[1].conv3[1].weight.min()) == 1.0
+    ref_file = '/root/reference/configs/recognition/moco/mscl_r50_cosm_lr3e-2.py'
+    if os.path.exists(ref_file):                      # the reference's own file loads unchanged where the tree is mounted
+        rcfg = Config.fromfile(ref_file)
+        rm = build_model(rcfg.model)
+        assert [n for n, _ in rm.state_dict().items()] == [e[0] for e in man]
+
+
 def test_registry_surface():
     from mscl_amd.registry import BACKBONES, HEADS, LOSSES, MODELS, NECKS, RECOGNIZERS, SSL_AUGS
     assert BACKBONES is NECKS is HEADS is RECOGNIZERS is LOSSES is MODELS          # builder.py:9-15
