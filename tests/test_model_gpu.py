@@ -1053,6 +1053,31 @@ def test_r3d18_single_stream_full_size(dev):
     assert not bad, bad
 
 
+def test_step_at_the_shipped_batch_of_32(dev):
+    """videos_per_gpu = 32 is the batch the shipped config and the reference train with (mscl_r18_cosm_lr2e-2.py:50, clip 8 x
+    112^2): 96 stacked InfoNCE rows (three 32-row tiles), 64 rows through the flow projection head in the batched flow pass, 128
+    LMCL rows.  All 23 log entries against the oracle (losses to 1e-3 relative, at most one row of an accuracy flips), integer
+    bookkeeping exact."""
+    from mscl_amd.synthetic import synthetic_batch
+    from oracle import fill as ofill, mscl as om
+    B, T, H, Kq = 32, 8, 112, 65536
+    model, _ = build(T, Kq, dev)
+    batch = synthetic_batch(B, T, H, H, 0, 0)
+    out = model.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})
+    model.zero_grad(); out['loss'].backward()
+    model.sync_streams(); torch.cuda.synchronize()
+    orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
+    torch.manual_seed(100)
+    oo = orc.train_step(batch)
+    logs_match(out['log_vars'], oo['log_vars'], 'B=32', rows=B, loss_tol=1e-3, pos_rows=B * (T // 2))
+    for rec in (model.recognizer, model.recognizer_flow):
+        assert int(rec.queue_ptr) == B and rec.batch_size == B
+        assert int(rec.count.min()) == 1 and int(rec.count.max()) == 1        # moco.py:434-437: every age +1, the new slots reset to 1
+    assert model.recognizer.iters == B and model.recognizer_flow.iters == 2 * B
+    g = model.arena.G
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
 def test_deterministic_mode_is_bit_identical(dev):
     """lib.set_deterministic (the reference's `--deterministic`, tools/train.py:55-57,149): two steps from the same state on the
     same batch give bit-identical log entries, query features and gradient arenas (eager launches on three streams); without
