@@ -65,6 +65,54 @@ def build_backbone_by_name(cfg):
 BACKBONES.register_module(name='ResNet3dSlowOnly', module=ResNet3dSlowOnlyHip)
 
 
+def bind_module(m, ar, key, rec):
+    """runtime views of one parameter-holding module into the arenas (`key`: the key-encoder twin); conv stems with fewer than
+    8 input channels register their padded-shadow refresh with `rec`"""
+    P, Pb = ('KX', 'Kb') if key else ('Q', 'Qb')
+    if isinstance(m, Conv3dHip):
+        sw = m.weight._mscl_slot
+        sb = m.bias._mscl_slot if m.bias is not None else None
+        rt = dict(slot_w=sw, slot_b=sb, bias=ar.view(P, sb) if sb is not None else None,
+                  dbias=None if key or sb is None else ar.view('G', sb), wT=None, dw=None)
+        dev = ar.device
+        if m.cin_eff == m.in_channels:
+            rt['w'] = ar.packed(Pb, sw)
+            if not key:
+                rt['dw'] = ar.packed('G', sw)
+        else:       # 3-channel stems: zero-padded 8-channel shadow (and padded gradient staging)
+            w8 = torch.zeros((m.out_channels, *m.k_exec, 8), dtype=torch.bfloat16, device=dev)
+            rt['w'] = w8
+            src = ar.packed(P, sw)
+
+            def refresh(w8=w8, src=src, cin=m.in_channels, pair=m.pair_w):
+                if pair:
+                    K.pair_w_weight(src, w8)
+                else:
+                    w8[..., :cin].copy_(src)
+            (rec._k_refresh if key else rec._q_refresh).append(refresh)
+            if not key:
+                dw8 = torch.zeros((m.out_channels, *m.k_exec, 8), dtype=torch.float32, device=dev)
+                rt['dw'] = dw8
+                rt['dw8_flush'] = (dw8, ar.packed('G', sw), m.in_channels)
+        if not key and m.cin_eff == m.in_channels:
+            wT = torch.empty((m.in_channels, *m.kernel_size, m.out_channels), dtype=torch.bfloat16, device=dev)
+            rt['wT'] = wT          # refreshed by ONE batched transpose launch (refresh_after_optimizer)
+        m._rt = rt
+    elif isinstance(m, BatchNorm3dHip):
+        sg, sb = m.weight._mscl_slot, m.bias._mscl_slot
+        m._rt = dict(gamma=ar.view(P, sg), beta=ar.view(P, sb), slot_g=sg, slot_b=sb,
+                     dgamma=None if key else ar.view('G', sg), dbeta=None if key else ar.view('G', sb))
+    elif isinstance(m, LinearHip):
+        sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
+        m._rt = dict(w=ar.view(P, sw), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
+                     dw=None if key else ar.view('G', sw), db=None if key else ar.view('G', sb))
+    elif isinstance(m, Conv1dK1Hip):       # (out, in, 1) contiguous == the (out, in) matrix of the linear kernels
+        sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
+        shp = (m.out_channels, m.in_channels)
+        m._rt = dict(w=ar.view(P, sw).view(shp), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
+                     dw=ar.view('G', sw).view(shp), db=ar.view('G', sb))
+
+
 @RECOGNIZERS.register_module()
 class MoCoV2(nn.Module):
     def __init__(self, backbone, neck, moco_head, im_key='imgs', dim_in=512, dim=128, K=65536, m_base=0.994,
@@ -136,6 +184,124 @@ class MoCoV2(nn.Module):
         emb, maps = emb_maps
         return mlp_head(self.mlp_k, emb), maps
 
+    # ------------------------------------------------------------------ stand-alone step (single-recognizer MoCo training)
+    # Inside MSCLWithAug the two recognizers share that model's arenas and step; a MoCoV2 built on its own (registry type
+    # 'MoCoV2' at the top of a config) owns an arena and runs recognizers/moco.py:442-515 itself.
+    def materialize(self, device='cuda'):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise MsclError('materialize() needs a GPU device: the HIP path has no CPU fallback')
+        from .lib import load
+        load()
+        ar = ParamArena(device)
+        plan = []
+        ar.begin_group('rec')
+        for mq, mk in zip(self.q_modules(), self.k_modules()):
+            for (nq, pq), (nk, pk) in zip(mq.named_parameters(), mk.named_parameters()):
+                assert nq == nk and pq.shape == pk.shape
+                plan.append((ar.add(nq, pq.shape), pq, pk))
+        ar.end_group('rec')
+        ar.allocate()
+        for slot, pq, pk in plan:
+            vq, vk = ar.view('Q', slot), ar.view('KX', slot)
+            vq.copy_(pq.data.to(device)); vk.copy_(pk.data.to(device))
+            pq.data, pk.data = vq, vk
+            pq.grad = ar.view('G', slot)
+            pq._mscl_slot = pk._mscl_slot = slot
+        for mod in self.modules():
+            for bname, buf in list(mod._buffers.items()):
+                if buf is not None:
+                    mod._buffers[bname] = buf.to(device)
+        self.arena = ar
+        self._arena, self._range = ar, tuple(ar.ranges['rec'])
+        self._k_refresh, self._q_refresh = [], []
+        for mods, key in ((self.q_modules(), False), (self.k_modules(), True)):
+            for top in mods:
+                for m in top.modules():
+                    bind_module(m, ar, key, self)
+        entries = [(m._rt['w'], m._rt['wT'], m.out_channels, m.taps, m.in_channels) for top in self.q_modules()
+                   for m in top.modules() if isinstance(m, Conv3dHip) and m._rt.get('wT') is not None]
+        self._tr_table = K.build_transpose_table(entries, device)
+        self.reducer = None                       # ClipSGD all-reduces the whole gradient arena after backward
+        self._m_ring = StagingRing((1,), torch.float32, device)
+        self._m_cpu = torch.zeros(1, dtype=torch.float32)
+        self._step = 0
+        self.sync_shadows()
+        return self
+
+    @torch.no_grad()
+    def sync_shadows(self):
+        ar = self._standalone()
+        K.cast_bf16(ar.Q, ar.Qb)
+        K.cast_bf16(ar.KX, ar.Kb)
+        for fn in self._q_refresh + self._k_refresh:
+            fn()
+        K.weight_transpose_batched(*self._tr_table)
+
+    @torch.no_grad()
+    def refresh_after_optimizer(self):
+        for fn in self._q_refresh:
+            fn()
+        K.weight_transpose_batched(*self._tr_table)
+
+    def sync_streams(self):
+        pass                                      # one stream
+
+    def _standalone(self):
+        ar = getattr(self, 'arena', None)
+        if ar is None:
+            raise MsclError('stand-alone MoCoV2: call materialize(device) first (inside MSCLWithAug the outer model owns the step)')
+        return ar
+
+    def zero_grad(self, set_to_none=False):
+        self._standalone().G.zero_()
+
+    def forward_train(self, im_q, im_k, aux_info=None, return_features=False, update_queue=True):
+        """ref: moco.py:473-515.  im_q / im_k: (B,3,T,H,W) fp32 device clips.  Returns the losses dict (top1_acc, top5_acc,
+        loss_cls with the head's suffix); with return_features also dict(q, k)."""
+        self._standalone()
+        B = im_q.shape[0]
+        K.ZEROS.reset(im_q.device)
+        bg = B * parallel.world_size()
+        self.batch_size = bg
+        self.m = momentum_at(self.iters, self.max_iters, self.m_base)
+        self._m_cpu[0] = self.m
+        self._m_ring.push(self._m_cpu)
+        aug = self.aug_gpu
+        self.momentum_update(self._m_ring.dev)                                   # moco.py:534
+        with torch.no_grad():
+            x_k = parallel.shuffle_select(im_k, self._step, 0)                   # shuffle-BN (moco.py:146-172)
+            k = self.encode_k(aug.pack_rgb(x_k))[0]
+            k = parallel.unshuffle_select(k, self._step, 0)                      # moco.py:174-191
+        q, _ = self.encode_q(aug.pack_rgb(im_q), levels=())                      # q_mlvl has no reader in MoCoHead.loss
+        loss, rank = _MoCoLossFn.apply(q, k, self, update_queue)
+        if self.training:
+            self.iters += bg
+        self._step += 1
+        sfx = self.moco_head.basename
+        rk = rank.float()
+        losses = OrderedDict()
+        losses['top1_acc' + sfx] = (rk < 1).float().mean()
+        losses['top5_acc' + sfx] = (rk < 5).float().mean()
+        losses['loss_cls' + sfx] = loss
+        self._dbg = dict(q=q.detach(), k=k)
+        if return_features:
+            return losses, dict(q=q, k=k)
+        return losses
+
+    def train_step(self, data_batch, optimizer=None, sync_logs=True, **kwargs):
+        """ref: moco.py:442-460 + recognizers/base.py:274-308: {'loss', 'log_vars', 'num_samples'}"""
+        im_q, im_k = data_batch[self.im_key][0], data_batch[self.im_key][1]
+        losses = self.forward_train(im_q, im_k, {})
+        loss = sum(v for k2, v in losses.items() if 'loss' in k2)
+        vals = torch.stack([v.detach().float() for v in losses.values()] + [loss.detach().float()])
+        if not parallel.single():
+            dist.all_reduce(vals)
+            vals = vals / parallel.world_size()
+        keys = list(losses.keys()) + ['loss']
+        log_vars = OrderedDict(zip(keys, vals.tolist())) if sync_logs else OrderedDict(zip(keys, vals.unbind()))
+        return dict(loss=loss, log_vars=log_vars, num_samples=im_q.shape[0])
+
     @torch.no_grad()
     def dequeue_and_enqueue(self, keys, gathered=None):
         """ref: moco.py:423-440 (keys are all-gathered first; bookkeeping is bit-exact int64 on device).
@@ -144,6 +310,30 @@ class MoCoV2(nn.Module):
         if self.K % keys.shape[0] != 0:
             raise AssertionError('K % batch_size == 0 (moco.py:432)')
         K.queue_enqueue(self.queue, self.count, self.queue_ptr, keys.contiguous())
+
+
+class _MoCoLossFn(torch.autograd.Function):
+    """InfoNCE of ONE recognizer against its own queue (moco.py:481-498 + heads/moco_head.py:38-77): the loss phase of a
+    stand-alone MoCoV2 step.  Returns (loss_cls, rank per row); the query gradient is computed here, as in _MSCLLossFn."""
+
+    @staticmethod
+    def forward(ctx, q, k, rec, update_queue):
+        B = q.shape[0]
+        inv_T = 1.0 / rec.T
+        ones = torch.full((B,), 1.0 / B, device=q.device)
+        pos = K.rowdot(q, k)
+        lse, loss_rows, rank = K.nce_forward(rec.queue, rec.count, q, pos, inv_T)
+        dq = K.nce_backward(rec.queue, rec.count, q, lse, ones, inv_T)
+        K.nce_pos_bwd(k, pos, lse, ones, dq, inv_T)
+        if update_queue:
+            rec.dequeue_and_enqueue(k)
+        ctx.save_for_backward(dq)
+        ctx.mark_non_differentiable(rank)
+        return loss_rows.mean(), rank
+
+    @staticmethod
+    def backward(ctx, g, _grank):
+        return g * ctx.saved_tensors[0], None, None, None
 
 
 class KeyGraph:
@@ -489,49 +679,7 @@ class MSCLWithAug(nn.Module):
         return self
 
     def _bind(self, m, ar, key, rec):
-        P, Pb = ('KX', 'Kb') if key else ('Q', 'Qb')
-        if isinstance(m, Conv3dHip):
-            sw = m.weight._mscl_slot
-            sb = m.bias._mscl_slot if m.bias is not None else None
-            rt = dict(slot_w=sw, slot_b=sb, bias=ar.view(P, sb) if sb is not None else None,
-                      dbias=None if key or sb is None else ar.view('G', sb), wT=None, dw=None)
-            dev = ar.device
-            if m.cin_eff == m.in_channels:
-                rt['w'] = ar.packed(Pb, sw)
-                if not key:
-                    rt['dw'] = ar.packed('G', sw)
-            else:       # 3-channel stems: zero-padded 8-channel shadow (and padded gradient staging)
-                w8 = torch.zeros((m.out_channels, *m.k_exec, 8), dtype=torch.bfloat16, device=dev)
-                rt['w'] = w8
-                src = ar.packed(P, sw)
-
-                def refresh(w8=w8, src=src, cin=m.in_channels, pair=m.pair_w):
-                    if pair:
-                        K.pair_w_weight(src, w8)
-                    else:
-                        w8[..., :cin].copy_(src)
-                (rec._k_refresh if key else rec._q_refresh).append(refresh)
-                if not key:
-                    dw8 = torch.zeros((m.out_channels, *m.k_exec, 8), dtype=torch.float32, device=dev)
-                    rt['dw'] = dw8
-                    rt['dw8_flush'] = (dw8, ar.packed('G', sw), m.in_channels)
-            if not key and m.cin_eff == m.in_channels:
-                wT = torch.empty((m.in_channels, *m.kernel_size, m.out_channels), dtype=torch.bfloat16, device=dev)
-                rt['wT'] = wT          # refreshed by ONE batched transpose launch (refresh_after_optimizer)
-            m._rt = rt
-        elif isinstance(m, BatchNorm3dHip):
-            sg, sb = m.weight._mscl_slot, m.bias._mscl_slot
-            m._rt = dict(gamma=ar.view(P, sg), beta=ar.view(P, sb), slot_g=sg, slot_b=sb,
-                         dgamma=None if key else ar.view('G', sg), dbeta=None if key else ar.view('G', sb))
-        elif isinstance(m, LinearHip):
-            sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
-            m._rt = dict(w=ar.view(P, sw), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
-                         dw=None if key else ar.view('G', sw), db=None if key else ar.view('G', sb))
-        elif isinstance(m, Conv1dK1Hip):       # (out, in, 1) contiguous == the (out, in) matrix of the linear kernels
-            sw, sb = m.weight._mscl_slot, m.bias._mscl_slot
-            shp = (m.out_channels, m.in_channels)
-            m._rt = dict(w=ar.view(P, sw).view(shp), b=ar.view(P, sb), slot_w=sw, slot_b=sb,
-                         dw=ar.view('G', sw).view(shp), db=ar.view('G', sb))
+        bind_module(m, ar, key, rec)
 
     @torch.no_grad()
     def sync_shadows(self):

@@ -1053,6 +1053,65 @@ def test_r3d18_single_stream_full_size(dev):
     assert not bad, bad
 
 
+def test_standalone_mocov2_step_vs_oracle(dev):
+    """A MoCoV2 recognizer on its own (registry type 'MoCoV2' at the top of a config; recognizers/moco.py:442-515): materialize,
+    train_step, backward, ClipSGD step -- against the oracle's MoCoV2.forward_train (the function the MSCL goldens pin).  Loss to
+    1e-3, accuracies equal, q / k cosine >= 0.995, gradient norm within 8 %, per-tensor cosine >= 0.90 on tensors carrying >= 1 %
+    of the norm (neck parameters receive none: q_mlvl has no reader), queue bookkeeping exact, two more optimizer steps finite."""
+    from mscl_amd import ClipSGD, Config
+    from mscl_amd.fill import fill_module
+    from mscl_amd.registry import build_recognizer
+    from oracle import fill as ofill, mscl as om
+    cfg = Config.fromfile(os.path.join(os.path.dirname(GOLD), '..', CFG_FILES['r18']))
+    rc = cfg.model.recognizer
+    rc.K = 4096
+    torch.manual_seed(0)
+    model = build_recognizer(rc)
+    fill_module(model)
+    model.materialize(dev).train()
+    opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+    neck = dict(in_channels=[128, 256, 512], out_channels=128,
+                sepc_cfg=dict(in_channels=[128, 128, 128], out_channels=128, stride=(2, 2, 2), iBN=False, Pconv_num=2))
+    orc = om.MoCoV2('rgb', 512, 128, 4096, rc.m_base, rc.max_iters, rc.T, neck=neck, basename='')
+    ofill.fill_module(orc); orc.train()
+    B, T, H = 4, 8, 112
+    g = torch.Generator().manual_seed(3)
+    im_q, im_k = torch.rand(B, 3, T, H, H, generator=g), torch.rand(B, 3, T, H, H, generator=g)
+    out = model.train_step(dict(imgs=[im_q.to(dev), im_k.to(dev)]))
+    opt.zero_grad(); out['loss'].backward()
+    torch.cuda.synchronize()
+    assert list(out['log_vars'].keys()) == ['top1_acc', 'top5_acc', 'loss_cls', 'loss'] and out['num_samples'] == B
+    orc.batch_size = B
+    ol, of = orc.forward_train(im_q, im_k)
+    ol['loss_cls'].backward()
+    assert abs(out['log_vars']['loss_cls'] - float(ol['loss_cls'])) <= 1e-3 * max(1.0, abs(float(ol['loss_cls'])))
+    assert abs(out['log_vars']['loss'] - float(ol['loss_cls'])) <= 1e-3 * max(1.0, abs(float(ol['loss_cls'])))
+    assert out['log_vars']['top1_acc'] == float(ol['top1_acc']) and out['log_vars']['top5_acc'] == float(ol['top5_acc'])
+    cos = torch.nn.functional.cosine_similarity
+    assert cos(model._dbg['q'].float().cpu(), of['q'].detach(), dim=1).min().item() >= 0.995
+    assert cos(model._dbg['k'].float().cpu(), of['k'].detach(), dim=1).min().item() >= 0.995
+    assert int(model.queue_ptr) == int(orc.queue_ptr) == B and model.iters == orc.iters == B
+    assert torch.equal(model.count.cpu(), orc.count)
+    assert torch.allclose(model.queue[:, :B].cpu(), orc.queue[:, :B], atol=2e-2)
+    go = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
+    gh = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    tot_o = sum(float(v.double().pow(2).sum()) for v in go.values()) ** 0.5
+    tot_h = sum(float(v.double().pow(2).sum()) for v in gh.values()) ** 0.5
+    assert abs(tot_h - tot_o) <= 0.08 * tot_o, (tot_h, tot_o)
+    for n, v in gh.items():
+        if n not in go:
+            assert float(v.abs().max()) == 0.0, n                         # e.g. the neck: no reader, no gradient
+        elif float(go[n].norm()) >= 0.01 * tot_o:
+            c = float(cos(v.flatten(), go[n].flatten(), dim=0))
+            assert c >= 0.90, (n, c)
+    opt.step()
+    for s in range(2):
+        out = model.train_step(dict(imgs=[im_q.to(dev), im_k.to(dev)]))
+        opt.zero_grad(); out['loss'].backward(); opt.step()
+        assert out['log_vars']['loss'] == out['log_vars']['loss'] and abs(out['log_vars']['loss']) < 1e4
+    assert int(model.queue_ptr) == 3 * B and model.iters == 3 * B
+
+
 def test_step_at_the_shipped_batch_of_32(dev):
     """videos_per_gpu = 32 is the batch the shipped config and the reference train with (mscl_r18_cosm_lr2e-2.py:50, clip 8 x
     112^2): 96 stacked InfoNCE rows (three 32-row tiles), 64 rows through the flow projection head in the batched flow pass, 128
