@@ -791,7 +791,10 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream);
 // layer-1 shape (3x3x3 s1 p1, 64 -> 64): halo-resident kernel, 131 / 109 us vs 156 / 135 us (fwd / dgrad) for the
 // implicit-GEMM kernel; MSCL_HALO=0 switches it off
+static int g_halo_off = 0;       // experiment switch (mscl_set_halo_off): the next launches skip the window-resident layer-1 kernel
+extern "C" int mscl_set_halo_off(int off) { g_halo_off = off; return 0; }
 static bool halo_enabled(const mscl_conv_desc* d) {
+  if (g_halo_off) return false;
   const char* e = getenv("MSCL_HALO");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;                        // forced (tests: small planes too)

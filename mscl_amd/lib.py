@@ -32,6 +32,7 @@ P = c_void_p
 _SIGS = {
     'mscl_abi_version': [],
     'mscl_set_deterministic': [c_int],
+    'mscl_set_halo_off': [c_int],
     'mscl_get_deterministic': [],
     'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P],
     'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],

@@ -41,6 +41,11 @@ LOG_KEYS = ('top1_acc', 'top5_acc', 'loss_cls', 'top1_acc_flow', 'top5_acc_flow'
 LOG_KEYS_NO_AUG_MX = tuple(k for k in LOG_KEYS if not k.endswith('_mx_aug') and not k.endswith('_mx_r_aug'))
 
 
+# experiment: the key encoder's layer-1 convs on the implicit-GEMM kernel (64 KB of LDS, co-resident with other chains' kernels)
+# instead of the window-resident one (144 KB: nothing else runs on the CU meanwhile)
+KEY_NO_HALO = os.environ.get('MSCL_KEY_NO_HALO', '0') == '1'
+
+
 def momentum_at(iters, max_iters, m_base):
     """ref: moco.py:413-415."""
     factor = min(iters / max_iters, 1)
@@ -180,7 +185,16 @@ class MoCoV2(nn.Module):
     def encode_k(self, x, levels=()):
         """key forward (moco.py:535-545).  k_mlvl has no reader on the MSCL path once the dead unshuffle all-gathers are
         dropped, so by default the key neck computes the embedding only."""
-        emb_maps, _ = self.neck_k(self.encoder_k(x), levels=levels)
+        if KEY_NO_HALO:
+            from . import lib as _lib
+            _lib.call('mscl_set_halo_off', 1)
+            try:
+                feats = self.encoder_k(x)
+            finally:
+                _lib.call('mscl_set_halo_off', 0)
+        else:
+            feats = self.encoder_k(x)
+        emb_maps, _ = self.neck_k(feats, levels=levels)
         emb, maps = emb_maps
         return mlp_head(self.mlp_k, emb), maps
 
