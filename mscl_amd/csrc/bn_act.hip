@@ -292,8 +292,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ rinv, const float* __restrict__ scratch, bf16_t* __restrict__ dy,
     bf16_t* __restrict__ dres, int identity_dres, long rows, int C, int relu,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rdgamma, float* __restrict__ rdbeta,
-    const float* __restrict__ beta, int groups) {
+    const float* __restrict__ beta, int groups, int ldc) {
   extern __shared__ float sm[];   // [10][groups][C]: gamma*inv, mean, inv, a, b; the residual's four; mask shift
+  // maps wider than 512 channels run as 512-channel chunks along blockIdx.y (C = chunk width, ldc = the map's channel count): the
+  // constants of a 2048-channel map took 80 KB of LDS = one block per CU, and the pass ran at 1.8 TB/s
+  const int ch = blockIdx.y * C;
+  gamma += ch; mean += ch; inv += ch; scratch += ch; dgamma += ch; dbeta += ch;
+  if (beta) beta += ch;
+  if (ry) { rgamma += ch; rmean += ch; rinv += ch; rdgamma += ch; rdbeta += ch; }
   const int GC = groups * C;
   float* gi = sm; float* mu = sm + GC; float* iv = sm + 2 * GC; float* ca = sm + 3 * GC; float* cb = sm + 4 * GC;
   float* rgi = sm + 5 * GC; float* rmu = sm + 6 * GC; float* riv = sm + 7 * GC; float* rcb = sm + 8 * GC;
@@ -304,18 +310,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   for (int c = threadIdx.x; c < C; c += 256) {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     for (int gq = 0; gq < groups; ++gq) {
-      const int k = gq * C + c;
-      const float* sc = scratch + (long)gq * MSCL_STAT_SLOTS * 4 * C;
-      gi[k] = gamma[c] * inv[k]; mu[k] = mean[k]; iv[k] = inv[k];
-      msh[k] = mask_y ? beta[c] - mean[k] * (gamma[c] * inv[k]) : 0.f;
+      const int k = gq * C + c, kg = gq * ldc + c;          // LDS index; index into the [group][ldc] arrays
+      const float* sc = scratch + (long)gq * MSCL_STAT_SLOTS * 4 * ldc;
+      gi[k] = gamma[c] * inv[kg]; mu[k] = mean[kg]; iv[k] = inv[kg];
+      msh[k] = mask_y ? beta[c] - mean[kg] * (gamma[c] * inv[kg]) : 0.f;
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) {
-        t0 += sc[sl * 4 * C + c]; t1 += sc[sl * 4 * C + C + c];
-        if (ry) t2 += sc[sl * 4 * C + 2 * C + c];
+        t0 += sc[sl * 4 * ldc + c]; t1 += sc[sl * 4 * ldc + ldc + c];
+        if (ry) t2 += sc[sl * 4 * ldc + 2 * ldc + c];
       }
       ca[k] = t0 * inv_n; cb[k] = t1 * inv_n;
-      if (ry) { rgi[k] = rgamma[c] * rinv[k]; rmu[k] = rmean[k]; riv[k] = rinv[k]; rcb[k] = t2 * inv_n; }
+      if (ry) { rgi[k] = rgamma[c] * rinv[kg]; rmu[k] = rmean[kg]; riv[k] = rinv[kg]; rcb[k] = t2 * inv_n; }
       p0 += t0; p1 += t1; p2 += t2;
     }
     if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step, or once with two groups)
@@ -325,10 +331,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
   __syncthreads();
   const int G = C >> 3;                      // a power of two (checked by the launcher)
+  const int gsh = 31 - __clz(G);
   const unsigned total32 = (unsigned)(rows * G), step32 = gridDim.x * blockDim.x, gmask = (unsigned)(G - 1);
   const unsigned ebound = groups > 1 ? (unsigned)(rows_g * G) : 0xFFFFFFFFu;
+  const long ldg = ldc >> 3, chg = ch >> 3;  // granules per map row, first granule of this chunk
   for (unsigned e32 = blockIdx.x * blockDim.x + threadIdx.x; e32 < total32; e32 += step32) {
-    const long e = (long)e32;
+    const long e = (long)(e32 >> gsh) * ldg + chg + (e32 & gmask);      // granule index in the map
     const int c0 = (int)(e32 & gmask) * 8 + (e32 >= ebound ? C : 0);
     float d[8], yy[8], o8[8];
     unpack8(*reinterpret_cast<const uint4*>(dout + e * 8), d);
@@ -405,15 +413,17 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
                        out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C, det);
     MSCL_LAUNCH_CHECK();
   }
-  const long total = rows * (C / 8);
-  long b2 = (total + 255) / 256; if (b2 > 2048) b2 = 2048;
-  if (C * groups > 1024) {      // 10 * C floats of constants per group: past the 64-KB default for dynamic LDS
+  int Ca = Cc, achunks = chunks;                                 // the apply pass's own chunking
+  if (const char* f = getenv("MSCL_BN_APPLY_CHUNK")) { if (f[0] == '0') { Ca = C; achunks = 1; } }     // tuning aid: whole rows per block
+  if (Ca * groups > 1024) {      // 10 * C floats of constants per group: past the 64-KB default for dynamic LDS
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2), dim3(256), (size_t)10 * groups * C * sizeof(float), st, dout, out, y,
+  const long total = rows * (Ca / 8);
+  long b2 = (total + 255) / 256; if (b2 > 2048 / achunks) b2 = 2048 / achunks; if (b2 < 1) b2 = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2, achunks), dim3(256), (size_t)10 * groups * Ca * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
-                     want_identity_dres, (long)rows, C, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups);
+                     want_identity_dres, (long)rows, Ca, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups, C);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
