@@ -36,6 +36,22 @@ SHAPES = [
 ]
 
 
+# ResNet3dSlowOnly-50 at 8 x 32 x 224^2 (BASELINE configs[4]; --r50): thin-K convs on 205-MB maps, HBM-bound
+SHAPES_R50 = [
+    ('r50_l1_c1_64_64', (8, 16, 56, 56, 64), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_l1_c2_133', (8, 16, 56, 56, 64), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r50_l1_c3_64_256', (8, 16, 56, 56, 64), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_l1_c1_256_64', (8, 16, 56, 56, 256), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_l2_c2_133_s2', (8, 16, 56, 56, 128), 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ('r50_l2_c3_128_512', (8, 16, 28, 28, 128), 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_l2_c1_512_128', (8, 16, 28, 28, 512), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_l3_c1_311', (8, 16, 14, 14, 1024), 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('r50_l3_c3_256_1024', (8, 16, 14, 14, 256), 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_l4_c1_311', (8, 16, 7, 7, 2048), 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('r50_l4_c3_512_2048', (8, 16, 7, 7, 512), 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+]
+
+
 def timeit(fn, iters):
     for _ in range(3):
         fn()
@@ -91,7 +107,11 @@ def main():
     ap.add_argument('--sweep', default=None, help='NAME=v1,v2,..: A/B an environment tuning hook that the library reads per '
                     'launch (e.g. MSCL_FAST_STAGES=2,3,4), variants interleaved per shape in ONE process')
     ap.add_argument('--rounds', type=int, default=3, help='rounds per variant with --sweep (min is reported)')
+    ap.add_argument('--r50', action='store_true', help='the ResNet3dSlowOnly-50 shapes at 8 x 32 x 224^2 instead (adds a GB/s column: x + y bytes)')
+    ap.add_argument('--no-stats', action='store_true', help='forward without the BatchNorm statistics epilogue')
     a = ap.parse_args()
+    if a.r50:
+        SHAPES[:] = SHAPES_R50
     if a.sweep:
         return sweep(a)
     dev = torch.device('cuda:0')
@@ -109,15 +129,18 @@ def main():
         stats = torch.zeros((K.STAT_SLOTS, 2, Kc), device=dev)[0]
         flops = 2.0 * d.N * d.To * d.Ho * d.Wo * Kc * kern[0] * kern[1] * kern[2] * C
         out = [f'{name:16s} {flops/1e9:7.2f} GF']
+        nbytes = 2.0 * (x.numel() + dy.numel())
+        gbs = (lambda ms: f' {nbytes/ms/1e6:6.0f} GB/s') if a.r50 else (lambda ms: '')
         if 'fwd' in modes:
-            ms = timeit(lambda: K.conv3d_fwd(x, w, d, stats=(stats[0], stats[1])), a.iters)
-            out.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF')
+            st = None if a.no_stats else (stats[0], stats[1])
+            ms = timeit(lambda: K.conv3d_fwd(x, w, d, stats=st), a.iters)
+            out.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF' + gbs(ms))
         if 'dgrad' in modes and C >= 16:
             ms = timeit(lambda: K.conv3d_dgrad(dy, wT, d), a.iters)
-            out.append(f'dgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF')
+            out.append(f'dgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF' + gbs(ms))
         if 'wgrad' in modes:
             ms = timeit(lambda: K.conv3d_wgrad(x, dy, d, dw), a.iters)
-            out.append(f'wgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF')
+            out.append(f'wgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF' + gbs(ms))
         print('  '.join(out), flush=True)
 
 
