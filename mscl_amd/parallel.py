@@ -173,10 +173,18 @@ class GradReducer:
     while backward continues with the earlier layers; `finish()` waits for all of them before the optimizer.
     Layer 4 alone is 100 MB of the 150 MB: it is reduced under the whole layer3..stem backward."""
 
-    def __init__(self, flat, ranges, need=None):
+    def __init__(self, flat, ranges, need=None, transport=None):
+        """transport: 'fp32' (default: the reference's DDP averages fp32 gradients) or 'bf16' (MSCL_GRAD_TRANSPORT=bf16): each
+        bucket travels as bf16 -- half the bytes over the xGMI links, 75 instead of 150 MB per step -- and is widened and
+        averaged on arrival.  Every rank receives the same sums, so the replicas stay bit-identical; the values differ from the
+        fp32 mean by one bf16 rounding of each rank's gradient and of the sum (relative 2^-8 per element, direction cosine
+        ~0.99999).  Opt-in: unmeasured on a multi-GPU node (SURVEY.md section 5.8 names it as the transport to try)."""
         self.flat, self.ranges = flat, list(ranges)
         self.need = list(need) if need is not None else [1] * len(self.ranges)   # trigger calls that complete a bucket
         self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)
+        self.transport = transport or os.environ.get('MSCL_GRAD_TRANSPORT', 'fp32')
+        if self.transport not in ('fp32', 'bf16'):
+            raise ValueError(f'gradient transport {self.transport!r}: fp32 or bf16')
 
     def bucket_done(self, i, force=False):
         if single() or i in self.launched:
@@ -187,18 +195,23 @@ class GradReducer:
         self.launched.add(i)
         a, b = self.ranges[i]
         seg = self.flat[a:b]
-        if _sum_then_scale():
-            self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), seg))
+        if self.transport == 'bf16':
+            buf = seg.to(torch.bfloat16)
+            self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), seg, buf))
+        elif _sum_then_scale():
+            self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), seg, None))
         else:
-            self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True), None))
+            self.works.append((dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True), None, None))
 
     def finish(self):
         if single():
             return
         for i in range(len(self.ranges)):          # anything a trigger missed (e.g. unused branches)
             self.bucket_done(i, force=True)
-        for w, seg in self.works:
+        for w, seg, buf in self.works:
             w.wait()
+            if buf is not None:
+                seg.copy_(buf)
             if seg is not None:
                 seg.div_(world_size())
         self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)

@@ -33,6 +33,16 @@ def _worker(rank, world, port, q):
         g = torch.full((1000,), float(rank + 1))
         parallel.allreduce_mean_(g, bucket_elems=300)
         assert torch.allclose(g, torch.full((1000,), (1 + world) * world / 2 / world))
+        # bucketed reducer, fp32 and bf16 transport: the mean on every rank, identical across ranks
+        for transport, tol in (('fp32', 0.0), ('bf16', 2 ** -7)):
+            flat = torch.linspace(-3.0, 5.0, 1000) * (rank + 1)
+            want = torch.linspace(-3.0, 5.0, 1000) * (1 + world) / 2
+            red = parallel.GradReducer(flat, [(600, 1000), (0, 600)], need=[1, 2], transport=transport)
+            red.bucket_done(0); red.bucket_done(1); red.bucket_done(1)           # the second bucket needs two trigger calls
+            red.finish()
+            assert torch.allclose(flat, want, rtol=tol, atol=1e-6 + tol * 0.01), (transport, float((flat - want).abs().max()))
+            both = parallel.all_gather_cat(flat[None])
+            assert torch.equal(both[0], both[1]), transport
         # replicated queue: the oracle's enqueue under 2 ranks keeps queue/ptr/count identical everywhere
         rec = om.MoCoV2('flow', 128, K=16, max_iters=100)
         with torch.no_grad():
