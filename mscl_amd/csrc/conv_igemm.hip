@@ -139,28 +139,52 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
     }
   }
 
-  // ---- epilogue: (+bias) (+addend) (relu) -> bf16, 4 consecutive channels per lane ----
-#pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    if (orow[i] < 0) continue;
-#pragma unroll
-    for (int j = 0; j < JN; ++j) {
-      const int n = n0 + wn0 + j * 16 + fq * 4;
-      if (n >= g.Cr) continue;
-      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      const long o = orow[i] + n;
+  // ---- epilogue: (+bias) (+addend) (relu) -> bf16 ----
+  // A lane holds 4 consecutive channels of one position per 16-channel tile: 8 bytes.  Stores of 8 bytes per lane are issue-bound
+  // on write-heavy layers (1-tap convs that widen the map, e.g. 64 -> 256 on a 205-MB map: 2.3 TB/s against 4.4-5.0 TB/s for the
+  // read-heavy direction), so two channel tiles are paired: v_permlane16_swap exchanges the quads between lane rows fq and fq ^ 1
+  // (same position, neighbouring channel quads), after which an even row holds 8 consecutive channels of tile j and an odd row
+  // 8 consecutive channels of tile j + 1 -- one 16-byte store per lane instead of two 8-byte ones, same bytes, same values.
+  auto quad = [&](int i, int j, bool ok) -> uint2 {
+    const int n = n0 + wn0 + j * 16 + fq * 4;
+    float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+    if (ok && n < g.Cr) {
       if (bias != nullptr) {
         const float4 bv = *reinterpret_cast<const float4*>(bias + n);
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
       }
       if (addend != nullptr) {
-        const uint2 av = *reinterpret_cast<const uint2*>(addend + o);
+        const uint2 av = *reinterpret_cast<const uint2*>(addend + orow[i] + n);
         v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
         v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
       }
-      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(out + o) = pv;
+    }
+    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
+    return pv;
+  };
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const bool rowok = orow[i] >= 0;
+    if constexpr (JN % 2 == 0) {
+#pragma unroll
+      for (int j = 0; j < JN; j += 2) {
+        const uint2 p0 = quad(i, j, rowok), p1 = quad(i, j + 1, rowok);
+        // every lane takes part in the swaps (EXEC full here: no divergent branch encloses them)
+        const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+        // even rows: {own tile-j quad, next row's tile-j quad}; odd rows: {previous row's tile-(j+1) quad, own tile-(j+1) quad}
+        const uint4 w = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        const int n = n0 + wn0 + (j + (fq & 1)) * 16 + (fq & 2) * 4;
+        if (rowok && n < g.Cr) *reinterpret_cast<uint4*>(out + orow[i] + n) = w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int n = n0 + wn0 + j * 16 + fq * 4;
+        const uint2 pv = quad(i, j, rowok);
+        if (rowok && n < g.Cr) *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
+      }
     }
   }
 }
