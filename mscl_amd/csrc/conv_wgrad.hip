@@ -268,21 +268,22 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 }
 
 // column sums, deterministic form: block x plain-stores the sums of its row share into part[x][C]; colsum_finish adds them in order
-__global__ __launch_bounds__(256) void colsum_det_kernel(const bf16_t* __restrict__ xx, float* __restrict__ part, long rows, int C) {
+__global__ __launch_bounds__(256) void colsum_det_kernel(const bf16_t* __restrict__ xx, float* __restrict__ part, long rows, int C, int ldc) {
+  xx += blockIdx.y * C; part += blockIdx.y * C;
   const int G = C / 8;
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const long per = (rows + gridDim.x - 1) / gridDim.x;
   const long rbeg = (long)blockIdx.x * per, rend = rbeg + per < rows ? rbeg + per : rows;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long r = rbeg + tr; r < rend; r += RP) {
-    float f[8]; unpack8(*reinterpret_cast<const uint4*>(xx + r * C + tg * 8), f);
+    float f[8]; unpack8(*reinterpret_cast<const uint4*>(xx + r * ldc + tg * 8), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] += f[i];
   }
   __shared__ float red[4 * 512];
   block_channel_sum(s, red, G, C, 1, 0);
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) part[(long)blockIdx.x * C + i] = (red[i] + red[C + i]) + (red[2 * C + i] + red[3 * C + i]);
+  for (int i = threadIdx.x; i < C; i += 256) part[(long)blockIdx.x * ldc + i] = (red[i] + red[C + i]) + (red[2 * C + i] + red[3 * C + i]);
 }
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 }
 
 // column sums of a bf16 (rows, C) matrix into fp32 out[C] (+=): conv bias gradient
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ xx, float* __restrict__ out, long rows, int C) {
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ xx, float* __restrict__ out, long rows, int C, int ldc) {
+  xx += blockIdx.y * C; out += blockIdx.y * C;      // matrices wider than 512 columns: 512-column chunks along blockIdx.y (ldc = row pitch)
   const int G = C / 8;
   const int tg = threadIdx.x % G;                 // requires 256 % G == 0 (C/8 power of two <= 256)
   const int tr = threadIdx.x / G, RP = 256 / G;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const long r = r0 + u * stride;
-      v[u] = *reinterpret_cast<const uint4*>(xx + (r < rows ? r : r0) * C + tg * 8);
+      v[u] = *reinterpret_cast<const uint4*>(xx + (r < rows ? r : r0) * ldc + tg * 8);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -419,19 +421,20 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   else if (d->K == 16 || d->K == 8) e = wide ? launch_w<16, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<16, 64>(g, x, dy, dw, st, dws, dfl);
   else return MSCL_E_SHAPE;
   if (e) return e;
-  if (dbias && d->K <= 512) {
+  if (dbias) {
+    const int Kc = d->K > 512 ? 512 : d->K, kchunks = d->K / Kc;        // K/8 is a power of two (checked above)
     if (mscl_det()) {
       if (ws == nullptr || ws_floats < (long)MSCL_STAT_SLOTS * d->K) return MSCL_E_ARG;
       float* part = ws + (ws_floats - (long)MSCL_STAT_SLOTS * d->K);
-      hipLaunchKernelGGL(colsum_det_kernel, dim3(MSCL_STAT_SLOTS), dim3(256), 0, st, dy, part, M, d->K);
+      hipLaunchKernelGGL(colsum_det_kernel, dim3(MSCL_STAT_SLOTS, kchunks), dim3(256), 0, st, dy, part, M, Kc, d->K);
       MSCL_LAUNCH_CHECK();
       hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->K + 255) / 256), dim3(256), 0, st, (const float*)part, dbias, MSCL_STAT_SLOTS, d->K);
       MSCL_LAUNCH_CHECK();
       return 0;
     }
-    const int RPc = 256 / (d->K / 8);
+    const int RPc = 256 / (Kc / 8);
     long blocks = (M + RPc * 4 - 1) / (RPc * 4); if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, dbias, M, d->K);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks, kchunks), dim3(256), 0, st, dy, dbias, M, Kc, d->K);
     MSCL_LAUNCH_CHECK();
   }
   return 0;

@@ -52,6 +52,15 @@ CONV_CASES = [
     ('big_m_tail', 3, 5, 13, 11, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('l1_plane_56', 1, 3, 56, 56, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # real layer-1 plane: 13 halo tiles, last partial
     ('lat_bias_long', 2, 4, 48, 48, 16, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # 18 432 rows: the bias-gradient column sum takes a full and a partial trip
+    # Bottleneck trunks (mscl_r50): 1x1x1 widening / narrowing, inflated 3x1x1, 1x3x3 with the spatial stride, 8-channel r2d_50 layers
+    ('r50_64_256', 2, 3, 12, 12, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_1024_256_311', 1, 4, 6, 6, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('r50_512_2048', 1, 2, 5, 5, 512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50_128_128_133_s2', 2, 3, 14, 14, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ('r50_ds_256_512_s2', 2, 3, 14, 14, 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ('r2d50_8_8_133', 2, 3, 14, 14, 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r2d50_8_32', 2, 3, 14, 14, 8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r2d50_32_8', 2, 3, 14, 14, 32, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
 ]
 
 
@@ -568,3 +577,103 @@ def test_color_aug_and_blur_match_oracle(dev):
     with pytest.raises(lib.MsclError):
         K.color_aug(xs, torch.zeros(2, K.AUG_PARAMS, device=dev), 0)
     assert K.color_aug(torch.empty((0, 3, 2, 8, 8), device=dev), torch.zeros(0, K.AUG_PARAMS, device=dev), 3).shape[0] == 0
+
+
+def test_maxpool_hw(dev):
+    """(1,3,3) / (1,2,2) / (0,1,1) max-pool, forward and gather backward, against torch on the same bf16 values -- bit for bit,
+    including the tie rule (first tap in scan order): a ReLU output with whole windows at zero."""
+    from mscl_amd import kernels as K_
+    for shape in ((2, 3, 14, 14, 64), (1, 2, 9, 11, 8), (2, 2, 7, 7, 16)):
+        x = F.relu(bf(rnd(shape, 11)).float() - 0.5)          # ~70 % exact zeros
+        x = bf(x)
+        out, win = K_.maxpool_hw_fwd(x.to(dev))
+        xr = x.float().permute(0, 4, 1, 2, 3).requires_grad_(True)
+        yr = F.max_pool3d(xr, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        assert torch.equal(out.float().cpu(), yr.detach().permute(0, 2, 3, 4, 1))
+        dy = bf(rnd(tuple(out.shape), 12))
+        yr.backward(dy.float().permute(0, 4, 1, 2, 3))
+        dx = K_.maxpool_hw_bwd(dy.to(dev), win, tuple(x.shape))
+        close(dx, xr.grad.permute(0, 2, 3, 4, 1), BF16_TOL, 'maxpool bwd')    # sums of up to 4 bf16 gradients, rounded once
+
+
+def test_statistics_groups_equal_separate_calls(dev):
+    """mscl_conv3d_fwd_groups / mscl_bn_act_fwd_groups / _bwd_groups on a batch of two calls' worth of samples == the two calls made
+    one after the other (per-call batch statistics, running statistics updated in call order, dgamma / dbeta summed)."""
+    import ctypes
+    from mscl_amd import kernels as K_, lib
+    N, T, H, W, C, Kc = 4, 3, 10, 10, 16, 32
+    x = bf(rnd((N, T, H, W, C), 21)); w = bf(rnd((Kc, 1, 3, 3, C), 22, scale=0.1))
+    xg, wg = x.to(dev), w.to(dev)
+    gamma, beta = (rnd((Kc,), 23) * 0.2 + 1).to(dev), (rnd((Kc,), 24) * 0.1).to(dev)
+    dout = bf(rnd((N, T, H, W, Kc), 25)).to(dev)
+
+    def bnp(stats, rm, rv, nbt, save, groups):
+        sp, sv = stats.data_ptr(), save.data_ptr()
+        return lib.BnParams(sp, sp + 4 * Kc, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(),
+                            sv, sv + 4 * groups * Kc)
+
+    def run(xs, groups, rm, rv, nbt, dgamma, dbeta, dos):
+        d = K_.conv_desc(tuple(xs.shape), Kc, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        stats = torch.zeros((groups, K_.STAT_SLOTS, 2, Kc), device=dev)
+        y = torch.empty(K_.out_shape(d), dtype=torch.bfloat16, device=dev)
+        out = torch.empty_like(y)
+        save = torch.empty((2, groups, Kc), device=dev)
+        lib.call('mscl_conv3d_fwd_groups', ctypes.byref(d), xs.data_ptr(), wg.data_ptr(), y.data_ptr(), None, None, 0,
+                 stats.data_ptr(), stats.data_ptr() + 4 * Kc, groups, None, 0, lib.stream_ptr())
+        bp = bnp(stats, rm, rv, nbt, save, groups)
+        rows = y.numel() // Kc
+        lib.call('mscl_bn_act_fwd_groups', y.data_ptr(), ctypes.byref(bp), None, None, out.data_ptr(), rows, Kc, 1e-5, 0.1, 1, groups,
+                 lib.stream_ptr())
+        scratch = torch.zeros((groups * K_.STAT_SLOTS * 4 * Kc,), device=dev)
+        dy, _ = K_.bn_act_bwd(dos, out, y, gamma, save[0], save[1], dgamma, dbeta, 1, scratch, groups=groups)
+        return out, dy
+    mk = lambda: (torch.zeros(Kc, device=dev), torch.ones(Kc, device=dev), torch.zeros((), dtype=torch.long, device=dev),
+                  torch.zeros(Kc, device=dev), torch.zeros(Kc, device=dev))
+    rm2, rv2, nb2, dg2, db2 = mk()
+    out2, dy2 = run(xg, 2, rm2, rv2, nb2, dg2, db2, dout)
+    rm1, rv1, nb1, dg1, db1 = mk()
+    oa, da = run(xg[:2].contiguous(), 1, rm1, rv1, nb1, dg1, db1, dout[:2].contiguous())
+    ob, dbb = run(xg[2:].contiguous(), 1, rm1, rv1, nb1, dg1, db1, dout[2:].contiguous())
+    close(out2, torch.cat([oa, ob]), 2.0 ** -8, 'grouped BN forward')
+    close(dy2, torch.cat([da, dbb]), 2.0 ** -7, 'grouped BN backward')
+    assert int(nb2) == int(nb1) == 2
+    close(rm2, rm1, 1e-5, 'running mean'); close(rv2, rv1, 1e-5, 'running var')
+    close(dg2, dg1, 1e-4, 'dgamma'); close(db2, db1, 1e-4, 'dbeta')
+
+
+def test_bn_wide_maps_and_fixed_order_statistics(dev):
+    """BatchNorm backward on maps of 1024 / 2048 channels (512-channel chunks) against autograd, and mscl_bn_stats (the
+    deterministic mode's statistics pass) against fp32 sums, twice: bit-identical."""
+    from mscl_amd import kernels as K_, lib
+    for C in (1024, 2048):
+        rows = 96
+        y = bf(rnd((rows, C), 31)); dout = bf(rnd((rows, C), 32))
+        gamma = (rnd((C,), 33) * 0.2 + 1)
+        yr = y.float().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = torch.zeros(C, requires_grad=True)
+        o = F.relu(F.batch_norm(yr, None, None, gr, br, training=True, eps=1e-5))
+        o.backward(dout.float())
+        mean = y.float().mean(0); inv = 1.0 / torch.sqrt(y.float().var(0, unbiased=False) + 1e-5)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        scratch = torch.zeros((K_.STAT_SLOTS * 4 * C,), device=dev)
+        dy, _ = K_.bn_act_bwd(dout.to(dev), bf(o.detach()).to(dev), y.to(dev), gamma.to(dev), mean.to(dev), inv.to(dev), dg, db, 1, scratch)
+        close(dy, yr.grad, 2.0 ** -6, f'bn bwd C={C}')
+        close(dg, gr.grad, 2e-3, 'dgamma'); close(db, br.grad, 2e-3, 'dbeta')
+        st = [torch.zeros((K_.STAT_SLOTS, 2, C), device=dev) for _ in range(2)]
+        for t in st:
+            lib.call('mscl_bn_stats', y.to(dev).data_ptr(), t.data_ptr(), t.data_ptr() + 4 * C, rows, C, 1, lib.stream_ptr())
+        assert torch.equal(st[0], st[1])
+        close(st[0][:, 0].sum(0), y.float().sum(0), 1e-5, 'stats sum'); close(st[0][:, 1].sum(0), (y.float() ** 2).sum(0), 1e-5, 'stats sumsq')
+
+
+def test_linear_more_than_32_rows(dev):
+    """the LMCL flow transform of mscl_r50 and the batched flow projection head: 64 rows = two launches of the 32-row kernels"""
+    from mscl_amd import kernels as K_
+    rows, i, o = 64, 256, 128
+    x = rnd((rows, i), 41).requires_grad_(True); w = (rnd((o, i), 42) / i ** 0.5).requires_grad_(True); b = rnd((o,), 43).requires_grad_(True)
+    y = F.linear(x, w, b)
+    yd = K_.linear_fwd(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev), False)
+    close(yd, y, F32_TOL, 'linear fwd 64 rows')
+    dy = rnd((rows, o), 44); y.backward(dy)
+    dw = torch.zeros(o, i, device=dev); db = torch.zeros(o, device=dev)
+    dx = K_.linear_bwd(x.detach().to(dev), w.detach().to(dev), yd, dy.to(dev), dw, db, False)
+    close(dx, x.grad, F32_TOL, 'dx'); close(dw, w.grad, F32_TOL, 'dw'); close(db, b.grad, F32_TOL, 'db')
