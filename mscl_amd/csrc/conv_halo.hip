@@ -740,7 +740,10 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
     const size_t lds = (size_t)2 * 256 * 128 + 2 * 64 * 128;          // 80 KB: two blocks per CU
     hipLaunchKernelGGL((conv_halo64_kernel<4, 128, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
                        addend, ssum, ssq, bn);
-  } else if (w8 && w8[0] == '8') {
+  } else if (!(w8 && w8[0] == '4')) {
+    // default since round 2: two waves per SIMD.  Measured inside the three-stream step, three alternating pairs in one call:
+    // 927 / 928 / 931 vs 920 / 920 / 923 clip-pairs/s, forward launch 104.2 vs 109.5 us, input gradient 102 vs 109 us
+    // (round 1 measured no gain: the other chains of the step were longer then).  MSCL_HALO_WAVES=4 selects one wave per SIMD.
     const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
     hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, st, g, src, w, out,
                        addend, ssum, ssq, bn);
