@@ -648,8 +648,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % (8 * WAVES_M * WAVES_N) == 0 && BN % (8 * WAVES_M * WAVES_N) == 0; }
 static bool fast_disabled() { const char* e = getenv("MSCL_IGEMM_FAST"); return e && e[0] == '0'; }
-// MSCL_IGEMM_WIDE: 0 = no 8-wave tiles, 1 (default) = where they measured faster, 2 = wherever they apply (A/B)
-static int wide_level() { const char* e = getenv("MSCL_IGEMM_WIDE"); return e ? atoi(e) : 1; }
+// MSCL_IGEMM_WIDE: 0 = no 8-wave tiles, 1 = only on the 256-channel maps of a few thousand positions (the round-1 choice, from
+// kernels timed alone), 2 (default) = wherever they apply: 256 x 128 on the 128-channel maps too.  Measured inside the step, three
+// alternating pairs in one call: 922 / 925 / 927 vs 915 / 915 / 914 clip-pairs/s.
+static int wide_level() { const char* e = getenv("MSCL_IGEMM_WIDE"); return e ? atoi(e) : 2; }
 // ring depth of the uniform-tap kernel for a grid of `nblk` blocks with `stage_bytes` of LDS per stage
 // (MSCL_FAST_STAGES = 2 / 3 / 4 forces it: tuning aid, read per launch)
 static int fast_stages(long nblk, int stage_bytes) {
