@@ -46,6 +46,11 @@ LOG_KEYS_NO_AUG_MX = tuple(k for k in LOG_KEYS if not k.endswith('_mx_aug') and 
 KEY_NO_HALO = os.environ.get('MSCL_KEY_NO_HALO', '0') == '1'
 
 
+# the RGB query chain (main stream, the step's critical chain) is issued before the side chains: 932.4-933.0 vs 928.8-931.2
+# clip-pairs/s from the captured graph in three alternating pairs (no difference for eager launches); =0 issues it last
+ISSUE_QUERY_FIRST = os.environ.get('MSCL_ISSUE_QUERY_FIRST', '1') == '1'
+
+
 def momentum_at(iters, max_iters, m_base):
     """ref: moco.py:413-415."""
     factor = min(iters / max_iters, 1)
@@ -989,6 +994,13 @@ class MSCLWithAug(nn.Module):
                 for tns in (im_k_x, fk_b, fk_a, flip_k0, flip_k1, flip_k2):
                     if tns is not None:
                         tns.record_stream(side_k if tns is im_k_x or tns is flip_k0 else s_fk)
+        # -- RGB query branch (the step's critical chain, on the main stream)
+        def issue_query():
+            x_q = aug.pack_rgb(aug.color(im_q, color_q, 0), flip_q)
+            return rec.encode_q(x_q, levels=(ids[0],))       # LMCL reads one pyramid level (local_cl_head.py:59)
+        q_first = ISSUE_QUERY_FIRST
+        if q_first:
+            q_rgb, maps_rgb = issue_query()
         with torch.cuda.stream(s_fq):
             if self.flow_batch:
                 Bq = flow_q.shape[0]
@@ -1018,9 +1030,8 @@ class MSCLWithAug(nn.Module):
             else:
                 x_k = aug.pack_rgb(aug.color(im_k, color_k, 1), flip_k)
             k_rgb = self._encode_key(0, rec, x_k, sc[0:1])
-        # -- RGB query branch
-        x_q = aug.pack_rgb(aug.color(im_q, color_q, 0), flip_q)
-        q_rgb, maps_rgb = rec.encode_q(x_q, levels=(ids[0],))       # LMCL reads one pyramid level (local_cl_head.py:59)
+        if not q_first:
+            q_rgb, maps_rgb = issue_query()
         if side_k is not main:
             main.wait_stream(side_k)
             k_rgb.record_stream(main)
