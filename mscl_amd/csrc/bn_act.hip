@@ -129,7 +129,13 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
     res_is_bn = 1;
   }
   const long total = rows * (C / 8);
-  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  // Grid cap 512 (two blocks per CU), was 2048: every block first rebuilds the per-channel scale / shift from the 16 statistics
+  // slots (bn_prepare), so blocks are not free, and a pass that fills every wave slot of the chip shuts the other chains of the
+  // step out.  Measured (caps 512 / 512 / 512 for forward / reduce / apply against 2048 / 1024 / 2048, alternating in one call):
+  // step 951.6 vs 926.5-928.8 clip-pairs/s, R3D-18 trunk alone 1750 vs 1701 clips/s, SlowOnly-50 trunk at 8 x 32 x 224^2 424.7 vs
+  // 400.4 clips/s; 256 and 384 measured like 512 on the step, 768-1024 in between.  MSCL_BN_FWD_CAP / _RED_CAP / _APPLY_CAP override.
+  static const long fwd_cap = [] { const char* e = getenv("MSCL_BN_FWD_CAP"); return e && atol(e) > 0 ? atol(e) : 512L; }();
+  long blocks = (total + 255) / 256; if (blocks > fwd_cap) blocks = fwd_cap;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * groups * C * sizeof(float),
                      (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu, groups);
   MSCL_LAUNCH_CHECK();
@@ -404,7 +410,8 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   const int RP = 256 / (Cc / 8);
   const long rows_g = rows / groups;
   long blocks = (rows_g + RP * 8 - 1) / (RP * 8);
-  const long cap = 1024 / (chunks * groups);                       // wider grids measured slower (more atomics)
+  static const long red_cap = [] { const char* e = getenv("MSCL_BN_RED_CAP"); return e && atol(e) > 0 ? atol(e) : 512L; }();    // see mscl_bn_act_fwd_groups
+  const long cap = red_cap / (chunks * groups);                    // wider grids measured slower (more atomics)
   if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
   const int det = mscl_det() ? 1 : 0;
   if (det && blocks > MSCL_STAT_SLOTS) blocks = MSCL_STAT_SLOTS;
@@ -420,7 +427,8 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   }
   const long total = rows * (Ca / 8);
-  long b2 = (total + 255) / 256; if (b2 > 2048 / achunks) b2 = 2048 / achunks; if (b2 < 1) b2 = 1;
+  static const long app_cap = [] { const char* e = getenv("MSCL_BN_APPLY_CAP"); return e && atol(e) > 0 ? atol(e) : 512L; }();  // see mscl_bn_act_fwd_groups
+  long b2 = (total + 255) / 256; if (b2 > app_cap / achunks) b2 = app_cap / achunks; if (b2 < 1) b2 = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2, achunks), dim3(256), (size_t)10 * groups * Ca * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
                      want_identity_dres, (long)rows, Ca, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups, C);

@@ -677,8 +677,11 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   if (ws != nullptr && blocks <= 256 && nk >= 32) {           // too few tiles for 256 CUs and a long K loop
     // measured on the 6272- and 784-position layers (tools/sweep_ksplit.sh): one round of <= 2 blocks per CU beats more
     // splits (98 tiles x 6 = 588 blocks ran 52 us, x 4 = 392 blocks 44 us), and a block wants >= 12 K steps
-    long want = (WAVES_M * WAVES_N == 8 ? 256 : 448) / blocks;      // wide tiles: one 96-KB block per CU
-    if (want > nk / (WAVES_M * WAVES_N == 8 ? 6 : 12)) want = nk / (WAVES_M * WAVES_N == 8 ? 6 : 12);
+    static const long ks_target = [] { const char* e = getenv("MSCL_KSPLIT_TARGET"); return e && atol(e) > 0 ? atol(e) : 448L; }();    // tuning aids
+    static const long ks_steps = [] { const char* e = getenv("MSCL_KSPLIT_MINSTEPS"); return e && atol(e) > 0 ? atol(e) : 12L; }();
+    long want = (WAVES_M * WAVES_N == 8 ? ks_target * 256 / 448 : ks_target) / blocks;      // wide tiles: one 96-KB block per CU
+    const long minsteps = WAVES_M * WAVES_N == 8 ? (ks_steps + 1) / 2 : ks_steps;
+    if (want > nk / minsteps) want = nk / minsteps;
     if (want > 16) want = 16;
     if (want * out_elems > ws_floats) want = ws_floats / out_elems;
     if (want > 1) g.ksplit = (int)want;

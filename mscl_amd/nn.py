@@ -226,7 +226,7 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
 # the convs whose backward runs on a stream registered here launch their wgrad kernel on the paired side stream:
 # the dgrad / BN-backward chain no longer waits for them.  {stream handle: side torch.cuda.Stream}
 PAIR_STEM = os.environ.get('MSCL_PAIR_STEM', '1') != '0'     # RGB stem on W-paired input (kernels.pair_w): K 1176 -> 672
-MASK_FROM_Y_MIN = 1 << 24    # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
+MASK_FROM_Y_MIN = int(os.environ.get('MSCL_MASK_FROM_Y_MIN', 1 << 24))    # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
 WGRAD_SIDE = {}
 
 
