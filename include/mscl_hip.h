@@ -31,9 +31,15 @@ typedef struct {
 
 /* BatchNorm statistics buffers (the `ssum` / `ssq` outputs of the convolution entry points and the `sum` / `sumsq` inputs
  * of mscl_bn_params) are MSCL_STAT_SLOTS copies of the [2][C] sums, laid out [slot][2][C] fp32 and zeroed by the caller:
- * the pointers address slot 0, producers add into slot (block index mod slots), consumers add the slots up.  (Thousands
- * of blocks adding into one 512-byte row run an order of magnitude below the float-atomic rate.) */
+ * the pointers address slot 0, producers add into a slot chosen by their block index, consumers add the slots up.  (Thousands
+ * of blocks adding into one 512-byte row run an order of magnitude below the float-atomic rate.)  Outside deterministic mode
+ * only the first MSCL_STAT_ACTIVE (4) slots are used -- every block of a consuming pass re-reads the slots of every channel, and
+ * that cost more than the contention more slots avoid; in deterministic mode each of up to MSCL_STAT_SLOTS blocks owns a slot.
+ * A caller that fills a statistics buffer itself puts its sums into the first MSCL_STAT_ACTIVE slots. */
+#define MSCL_STAT_ACTIVE 4
+#ifndef MSCL_STAT_SLOTS
 #define MSCL_STAT_SLOTS 16
+#endif
 
 int mscl_abi_version(void);
 

@@ -12,7 +12,7 @@ struct BnDev {
 // `groups` statistics groups (see mscl_conv3d_fwd_groups): scale / shift are [groups][C]; the running statistics take the
 // groups' updates one after the other, in group order -- what the reference's consecutive module calls do
 __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* shift, int C, float inv_n,
-                                           float unbias, float eps, float momentum, bool writer, int groups) {
+                                           float unbias, float eps, float momentum, bool writer, int groups, int nslots) {
   if (b.sum == nullptr) {           // evaluation mode (nn.BatchNorm3d.eval()): running statistics, nothing is written
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const float sc = b.gamma[c] * rsqrtf(b.rvar[c] + eps);
@@ -25,8 +25,7 @@ __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* 
       const float* gs = b.sum + (long)gi * MSCL_STAT_SLOTS * 2 * C;
       const float* gq = b.sumsq + (long)gi * MSCL_STAT_SLOTS * 2 * C;
       float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) { s1 += gs[sl * 2 * C + c]; s2 += gq[sl * 2 * C + c]; }
+      for (int sl = 0; sl < nslots; ++sl) { s1 += gs[sl * 2 * C + c]; s2 += gq[sl * 2 * C + c]; }
       const float mean = s1 * inv_n;
       const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
       const float inv = rsqrtf(var + eps);
@@ -45,7 +44,7 @@ __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, BnDev bn,
                                                          const bf16_t* __restrict__ res, BnDev rbn, int res_is_bn,
                                                          bf16_t* __restrict__ out, long rows, int C, float eps,
-                                                         float momentum, int relu, int groups) {
+                                                         float momentum, int relu, int groups, int nslots) {
   extern __shared__ float sm[];          // scale[groups][C], shift, rscale, rshift
   const int GC = groups * C;
   float* scale = sm; float* shift = sm + GC; float* rscale = sm + 2 * GC; float* rshift = sm + 3 * GC;
@@ -53,8 +52,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
   const float inv_n = 1.f / (float)rows_g;
   const float unbias = rows_g > 1 ? (float)rows_g / (float)(rows_g - 1) : 1.f;
   const bool writer = blockIdx.x == 0;
-  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer, groups);
-  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer, groups);
+  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer, groups, nslots);
+  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer, groups, nslots);
   __syncthreads();
   const int G = C >> 3;
   const long total = rows * G;
@@ -137,7 +136,7 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
   static const long fwd_cap = [] { const char* e = getenv("MSCL_BN_FWD_CAP"); return e && atol(e) > 0 ? atol(e) : 512L; }();
   long blocks = (total + 255) / 256; if (blocks > fwd_cap) blocks = fwd_cap;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * groups * C * sizeof(float),
-                     (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu, groups);
+                     (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu, groups, mscl_stat_nslots());
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     // deterministic mode: at most MSCL_STAT_SLOTS blocks per group, block x owns slot x (plain store; the apply pass adds the
     // slots in slot order)
     if (det) scratch[blockIdx.x * 4 * ldc + vv * ldc + c] = t;
-    else atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_SLOTS) * 4 * ldc + vv * ldc + c], t);
+    else atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_ACTIVE) * 4 * ldc + vv * ldc + c], t);
   }
 }
 
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ rinv, const float* __restrict__ scratch, bf16_t* __restrict__ dy,
     bf16_t* __restrict__ dres, int identity_dres, long rows, int C, int relu,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rdgamma, float* __restrict__ rdbeta,
-    const float* __restrict__ beta, int groups, int ldc) {
+    const float* __restrict__ beta, int groups, int ldc, int nslots) {
   extern __shared__ float sm[];   // [10][groups][C]: gamma*inv, mean, inv, a, b; the residual's four; mask shift
   // maps wider than 512 channels run as 512-channel chunks along blockIdx.y (C = chunk width, ldc = the map's channel count): the
   // constants of a 2048-channel map took 80 KB of LDS = one block per CU, and the pass ran at 1.8 TB/s
@@ -321,8 +320,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       gi[k] = gamma[c] * inv[kg]; mu[k] = mean[kg]; iv[k] = inv[kg];
       msh[k] = mask_y ? beta[c] - mean[kg] * (gamma[c] * inv[kg]) : 0.f;
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < MSCL_STAT_SLOTS; ++sl) {
+      for (int sl = 0; sl < nslots; ++sl) {
         t0 += sc[sl * 4 * ldc + c]; t1 += sc[sl * 4 * ldc + ldc + c];
         if (ry) t2 += sc[sl * 4 * ldc + 2 * ldc + c];
       }
@@ -431,7 +429,8 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   long b2 = (total + 255) / 256; if (b2 > app_cap / achunks) b2 = app_cap / achunks; if (b2 < 1) b2 = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2, achunks), dim3(256), (size_t)10 * groups * Ca * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
-                     want_identity_dres, (long)rows, Ca, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups, C);
+                     want_identity_dres, (long)rows, Ca, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups, C,
+                     pre ? MSCL_STAT_ACTIVE : mscl_stat_nslots());      // (relu = 2: the fused producer is an atomic one)
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -89,12 +89,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+extern int g_mscl_deterministic;
+static inline int mscl_det_flag_value() { return g_mscl_deterministic; }
 // BatchNorm statistics are accumulated into MSCL_STAT_SLOTS copies of the [2][C] sums (slot = block index mod slots;
 // consumers add the slots up): thousands of blocks adding into ONE 512-byte row run an order of magnitude below the
 // float-atomic rate (MI355X_MICROARCH.md, Global float atomics, row 'contention').  Slot stride = 2 * C floats.
 #ifndef MSCL_STAT_SLOTS
 #define MSCL_STAT_SLOTS 16
 #endif
+// Of the MSCL_STAT_SLOTS slots a statistics buffer holds, the atomic producers spread over the first MSCL_STAT_ACTIVE only and the
+// consumers add just those: every block of a consuming pass re-reads all active slots of every channel in its prologue, which costs
+// more than the contention the extra slots avoid (measured inside the step with 1 / 2 / 4 / 8 / 16 / 32 slots: 948 / 964 / 970 / 971 /
+// 956 / 897 clip-pairs/s).  The deterministic mode writes one slot per block (plain stores) and its consumers add all
+// MSCL_STAT_SLOTS: the `nslots` argument of the consuming kernels says which.
+#ifndef MSCL_STAT_ACTIVE
+#define MSCL_STAT_ACTIVE 4
+#endif
+static inline int mscl_stat_nslots() { return mscl_det_flag_value() ? MSCL_STAT_SLOTS : MSCL_STAT_ACTIVE; }
 
 // exact floor(n / d) for 0 <= n < 2^31 via one 32x32->64 multiply (Granlund-Montgomery round-up method)
 struct FastDiv { uint32_t magic; int shift; };
@@ -108,7 +119,6 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((uint64_t)
 
 // Deterministic mode (mscl_set_deterministic, include/mscl_hip.h): every fp32 sum whose order the hardware would otherwise pick
 // (float atomics between blocks) is taken in a fixed order instead, so two runs on the same inputs are bit-identical.
-extern int g_mscl_deterministic;
 static inline bool mscl_det() { return g_mscl_deterministic != 0; }
 
 #define MSCL_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

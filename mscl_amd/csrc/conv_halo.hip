@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
     }
     __syncthreads();
     for (int i = tid; i < HC; i += 64 * NW) {
-      const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * g.stat_stride;
+      const int so = (int)(blockIdx.x % MSCL_STAT_ACTIVE) * g.stat_stride;
       atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
     }
   }
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, 
     }
     __syncthreads();
     for (int i = tid; i < HC; i += 256) {
-      const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * HC;
+      const int so = (int)(blockIdx.x % MSCL_STAT_ACTIVE) * 2 * HC;
       atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
     }
   }

@@ -131,7 +131,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc
       __syncthreads();
       for (int i = tid; i < BN; i += (int)blockDim.x) {
         if (n0 + i < g.Cr) {
-          const int so = ((g_lo + pass) * MSCL_STAT_SLOTS + (int)(blockIdx.x % MSCL_STAT_SLOTS)) * 2 * g.Cr;
+          const int so = ((g_lo + pass) * MSCL_STAT_SLOTS + (int)(blockIdx.x % MSCL_STAT_ACTIVE)) * 2 * g.Cr;
           atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
         }
       }
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
   block_channel_sum(q, red, G, C, 2, 1);
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += 256) {
-    const int so = (int)(blockIdx.x % MSCL_STAT_SLOTS) * 2 * C;
+    const int so = (int)(blockIdx.x % MSCL_STAT_ACTIVE) * 2 * C;
     atomicAdd(&ssum[so + i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
     atomicAdd(&ssq[so + i], red[4 * C + i] + red[5 * C + i] + red[6 * C + i] + red[7 * C + i]);
   }
@@ -734,7 +734,8 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
     const long rows = out_elems / g.Cr;
     const int RP = 256 / (g.Cr / 8);
     const int ngrp = g.grp_rows > 0 ? (int)(rows / g.grp_rows) : 1;
-    long fb = (rows / ngrp + RP - 1) / RP; if (fb > 2048 / ngrp) fb = 2048 / ngrp; if (fb < 1) fb = 1;
+    static const long fin_cap = [] { const char* e = getenv("MSCL_FINALIZE_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();   // tuning aid
+    long fb = (rows / ngrp + RP - 1) / RP; if (fb > fin_cap / ngrp) fb = fin_cap / ngrp; if (fb < 1) fb = 1;
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb, ngrp), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
                        rows, g.Cr, g.ksplit, (long)g.grp_rows);
     MSCL_LAUNCH_CHECK();

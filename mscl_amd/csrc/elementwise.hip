@@ -1,6 +1,9 @@
 // Layout conversion, pooling, resize-add, small dense layers (gfx950).  All HBM- or launch-bound:
 // 16-byte accesses along the channel axis, one wave per output where a reduction is needed.
 #include "common.h"
+#include <cstdlib>
+// grid cap of the elementwise passes (MSCL_EW_CAP: tuning aid)
+static long ew_cap() { static const long c = [] { const char* e = getenv("MSCL_EW_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }(); return c; }
 
 // ---------------------------------------------------------------- input packing NCTHW fp32 -> NDHWC8 bf16
 // frames [t_off, t_off+T) of a clip holding T_total frames (the base / rotated halves of the flow clip,
@@ -244,7 +247,7 @@ extern "C" int mscl_add_relu(const uint16_t* a, const uint16_t* b, const uint16_
                              void* stream) {
   if (!a || !out || n <= 0) return MSCL_E_ARG;
   if (n % 8) return MSCL_E_SHAPE;
-  long blocks = (n / 8 + 255) / 256; if (blocks > 2048) blocks = 2048;
+  long blocks = (n / 8 + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
   hipLaunchKernelGGL(add_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, (long)(n / 8), relu);
   MSCL_LAUNCH_CHECK();
   return 0;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict_
 extern "C" int mscl_relu_bwd(const uint16_t* dout, const uint16_t* out, uint16_t* din, int64_t n, void* stream) {
   if (!dout || !out || !din || n <= 0) return MSCL_E_ARG;
   if (n % 8) return MSCL_E_SHAPE;
-  long blocks = (n / 8 + 255) / 256; if (blocks > 2048) blocks = 2048;
+  long blocks = (n / 8 + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, out, din, (long)(n / 8));
   MSCL_LAUNCH_CHECK();
   return 0;
@@ -327,7 +330,7 @@ extern "C" int mscl_upsample_add(const uint16_t* src, uint16_t* dst, int N, int 
   if (C % 8) return MSCL_E_SHAPE;
   const long total = (long)N * Td * Hd * Wd * (C / 8);
   if (total >= (1L << 31) || (long)Td * Ts >= (1L << 31)) return MSCL_E_SHAPE;
-  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  long blocks = (total + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
   hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, Ts, Hs, Ws,
                      Td, Hd, Wd, C, trilinear, accumulate, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
   MSCL_LAUNCH_CHECK();
@@ -396,7 +399,7 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
   if (C % 8) return MSCL_E_SHAPE;
   const long total = (long)N * Ts * Hs * Ws * (C / 8);
   if ((long)N * Td * Hd * Wd * (C / 8) >= (1L << 31) || (long)Td * Ts >= (1L << 31)) return MSCL_E_SHAPE;
-  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  long blocks = (total + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, N, Ts, Hs, Ws,
                      Td, Hd, Wd, C, trilinear, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
   MSCL_LAUNCH_CHECK();
@@ -466,7 +469,7 @@ extern "C" int mscl_pool_bwd(const float* dout, uint16_t* dx, int outer, int inn
   if (!dout || !dx || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
   if (C % 8) return MSCL_E_SHAPE;
   const long total = (long)outer * inner * (C / 8);
-  long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+  long blocks = (total + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
   hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, dx, (long)inner, C, total, accumulate);
   MSCL_LAUNCH_CHECK();
   return 0;

@@ -38,7 +38,10 @@ def _splitk_ws(rows, chans, device):
     return torch.empty((nslab * rows * chans,), dtype=torch.float32, device=device)
 
 
-STAT_SLOTS = 16         # = MSCL_STAT_SLOTS (include/mscl_hip.h): BN statistics buffers are [slots][2][C]
+import os as _os
+STAT_SLOTS = int(_os.environ.get('MSCL_STAT_SLOTS', 16))   # = MSCL_STAT_SLOTS (include/mscl_hip.h): BN statistics buffers are [slots][2][C]
+# (the environment variable only serves A/B runs against a library built with another -DMSCL_STAT_SLOTS, selected by MSCL_LIB)
+STAT_ACTIVE = 4         # = MSCL_STAT_ACTIVE (csrc/common.h): the slots the atomic producers use and the consumers add outside deterministic mode
 
 
 def new_stats(C, device, groups=1):

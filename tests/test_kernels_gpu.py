@@ -212,13 +212,13 @@ def test_bn_act_fwd_bwd(C, relu, resmode, dev):
         rr = res.float().requires_grad_(True); m2, z2 = bn_ref(rr, rgamma, rbeta); z = z + z2
     out_ref = F.relu(z) if relu else z
     # device
-    def stats_of(t):                       # [slots][2][C], the sums split unevenly over two slots
-        from mscl_amd.kernels import STAT_SLOTS
+    def stats_of(t):                       # [slots][2][C], the sums split unevenly over two of the active slots
+        from mscl_amd.kernels import STAT_ACTIVE, STAT_SLOTS
         f = t.float().to(dev).reshape(-1, C)
         st = torch.zeros((STAT_SLOTS, 2, C), device=dev)
         h = f.shape[0] // 3
         st[0, 0], st[0, 1] = f[:h].sum(0), (f[:h] * f[:h]).sum(0)
-        st[5, 0], st[5, 1] = f[h:].sum(0), (f[h:] * f[h:]).sum(0)
+        st[STAT_ACTIVE - 1, 0], st[STAT_ACTIVE - 1, 1] = f[h:].sum(0), (f[h:] * f[h:]).sum(0)
         return st[0, 0], st[0, 1], st
     mk = lambda: dict(rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev),
                       nbt=torch.zeros((), dtype=torch.long, device=dev), sm=torch.empty(C, device=dev), si=torch.empty(C, device=dev))
