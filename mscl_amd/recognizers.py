@@ -619,7 +619,13 @@ class MSCLWithAug(nn.Module):
         # base || rotated flow query clips in ONE trunk pass with two BatchNorm statistics groups (halves the ~250 launches of the
         # two query passes, forward and backward); needs a flow neck without parameters of its own (BaseMoCo)
         self.flow_batch = os.environ.get('MSCL_FLOW_BATCH', '1') == '1'
-        self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0') == '1'     # measured 13 % slower: two MFMA-heavy kernels thrash     # MSCL_STREAMS=1: everything on the current stream
+        # RGB weight gradients (leaves of the backward chain) off the main stream -- an experiment that stays OFF: '1' = a stream of
+        # their own, 'flow' / 'key' = the flow / RGB-key stream (idle during most of the backward).  Measured in round 2 against
+        # 954-957 clip-pairs/s: 889 / 851-856 / 892.  Two MFMA-heavy kernels side by side lose more than the shorter chain gains.
+        # Also NOT safe under whole-step capture: the final loss of those runs sat 1.2 below the default's (36.0 vs 37.2 +- 0.2) --
+        # tensor.record_stream() is what keeps dy / x alive for the side stream, and the allocator does not honour it for
+        # allocations of a graph's private pool.
+        self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0')
         self._side = None
 
     # ------------------------------------------------------------------ device placement
@@ -965,8 +971,8 @@ class MSCLWithAug(nn.Module):
         main = torch.cuda.current_stream()
         multi = self.two_streams
         nn_hip.WGRAD_SIDE.clear()
-        if multi and self.wgrad_stream:
-            nn_hip.WGRAD_SIDE[main.cuda_stream] = self._side_stream(2)      # RGB backward: wgrad off the dgrad chain
+        if multi and self.wgrad_stream != '0':
+            nn_hip.WGRAD_SIDE[main.cuda_stream] = self._side_stream({'1': 2, 'flow': 0, 'key': 1}[self.wgrad_stream])   # RGB backward: wgrad off the dgrad chain
         s_fq = self._side_stream(0) if multi else main       # flow query passes (base, rotated): share BN running stats -> in order
         s_fk = s_fq                                          # flow key passes share the flow stream (a 4th stream measured 3 % slower)
         side = s_fq
