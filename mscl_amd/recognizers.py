@@ -974,12 +974,12 @@ class MSCLWithAug(nn.Module):
         if multi and self.wgrad_stream != '0':
             nn_hip.WGRAD_SIDE[main.cuda_stream] = self._side_stream({'1': 2, 'flow': 0, 'key': 1}[self.wgrad_stream])   # RGB backward: wgrad off the dgrad chain
         s_fq = self._side_stream(0) if multi else main       # flow query passes (base, rotated): share BN running stats -> in order
-        s_fk = s_fq                                          # flow key passes share the flow stream (a 4th stream measured 3 % slower)
+        s_fk = self._side_stream(2) if (multi and os.environ.get('MSCL_FLOWK_STREAM') == '1') else s_fq    # flow key passes share the flow stream (a 4th stream measured 3 % slower in round 1)
         side = s_fq
         for st in (s_fq, s_fk):
             if st is not main:
                 st.wait_stream(main)
-        side_k = self._side_stream(1) if side is not main else main
+        side_k = self._side_stream(0 if os.environ.get('MSCL_KEY_ON_FLOW') == '1' else 1) if side is not main else main   # (=1: A/B with two streams)
         if side_k is not main:
             side_k.wait_stream(main)
         if dp:
