@@ -1,5 +1,5 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/evidence; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev6; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_v3.json 2> $O/bench_v3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_v3_prof.json 2> $O/bench_v3_prof.err
