@@ -28,9 +28,16 @@ __device__ __forceinline__ void nce_partial(const float* __restrict__ queue, con
   const int cq = dim / NCE_WAVES, c0 = wave * cq;
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-#pragma unroll 8
-  for (int c = c0; c < c0 + cq; ++c) {
-    const float w = queue[(long)c * K + k];
+  // every queue load of this lane's column slice is issued before the first use (dim <= 128: at most 32 per wave): the pass
+  // is one round of blocks, so its time is the number of dependent memory round trips, not bandwidth
+  float wv[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) wv[i] = i < cq ? queue[(long)(c0 + i) * K + k] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    if (i >= cq) break;
+    const int c = c0 + i;
+    const float w = wv[i];
     const float4* qv = reinterpret_cast<const float4*>(qs + c * RT);
 #pragma unroll
     for (int r4 = 0; r4 < RT / 4; ++r4) {
@@ -118,9 +125,14 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
     float acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-#pragma unroll 8
-    for (int c = c0; c < c0 + cq; ++c) {
-      const float w = queue[(long)c * K + kk];
+    float wv[32];                               // all loads of the slice in flight at once (see nce_partial)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wv[i] = i < cq ? queue[(long)(c0 + i) * K + kk] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i >= cq) break;
+      const int c = c0 + i;
+      const float w = wv[i];
       Wt[c * NCE_WPAD + lane] = live ? w : 0.f;
       const float4* qv = reinterpret_cast<const float4*>(qs + c * RT);
 #pragma unroll
