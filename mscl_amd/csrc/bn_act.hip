@@ -134,7 +134,8 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
   // step 951.6 vs 926.5-928.8 clip-pairs/s, R3D-18 trunk alone 1750 vs 1701 clips/s, SlowOnly-50 trunk at 8 x 32 x 224^2 424.7 vs
   // 400.4 clips/s; 256 and 384 measured like 512 on the step, 768-1024 in between.  MSCL_BN_FWD_CAP / _RED_CAP / _APPLY_CAP override.
   static const long fwd_cap = [] { const char* e = getenv("MSCL_BN_FWD_CAP"); return e && atol(e) > 0 ? atol(e) : 512L; }();
-  long blocks = (total + 255) / 256; if (blocks > fwd_cap) blocks = fwd_cap;
+  static const long gpt = [] { const char* e = getenv("MSCL_BN_GPT"); return e && atol(e) > 0 ? atol(e) : 1L; }();   // granules per thread (tuning aid)
+  long blocks = (total + 256 * gpt - 1) / (256 * gpt); if (blocks > fwd_cap) blocks = fwd_cap;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * groups * C * sizeof(float),
                      (hipStream_t)stream, y, b, residual, rb, res_is_bn, out, (long)rows, C, eps, momentum, relu, groups, mscl_stat_nslots());
   MSCL_LAUNCH_CHECK();
@@ -426,7 +427,8 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   }
   const long total = rows * (Ca / 8);
   static const long app_cap = [] { const char* e = getenv("MSCL_BN_APPLY_CAP"); return e && atol(e) > 0 ? atol(e) : 512L; }();  // see mscl_bn_act_fwd_groups
-  long b2 = (total + 255) / 256; if (b2 > app_cap / achunks) b2 = app_cap / achunks; if (b2 < 1) b2 = 1;
+  static const long gpt = [] { const char* e = getenv("MSCL_BN_GPT"); return e && atol(e) > 0 ? atol(e) : 1L; }();   // granules per thread (tuning aid)
+  long b2 = (total + 256 * gpt - 1) / (256 * gpt); if (b2 > app_cap / achunks) b2 = app_cap / achunks; if (b2 < 1) b2 = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2, achunks), dim3(256), (size_t)10 * groups * Ca * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
                      want_identity_dres, (long)rows, Ca, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups, C,
