@@ -1,6 +1,8 @@
 // Parameter-sized elementwise passes over the flat fp32 parameter arena (gfx950, HBM-bound):
 // key-encoder EMA, gradient sum of squares, clip + SGD-momentum, bf16 shadow refresh.
 #include "common.h"
+#include <cstdlib>
+static long ema_cap() { static const long c = [] { const char* e = getenv("MSCL_EMA_CAP"); return e && atol(e) > 0 ? atol(e) : 4096L; }(); return c; }   // tuning aid
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq,
                                                   bf16_t* __restrict__ pkb, long n, float m_val, const float* __restrict__ m_dev) {
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const 
 extern "C" int mscl_ema_update(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, float m, void* stream) {
   if (!pk || !pq || n <= 0) return MSCL_E_ARG;
   if (((uintptr_t)pk | (uintptr_t)pq) & 15 || ((uintptr_t)pk_bf16 & 7)) return MSCL_E_SHAPE;
-  long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  long blocks = (n / 4 + 255) / 256; if (blocks > ema_cap()) blocks = ema_cap(); if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, pq, pk_bf16, (long)n, m,
                      (const float*)nullptr);
   MSCL_LAUNCH_CHECK();
@@ -31,7 +33,7 @@ extern "C" int mscl_ema_update(float* pk, const float* pq, uint16_t* pk_bf16, in
 extern "C" int mscl_ema_update_dev(float* pk, const float* pq, uint16_t* pk_bf16, int64_t n, const float* m_dev, void* stream) {
   if (!pk || !pq || !m_dev || n <= 0) return MSCL_E_ARG;
   if (((uintptr_t)pk | (uintptr_t)pq) & 15 || ((uintptr_t)pk_bf16 & 7)) return MSCL_E_SHAPE;
-  long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  long blocks = (n / 4 + 255) / 256; if (blocks > ema_cap()) blocks = ema_cap(); if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, pq, pk_bf16, (long)n, 0.f, m_dev);
   MSCL_LAUNCH_CHECK();
   return 0;
