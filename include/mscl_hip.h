@@ -276,6 +276,16 @@ int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* 
  * partial sums, at least ceil(K / 128) * roundup(min(R, 32), 8) * dim floats.
  * Any R: rows beyond 32 run as further 32-row tiles over the same snapshot (3 row groups of a per-GPU batch of 32 = 96
  * rows); part then holds [tile][blk][rows of the tile], R * nblk * 3 floats in all. */
+/* The *_virt forms read the snapshot the reference takes AFTER `_dequeue_and_enqueue(new_keys)` (moco.py:423-440: every age +1,
+ * the n_new columns from *queue_ptr on replaced by new_keys (n_new x dim fp32) at age 1) from the buffers as they stand BEFORE
+ * that write -- the same arithmetic on the same values, so the pass on the later snapshot (the rotated-flow and rf terms of
+ * mscl.py:255-261 read the flow queue after the base pass's enqueue) can run beside the pass on the earlier one.  new_keys = NULL:
+ * the plain forms. */
+int mscl_nce_fwd_virt(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
+                      int R, int dim, int K, float inv_T, const float* new_keys, int n_new, const int64_t* queue_ptr, void* stream);
+int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
+                      float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T,
+                      const float* new_keys, int n_new, const int64_t* queue_ptr, void* stream);
 int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit,
                  float* part, int R, int dim, int K, float inv_T, void* stream);
 int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank,

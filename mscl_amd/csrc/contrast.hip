@@ -8,6 +8,23 @@
 #define NCE_COLS 64           // queue columns per block; 4 waves split the feature dimension
 #define NCE_WAVES 4
 
+// "Virtual enqueue": the snapshot the reference takes AFTER _dequeue_and_enqueue(keys) (moco.py:423-440) -- every age +1, the
+// n_new columns from *ptr on replaced by the new keys at age 1 -- read straight from the queue as it stands BEFORE that write
+// plus the keys (keys: n_new x dim fp32 row-major, ptr: the device queue_ptr).  Same arithmetic on the same values as after the
+// real write, so the pass that needs the later snapshot (App. E-3: the rotated-flow and rf terms) no longer waits for the pass
+// on the earlier one.  keys == NULL: the queue as it stands.
+struct NceVirt { const float* keys; const int64_t* ptr; int n_new; };
+__device__ __forceinline__ bool nce_in_new(const NceVirt& v, int k, int& j) {
+  if (v.keys == nullptr) return false;
+  j = k - (int)*v.ptr;
+  return j >= 0 && j < v.n_new;
+}
+__device__ __forceinline__ float nce_age(const NceVirt& v, const int64_t* count, int k) {
+  int j;
+  if (v.keys == nullptr) return (float)count[k];
+  return nce_in_new(v, k, j) ? 1.f : (float)(count[k] + 1);
+}
+
 // Each block owns 64 queue columns; wave w accumulates channels [w*dim/4, (w+1)*dim/4) of the dot products
 // (4x the loads in flight of a column-per-thread loop: the pass is latency-bound otherwise), partials are
 // summed through LDS.  lg[r] = logit of (row r, this lane's column) is returned to wave 0's lanes.
@@ -24,15 +41,17 @@ __device__ __forceinline__ void nce_stage_q(const float* __restrict__ q, float* 
 
 template <int RT>
 __device__ __forceinline__ void nce_partial(const float* __restrict__ queue, const float* __restrict__ qs, int k, int dim,
-                                            int K, int wave, float* acc) {
+                                            int K, int wave, float* acc, const NceVirt& vt) {
   const int cq = dim / NCE_WAVES, c0 = wave * cq;
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
   // every queue load of this lane's column slice is issued before the first use (dim <= 128: at most 32 per wave): the pass
   // is one round of blocks, so its time is the number of dependent memory round trips, not bandwidth
   float wv[32];
+  int jn = 0;
+  const bool isnew = nce_in_new(vt, k, jn);
 #pragma unroll
-  for (int i = 0; i < 32; ++i) wv[i] = i < cq ? queue[(long)(c0 + i) * K + k] : 0.f;
+  for (int i = 0; i < 32; ++i) wv[i] = i < cq ? (isnew ? vt.keys[(long)jn * dim + c0 + i] : queue[(long)(c0 + i) * K + k]) : 0.f;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
     if (i >= cq) break;
@@ -52,7 +71,7 @@ __device__ __forceinline__ void nce_partial(const float* __restrict__ queue, con
 template <int RT>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
                                                       const float* __restrict__ q, const float* __restrict__ pos,
-                                                      float* __restrict__ part, int R, int dim, int K, float inv_T) {
+                                                      float* __restrict__ part, int R, int dim, int K, float inv_T, const NceVirt vt) {
   __shared__ float red[NCE_WAVES][RT][NCE_COLS];
   __shared__ __attribute__((aligned(16))) float qs[128 * RT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -61,12 +80,12 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
   nce_stage_q<RT>(q, qs, R, dim);
   __syncthreads();
   float acc[RT];
-  nce_partial<RT>(queue, qs, live ? k : K - 1, dim, K, wave, acc);
+  nce_partial<RT>(queue, qs, live ? k : K - 1, dim, K, wave, acc, vt);
 #pragma unroll
   for (int r = 0; r < RT; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
   // wave w finishes rows r = w, w+4, ...
-  const float decay = powf(0.99999f, (float)count[live ? k : K - 1]);      // recognizers/moco.py:484
+  const float decay = powf(0.99999f, nce_age(vt, count, live ? k : K - 1));      // recognizers/moco.py:484
   for (int r = wave; r < R; r += NCE_WAVES) {
     const float dot = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
     const float l = live ? dot * decay * inv_T : -INFINITY;
@@ -105,7 +124,7 @@ template <int RT>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
                                                       const float* __restrict__ q, const float* __restrict__ lse,
                                                       const float* __restrict__ row_scale, float* __restrict__ slab,
-                                                      int R, int dim, int K, float inv_T) {
+                                                      int R, int dim, int K, float inv_T, const NceVirt vt) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // qs[dim][RT], Wt[dim][NCE_WPAD], red[4][RT][NCE_COLS] (reused as gcoef[RT][NCE_COLS])
   float* qs = sm; float* Wt = qs + dim * RT; float* red = Wt + dim * NCE_WPAD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,8 +145,10 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = 0.f;
     float wv[32];                               // all loads of the slice in flight at once (see nce_partial)
+    int jn = 0;
+    const bool isnew = nce_in_new(vt, kk, jn);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) wv[i] = i < cq ? queue[(long)(c0 + i) * K + kk] : 0.f;
+    for (int i = 0; i < 32; ++i) wv[i] = i < cq ? (isnew ? vt.keys[(long)jn * dim + c0 + i] : queue[(long)(c0 + i) * K + kk]) : 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       if (i >= cq) break;
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < RT; ++r) red[(wave * RT + r) * NCE_COLS + lane] = acc[r];
     __syncthreads();
-    const float decay = powf(0.99999f, (float)count[kk]);
+    const float decay = powf(0.99999f, nce_age(vt, count, kk));
     float coef[RT / NCE_WAVES + 1];
     int nc = 0;
     for (int r = wave; r < RT; r += NCE_WAVES, ++nc) {
@@ -203,7 +224,14 @@ __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __rest
 #define NCE_ROW_TILE 32
 extern "C" int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
                             int R, int dim, int K, float inv_T, void* stream) {
+  return mscl_nce_fwd_virt(queue, count, q, pos_logit, part, R, dim, K, inv_T, nullptr, 0, nullptr, stream);
+}
+extern "C" int mscl_nce_fwd_virt(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
+                                 int R, int dim, int K, float inv_T, const float* new_keys, int n_new, const int64_t* queue_ptr,
+                                 void* stream) {
   if (!queue || !count || !q || !pos_logit || !part || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+  if (new_keys && (!queue_ptr || n_new <= 0 || n_new > K)) return MSCL_E_ARG;
+  const NceVirt vt{new_keys, queue_ptr, new_keys ? n_new : 0};
   if (dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
@@ -212,10 +240,10 @@ extern "C" int mscl_nce_fwd(const float* queue, const int64_t* count, const floa
     const float* qt = q + (size_t)r0 * dim; const float* pt = pos_logit + r0;
     float* part_t = part + (size_t)nblk * r0 * 3;
     NCE_DISPATCH(Rt,
-      hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T),
-      hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T),
-      hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T),
-      hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T))
+      hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt))
     MSCL_LAUNCH_CHECK();
   }
   return 0;
@@ -233,7 +261,14 @@ extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float*
 }
 extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
                             float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T, void* stream) {
+  return mscl_nce_bwd_virt(queue, count, q, lse, row_scale, dq, ws, ws_floats, R, dim, K, inv_T, nullptr, 0, nullptr, stream);
+}
+extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
+                                 float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T,
+                                 const float* new_keys, int n_new, const int64_t* queue_ptr, void* stream) {
   if (!queue || !count || !q || !lse || !row_scale || !dq || !ws || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+  if (new_keys && (!queue_ptr || n_new <= 0 || n_new > K)) return MSCL_E_ARG;
+  const NceVirt vt{new_keys, queue_ptr, new_keys ? n_new : 0};
   if (dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (K + NCE_COLS * NCE_BWD_CHUNKS - 1) / (NCE_COLS * NCE_BWD_CHUNKS);
@@ -251,10 +286,10 @@ extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const floa
     const size_t lds = ((size_t)dim * rt + (size_t)dim * NCE_WPAD + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
     const float* qt = q + (size_t)r0 * dim; const float* lt = lse + r0; const float* st_ = row_scale + r0;
     NCE_DISPATCH(Rt,
-      hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
-      hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
-      hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T),
-      hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T))
+      hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_bwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_bwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_bwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T, vt))
     MSCL_LAUNCH_CHECK();
     // (deterministic mode: one block column, so every element receives ONE add of a sum taken in slab order)
     hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, mscl_det() ? 1 : 32), dim3(256), 0, st, (const float*)ws,

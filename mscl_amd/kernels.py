@@ -415,8 +415,10 @@ def l2norm_bwd(y, norms, dy):
 NCE_COLS = 64
 
 
-def nce_forward(queue, count, q, pos, inv_T):
-    """Returns (lse, loss_rows, rank) for R query rows against the aged queue snapshot."""
+def nce_forward(queue, count, q, pos, inv_T, virt=None):
+    """Returns (lse, loss_rows, rank) for R query rows against the aged queue snapshot.
+    virt = (new_keys (n, dim) fp32, queue_ptr int64[1]): the snapshot AFTER those keys' enqueue, read from the buffers as they stand
+    before it (mscl_nce_fwd_virt)."""
     R, dim = q.shape
     K = queue.shape[1]
     nblk = (K + NCE_COLS - 1) // NCE_COLS
@@ -425,19 +427,22 @@ def nce_forward(queue, count, q, pos, inv_T):
     lse = torch.empty((R,), dtype=torch.float32, device=dev)
     loss = torch.empty((R,), dtype=torch.float32, device=dev)
     rank = torch.empty((R,), dtype=torch.int32, device=dev)
-    call('mscl_nce_fwd', ptr(queue), ptr(count), ptr(q), ptr(pos), ptr(part), R, dim, K, inv_T, stream_ptr())
+    vk, vp = virt if virt is not None else (None, None)
+    call('mscl_nce_fwd_virt', ptr(queue), ptr(count), ptr(q), ptr(pos), ptr(part), R, dim, K, inv_T,
+         ptr(vk), vk.shape[0] if vk is not None else 0, ptr(vp), stream_ptr())
     call('mscl_nce_finish', ptr(part), ptr(pos), ptr(lse), ptr(loss), ptr(rank), R, nblk, inv_T, stream_ptr())
     return lse, loss, rank
 
 
-def nce_backward(queue, count, q, lse, row_scale, inv_T):
+def nce_backward(queue, count, q, lse, row_scale, inv_T, virt=None):
     """dq (R, dim) = inv_T * row_scale[r] * sum_k softmax_k * W[:, k] (negatives only)."""
     R, dim = q.shape
     dq = torch.zeros((R, dim), dtype=torch.float32, device=q.device)
     Kq = queue.shape[1]
     ws = torch.empty(((Kq + 127) // 128) * ((min(R, 32) + 7) // 8 * 8) * dim, dtype=torch.float32, device=q.device)
-    call('mscl_nce_bwd', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), ptr(ws), ws.numel(), R, dim, Kq,
-         inv_T, stream_ptr())
+    vk, vp = virt if virt is not None else (None, None)
+    call('mscl_nce_bwd_virt', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), ptr(ws), ws.numel(), R, dim, Kq,
+         inv_T, ptr(vk), vk.shape[0] if vk is not None else 0, ptr(vp), stream_ptr())
     return dq
 
 

@@ -505,10 +505,10 @@ class _MSCLLossFn(torch.autograd.Function):
         dev = q_rgb.device
         ones = torch.full((B,), 1.0 / B, device=dev)
 
-        def run(queue_owner, Q, Kp, scale):
+        def run(queue_owner, Q, Kp, scale, virt=None):
             pos = K.rowdot(Q, Kp)
-            lse, loss_rows, rank = K.nce_forward(queue_owner.queue, queue_owner.count, Q, pos, inv_T)
-            dq = K.nce_backward(queue_owner.queue, queue_owner.count, Q, lse, scale, inv_T)
+            lse, loss_rows, rank = K.nce_forward(queue_owner.queue, queue_owner.count, Q, pos, inv_T, virt)
+            dq = K.nce_backward(queue_owner.queue, queue_owner.count, Q, lse, scale, inv_T, virt)
             K.nce_pos_bwd(Kp, pos, lse, scale, dq, inv_T)
             return loss_rows, rank, dq
 
@@ -525,15 +525,31 @@ class _MSCLLossFn(torch.autograd.Function):
         with torch.cuda.stream(fork if fork is not None else main):
             QA = torch.cat(rowsA, 0)
             lossA, rankA, dA = run(rec, QA, k_rgb.repeat(len(rowsA), 1), ones.repeat(len(rowsA)))
-        # pass B: flow queue before enqueue -> loss_cls_flow
-        lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
         kg = model._kglobal
-        recf.dequeue_and_enqueue(k_fb, kg.get('fb'))                     # base pass: update_queue=True (mscl.py:239)
-        # pass C: flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug
+        # pass C reads the flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug.  It takes that
+        # snapshot "virtually" -- ages + 1, the columns the enqueue will write replaced by the keys it will write
+        # (kernels.nce_forward(virt=)) -- so it does not wait for pass B and the write: it runs on the idle flow stream beside B
         rowsC = [q_fa, q_rgb] + ([q_rgb] if use_aug_mx else [])
         keysC = [k_fa, k_fb] + ([k_fa] if use_aug_mx else [])
-        scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
-        lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC)
+        forkC = model._side_stream(0) if (model.two_streams and model.loss_fork_c) else None
+        newk = kg.get('fb') if kg.get('fb') is not None else k_fb          # what dequeue_and_enqueue will write (gathered at W > 1)
+        if forkC is not None:
+            forkC.wait_stream(main)
+            for tns in rowsC + keysC + [ones, newk]:
+                tns.record_stream(forkC)
+            with torch.cuda.stream(forkC):
+                scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
+                lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC, virt=(newk.contiguous(), recf.queue_ptr))
+        # pass B: flow queue before enqueue -> loss_cls_flow
+        lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
+        if forkC is not None:
+            main.wait_stream(forkC)                   # C has read the queue: the enqueue may overwrite it
+            for tns in (lossC, rankC, dC):
+                tns.record_stream(main)
+        recf.dequeue_and_enqueue(k_fb, kg.get('fb'))                     # base pass: update_queue=True (mscl.py:239)
+        if forkC is None:
+            scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
+            lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC)
         if model.update_aug_flow:
             recf.dequeue_and_enqueue(k_fa, kg.get('fa'))
         if fork is not None:
@@ -611,6 +627,9 @@ class MSCLWithAug(nn.Module):
         self._a2a = False
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
         self.loss_fork = os.environ.get('MSCL_LOSS_FORK', '1') != '0'          # RGB-queue InfoNCE pass beside the flow-queue passes
+        # ... and (opt-in, MSCL_LOSS_FORK_C=1) the post-enqueue flow-queue pass on a "virtual" snapshot beside the pre-enqueue one:
+        # exact (test_nce_virtual_enqueue_equals_real_enqueue) but no faster -- 957.8 vs 957.6 clip-pairs/s over five alternating pairs
+        self.loss_fork_c = os.environ.get('MSCL_LOSS_FORK_C', '0') == '1' 
         self.key_graphs = os.environ.get('MSCL_KEY_GRAPHS', '1') == '1'          # key branches as sub-graphs in eager steps
         self._key_graph = [KeyGraph(), KeyGraph(), KeyGraph()]                  # RGB, flow base, flow rotated
         self.query_graphs = os.environ.get('MSCL_QUERY_GRAPHS', '1') == '1'      # flow query passes (fwd + bwd) likewise

@@ -677,3 +677,35 @@ def test_linear_more_than_32_rows(dev):
     dw = torch.zeros(o, i, device=dev); db = torch.zeros(o, device=dev)
     dx = K_.linear_bwd(x.detach().to(dev), w.detach().to(dev), yd, dy.to(dev), dw, db, False)
     close(dx, x.grad, F32_TOL, 'dx'); close(dw, w.grad, F32_TOL, 'dw'); close(db, b.grad, F32_TOL, 'db')
+
+
+def test_nce_virtual_enqueue_equals_real_enqueue(dev):
+    """mscl_nce_fwd_virt / _bwd_virt: the InfoNCE pass on the snapshot AFTER an enqueue, read from the buffers BEFORE it, against the
+    same pass after the real mscl_queue_enqueue -- bit for bit (same arithmetic on the same values), at a pointer in the middle
+    of the queue and at its last slot group."""
+    from mscl_amd import kernels as K_, lib
+    dim, Kq, R, n = 128, 4096, 24, 8
+    lib.set_deterministic(True)            # one add per dq element: the two runs are comparable bit for bit
+    try:
+        _virt_vs_real(K_, dev, dim, Kq, R, n)
+    finally:
+        lib.set_deterministic(False)
+
+
+def _virt_vs_real(K_, dev, dim, Kq, R, n):
+    for p0 in (1024, Kq - n):
+        queue = F.normalize(rnd((dim, Kq), 51), dim=0).to(dev)
+        count = torch.randint(0, 5000, (Kq,), generator=torch.Generator().manual_seed(52)).to(dev)
+        qptr = torch.tensor([p0], dtype=torch.long, device=dev)
+        q = F.normalize(rnd((R, dim), 53), dim=1).to(dev); kpos = F.normalize(rnd((R, dim), 54), dim=1).to(dev)
+        keys = F.normalize(rnd((n, dim), 55), dim=1).to(dev)
+        scale = torch.full((R,), 1.0 / R, device=dev)
+        pos = K_.rowdot(q, kpos)
+        lse_v, loss_v, rank_v = K_.nce_forward(queue, count, q, pos, 1 / 0.07, virt=(keys, qptr))
+        dq_v = K_.nce_backward(queue, count, q, lse_v, scale, 1 / 0.07, virt=(keys, qptr))
+        K_.queue_enqueue(queue, count, qptr, keys)
+        assert int(qptr) == (p0 + n) % Kq
+        lse_r, loss_r, rank_r = K_.nce_forward(queue, count, q, pos, 1 / 0.07)
+        dq_r = K_.nce_backward(queue, count, q, lse_r, scale, 1 / 0.07)
+        assert torch.equal(lse_v, lse_r) and torch.equal(loss_v, loss_r) and torch.equal(rank_v, rank_r)
+        assert torch.equal(dq_v, dq_r)
