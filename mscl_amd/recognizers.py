@@ -46,8 +46,8 @@ LOG_KEYS_NO_AUG_MX = tuple(k for k in LOG_KEYS if not k.endswith('_mx_aug') and 
 KEY_NO_HALO = os.environ.get('MSCL_KEY_NO_HALO', '0') == '1'
 
 
-# the RGB query chain (main stream, the step's critical chain) is issued before the side chains: 932.4-933.0 vs 928.8-931.2
-# clip-pairs/s from the captured graph in three alternating pairs (no difference for eager launches); =0 issues it last
+# under whole-step capture the RGB query chain (main stream, the step's critical chain) is recorded before the side chains:
+# 932.4-933.0 vs 928.8-931.2 clip-pairs/s in three alternating pairs; =0 records it last (eager launches always issue it last)
 ISSUE_QUERY_FIRST = os.environ.get('MSCL_ISSUE_QUERY_FIRST', '1') == '1'
 
 
@@ -1023,7 +1023,9 @@ class MSCLWithAug(nn.Module):
         def issue_query():
             x_q = aug.pack_rgb(aug.color(im_q, color_q, 0), flip_q)
             return rec.encode_q(x_q, levels=(ids[0],))       # LMCL reads one pyramid level (local_cl_head.py:59)
-        q_first = ISSUE_QUERY_FIRST
+        # (only while a whole-step capture records: there the order is just the graph's node order.  Eager launches keep the query
+        #  chain last -- its ~250 host-side launches would otherwise delay the side chains' cheap sub-graph replays by ~2.5 ms)
+        q_first = ISSUE_QUERY_FIRST and torch.cuda.is_current_stream_capturing()
         if q_first:
             q_rgb, maps_rgb = issue_query()
         with torch.cuda.stream(s_fq):
