@@ -773,7 +773,8 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   if (wide_ok && Cr >= 128) {
     const int nk = g.ntaps << (g.cgs - 3);
     // 128 output channels: 256 positions x 128 (196 tiles on the 50176-position maps) -- a tie at best, A/B only
-    if (wide >= 2 && Cr == 128 && (blocks(256, 128) >= 160 || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
+    static const long w128_min = [] { const char* e = getenv("MSCL_IGEMM_W128_MIN"); return e && atol(e) > 0 ? atol(e) : 160L; }();         // tuning aid
+    if (wide >= 2 && Cr == 128 && (blocks(256, 128) >= w128_min || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
     // 256 output channels on maps of a few thousand positions: 128 positions x 256 channels, K split over the grid
     if (Cr >= 256 && Cr % 256 == 0 && can_split && nk >= 32 && blocks(128, 256) <= 128 && (wide >= 2 || (Cr == 256 && blocks(128, 256) >= 24)))
       GO(128, 256, 64, 2, 4);
@@ -782,7 +783,8 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     if (Cr >= 128) {
       // a few dozen 128 x 128 tiles (784-position maps): 64-row tiles double the tiles per split, so fewer fp32 slabs
       // make the same number of blocks (512 -> 512 3x3x3 on 784 positions: 34 -> 32 us, 128 -> 128 on 6272: 30 -> 25 us)
-      if (can_split && g.nclass == 0 && blocks(128, 128) <= 64) GO(64, 128, 64, 2, 2);
+      static const long small_max = [] { const char* e = getenv("MSCL_IGEMM_SMALLTILE_MAX"); return e && atol(e) > 0 ? atol(e) : 64L; }();   // tuning aid
+      if (can_split && g.nclass == 0 && blocks(128, 128) <= small_max) GO(64, 128, 64, 2, 2);
       if (blocks(128, 128) >= 384 || can_split) GO(128, 128, 64, 2, 2);
       GO(64, 128, 64, 2, 2);
     }
