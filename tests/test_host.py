@@ -113,6 +113,15 @@ def test_c_abi_exports_every_declared_symbol():
     assert handle.mscl_sumsq(None, None, 0, None, 0, None) == -1
 
 
+def test_statistics_slot_constants_match_the_header():
+    """kernels.STAT_SLOTS / STAT_ACTIVE size and fill the BatchNorm statistics buffers on the Python side; the kernels take theirs
+    from include/mscl_hip.h"""
+    from mscl_amd import kernels as K_
+    header = open(os.path.join(ROOT, 'include', 'mscl_hip.h')).read()
+    assert int(re.search(r'#define MSCL_STAT_SLOTS (\d+)', header).group(1)) == K_.STAT_SLOTS
+    assert int(re.search(r'#define MSCL_STAT_ACTIVE (\d+)', header).group(1)) == K_.STAT_ACTIVE <= K_.STAT_SLOTS
+
+
 def test_fill_is_deterministic_and_q_k_twins_equal(model):
     from mscl_amd.fill import fill_module, fill_value
     import numpy as np
