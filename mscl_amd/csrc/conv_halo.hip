@@ -740,6 +740,14 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
     const size_t lds = (size_t)2 * 256 * 128 + 2 * 64 * 128;          // 80 KB: two blocks per CU
     hipLaunchKernelGGL((conv_halo64_kernel<4, 128, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
                        addend, ssum, ssq, bn);
+  } else if (getenv("MSCL_HALO_RING") && getenv("MSCL_HALO_RING")[0] == '2') {
+    // A/B: a 2-stage weight ring leaves 48 KB of the CU's LDS free (112 KB per block), enough for a 35-KB block of another
+    // chain's implicit-GEMM kernel to run on the same CU
+    static bool a2 = false;
+    if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<8, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
+    const size_t lds = (size_t)2 * 384 * 128 + 2 * 64 * 128;
+    hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, st, g, src, w, out,
+                       addend, ssum, ssq, bn);
   } else if (!(w8 && w8[0] == '4')) {
     // default since round 2: two waves per SIMD.  Measured inside the three-stream step, three alternating pairs in one call:
     // 927 / 928 / 931 vs 920 / 920 / 923 clip-pairs/s, forward launch 104.2 vs 109.5 us, input gradient 102 vs 109 us
