@@ -53,6 +53,9 @@ int mscl_abi_version(void);
 /* tuning aid: while non-zero, mscl_conv3d_fwd / _dgrad do not take the window-resident layer-1 kernel (host-side switch read at
  * launch time: brackets the launches of one chain) */
 int mscl_set_halo_off(int off);
+/* test aid: number of launches the ping-pong shared-tap conv kernel (conv_pp.hip) has taken in this process, so that a parity
+ * test can assert which kernel family produced the result it checked */
+int64_t mscl_debug_pp_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);
 /* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order:

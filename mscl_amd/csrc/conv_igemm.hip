@@ -24,170 +24,10 @@
 //  * Small-M layers (layer3/4, pyramid levels): split-K over the grid with fp32 atomic partials + a finalize
 //    pass (bias / addend / ReLU / BN statistics / bf16), so >= 2 blocks per CU exist even at M = 784.
 //  * blockIdx is remapped so that an XCD's L2 sees neighbouring position tiles (halo reuse).
-#include "common.h"
+#include "igemm.h"
 #include <cstdio>
 #include <cstdlib>
 
-struct ClassInfo { unsigned char ro[3]; unsigned char ntl; unsigned char taps[8]; int TrS, HrS, WrS, M; FastDiv dW, dH, dT; };
-
-struct IGemmGeom {
-  int N, Ts, Hs, Ws, Cs;   // source (gathered) tensor
-  int Tr, Hr, Wr, Cr;      // row tensor
-  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
-  int M, KG, cgs, ntaps;
-  int lsT, lsH, lsW;
-  int mode;                // 0 forward gather, 1 dgrad stride-1 (linear), 2 dgrad strided (parity classes)
-  int mtiles, ntiles, ksplit, nclass;
-  int grp_rows;            // BatchNorm statistics groups (forward only): rows [k*grp_rows, (k+1)*grp_rows) feed group k; 0 = one group
-  FastDiv dW, dH, dT;      // dense launches: division by Wr, Hr, Tr
-  FastDiv dKW, dKH;        // tap index -> (kt, kh, kw) (uniform-tap kernel)
-  ClassInfo cls[8];
-};
-
-__device__ __forceinline__ auto make_uniform_rsrc(const void* p, unsigned bytes) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
-  void* q = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
-template <int BK> __device__ __forceinline__ int swz(int row, int g) {
-  if constexpr (BK == 64) return g ^ ((row >> 1) & 7);
-  else { const int q = (row >> 2) & 3; return g ^ ((0x78 >> (q * 2)) & 3); }   // q -> {0,2,3,1}
-}
-
-// Shared epilogue: split-K slab store, or BatchNorm statistics + (+bias)(+addend)(relu) -> bf16.
-template <int BM, int BN, int IM, int JN>
-__device__ __forceinline__ void igemm_epilogue(const IGemmGeom& g, f32x4_t (&acc)[JN][IM], unsigned char* smem, int tid, int fr, int fq,
-                                               int m0, int n0, int wm0, int wn0, int split, int Mc, FastDiv dW, FastDiv dH, FastDiv dT,
-                                               int TrS, int HrS, int WrS, int rsT, int rsH, int rsW, int roT, int roH, int roW,
-                                               bf16_t* __restrict__ out, const float* __restrict__ bias,
-                                               const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
-                                               float* __restrict__ stat_sq, int relu, float* __restrict__ partial) {
-  // output position of this lane's rows (class-strided for the parity-split input gradient)
-  long orow[IM];
-#pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    const int m = m0 + wm0 + i * 16 + fr;
-    if (m < Mc) {
-      const int q1 = fdiv(m, dW), ws_ = m - q1 * WrS;
-      const int q2 = fdiv(q1, dH), hs_ = q1 - q2 * HrS;
-      const int n = fdiv(q2, dT), ts_ = q2 - n * TrS;
-      orow[i] = ((((long)n * g.Tr + ts_ * rsT + roT) * g.Hr + hs_ * rsH + roH) * g.Wr + ws_ * rsW + roW) * g.Cr;
-    } else orow[i] = -1;
-  }
-
-  if (partial != nullptr) {                   // split-K: this split's fp32 slab (plain 16-byte stores); the
-    float* slab = partial + (long)split * ((long)g.N * g.Tr * g.Hr * g.Wr * g.Cr);   // epilogue runs in splitk_finalize_kernel
-#pragma unroll
-    for (int i = 0; i < IM; ++i) {
-      if (orow[i] < 0) continue;
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const int n = n0 + wn0 + j * 16 + fq * 4;
-        if (n >= g.Cr) continue;
-        *reinterpret_cast<float4*>(slab + orow[i] + n) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-      }
-    }
-    return;
-  }
-
-  // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
-  if (stat_sum != nullptr) {
-    float* red = reinterpret_cast<float*>(smem);      // [2][BN], tiles are dead after the last barrier
-    // statistics groups (a batch that holds two BatchNorm calls of the reference, e.g. base || rotated flow clips): rows below
-    // `bound` feed group g_lo, the rest (a tile that straddles the boundary; there are at most two groups) group g_lo + 1
-    int g_lo = 0, bound = 0x7fffffff, npass = 1;
-    if (g.grp_rows > 0) {
-      g_lo = m0 / g.grp_rows;
-      bound = (g_lo + 1) * g.grp_rows;
-      npass = (min(m0 + BM, Mc) > bound) ? 2 : 1;
-    }
-    for (int pass = 0; pass < npass; ++pass) {
-      for (int i = tid; i < 2 * BN; i += (int)blockDim.x) red[i] = 0.f;
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < IM; ++i) {
-          const bool mine = ((m0 + wm0 + i * 16 + fr) < bound) == (pass == 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = mine ? acc[j][i][r] : 0.f; s[r] += v; q[r] += v * v; }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
-        }
-        if (fr == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int nl = wn0 + j * 16 + fq * 4 + r;
-            atomicAdd(&red[nl], s[r]);
-            atomicAdd(&red[BN + nl], q[r]);
-          }
-        }
-      }
-      __syncthreads();
-      for (int i = tid; i < BN; i += (int)blockDim.x) {
-        if (n0 + i < g.Cr) {
-          const int so = ((g_lo + pass) * MSCL_STAT_SLOTS + (int)(blockIdx.x % MSCL_STAT_ACTIVE)) * 2 * g.Cr;
-          atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
-        }
-      }
-      if (npass > 1) __syncthreads();
-    }
-  }
-
-  // ---- epilogue: (+bias) (+addend) (relu) -> bf16 ----
-  // A lane holds 4 consecutive channels of one position per 16-channel tile: 8 bytes.  Stores of 8 bytes per lane are issue-bound
-  // on write-heavy layers (1-tap convs that widen the map, e.g. 64 -> 256 on a 205-MB map: 2.3 TB/s against 4.4-5.0 TB/s for the
-  // read-heavy direction), so two channel tiles are paired: v_permlane16_swap exchanges the quads between lane rows fq and fq ^ 1
-  // (same position, neighbouring channel quads), after which an even row holds 8 consecutive channels of tile j and an odd row
-  // 8 consecutive channels of tile j + 1 -- one 16-byte store per lane instead of two 8-byte ones, same bytes, same values.
-  auto quad = [&](int i, int j, bool ok) -> uint2 {
-    const int n = n0 + wn0 + j * 16 + fq * 4;
-    float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-    if (ok && n < g.Cr) {
-      if (bias != nullptr) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (addend != nullptr) {
-        const uint2 av = *reinterpret_cast<const uint2*>(addend + orow[i] + n);
-        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
-        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
-      }
-    }
-    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
-    return pv;
-  };
-#pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    const bool rowok = orow[i] >= 0;
-    if constexpr (JN % 2 == 0) {
-#pragma unroll
-      for (int j = 0; j < JN; j += 2) {
-        const uint2 p0 = quad(i, j, rowok), p1 = quad(i, j + 1, rowok);
-        // every lane takes part in the swaps (EXEC full here: no divergent branch encloses them)
-        const auto sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
-        // even rows: {own tile-j quad, next row's tile-j quad}; odd rows: {previous row's tile-(j+1) quad, own tile-(j+1) quad}
-        const uint4 w = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        const int n = n0 + wn0 + (j + (fq & 1)) * 16 + (fq & 2) * 4;
-        if (rowok && n < g.Cr) *reinterpret_cast<uint4*>(out + orow[i] + n) = w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const int n = n0 + wn0 + j * 16 + fq * 4;
-        const uint2 pv = quad(i, j, rowok);
-        if (rowok && n < g.Cr) *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
-      }
-    }
-  }
-}
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
@@ -645,6 +485,19 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------- host side
+// the pass that follows a split-K launch (also used by conv_pp.hip)
+int mscl_launch_splitk_finalize(const float* partial, bf16_t* out, const float* bias, const bf16_t* addend, int relu, float* ssum,
+                                float* ssq, long rows, int C, int nslab, long grp_rows, hipStream_t st) {
+  const int RP = 256 / (C / 8);
+  const int ngrp = grp_rows > 0 ? (int)(rows / grp_rows) : 1;
+  static const long fin_cap = [] { const char* e = getenv("MSCL_FINALIZE_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();   // tuning aid
+  long fb = (rows / ngrp + RP - 1) / RP; if (fb > fin_cap / ngrp) fb = fin_cap / ngrp; if (fb < 1) fb = 1;
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb, ngrp), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
+                     rows, C, nslab, grp_rows);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % (8 * WAVES_M * WAVES_N) == 0 && BN % (8 * WAVES_M * WAVES_N) == 0; }
 static bool fast_disabled() { const char* e = getenv("MSCL_IGEMM_FAST"); return e && e[0] == '0'; }
@@ -730,16 +583,8 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
                        relu, partial);
     MSCL_LAUNCH_CHECK();
   }
-  if (g.ksplit > 1) {
-    const long rows = out_elems / g.Cr;
-    const int RP = 256 / (g.Cr / 8);
-    const int ngrp = g.grp_rows > 0 ? (int)(rows / g.grp_rows) : 1;
-    static const long fin_cap = [] { const char* e = getenv("MSCL_FINALIZE_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();   // tuning aid
-    long fb = (rows / ngrp + RP - 1) / RP; if (fb > fin_cap / ngrp) fb = fin_cap / ngrp; if (fb < 1) fb = 1;
-    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb, ngrp), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
-                       rows, g.Cr, g.ksplit, (long)g.grp_rows);
-    MSCL_LAUNCH_CHECK();
-  }
+  if (g.ksplit > 1)
+    return mscl_launch_splitk_finalize(partial, out, bias, addend, relu, ssum, ssq, out_elems / g.Cr, g.Cr, g.ksplit, (long)g.grp_rows, st);
   return 0;
 }
 
@@ -763,6 +608,17 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
       TRY(128, 128, 32, 2, 2); TRY(256, 64, 32, 4, 1); TRY(128, 64, 32, 2, 2); TRY(64, 64, 32, 2, 2);
       TRY(256, 128, 32, 4, 1); TRY(64, 128, 32, 2, 2);
 #undef TRY
+    }
+  }
+  // ping-pong kernel with shared W taps (conv_pp.hip): kW = 3, stride 1 along W, source channels a multiple of 64, output
+  // channels a multiple of 128.  MSCL_PP: 0 = off, 1 (default) = maps of >= pp_min positions, 2 = wherever it applies.
+  {
+    const char* e_pp = getenv("MSCL_PP");                    // read per launch: tests and A/B sweeps flip it inside one process
+    const int pp_level = e_pp ? atoi(e_pp) : 1;
+    static const long pp_min = [] { const char* e = getenv("MSCL_PP_MIN"); return e && atol(e) > 0 ? atol(e) : 16384L; }();
+    if (pp_level > 0 && (pp_level >= 2 || rowsM >= pp_min)) {
+      const int r = mscl_launch_conv_pp(g, src, wgt, out, bias, addend, ssum, ssq, relu, ws, ws_floats, st);
+      if (r != MSCL_PP_SKIP) return r;
     }
   }
   const bool can_split = ws != nullptr;

@@ -1,0 +1,289 @@
+// Conv3d forward / stride-1 input gradient for the 128-and-wider channel layers: implicit GEMM, bf16 MFMA, one 512-thread block per
+// CU, ping-pong schedule (replaces the two-barrier-per-K-step loop of conv_igemm_fast_kernel on these shapes).
+// Reference ops: the 3x3x3 convolutions of BasicBlock / Conv3DSimple (mmaction/models/backbones/r3d.py:16-34,95-127), the SEPC
+// PConv3D convolutions (necks/sepc.py:57-135) and the FPN output convolutions (necks/fpn.py:130-152).
+//
+// What bounds an im2col-style conv on a CU is the global -> LDS path: ~30 B/clk/CU (MI355X_MICROARCH.md, "Indexed rows: gather into
+// LDS"), i.e. ~100+ issue cycles per 1-KiB LDS-DMA instruction, against 16 cycles per v_mfma_f32_16x16x32_bf16.  A 256 x 128 x 64
+// step re-staged per tap needs 6 DMA instructions per wave per 32 MFMAs.  Two changes take that to 3.3:
+//  * SHARED W TAPS.  Rows of the GEMM are positions in PADDED-LINEAR order: q = (n,t,h) * (W + 2) + wp, wp = 0 and W + 1 being
+//    zero columns (the buffer unit writes the zeros: out-of-range offset).  The three kw taps of a (kt, kh) pair are then the
+//    SAME LDS rows read one row up / in place / one row down, so the position tile is staged once per (kt, kh, 64 channels) and
+//    only the three 128 x 64 weight tiles differ.  A block stages 256 rows and stores the 254 inner ones (tiles overlap by 2).
+//    Cost: 2 / (W + 2) of the MFMA work lands on padding columns (6.7 % at W = 28).
+//  * PING-PONG.  8 waves = 2 per SIMD.  Every wave runs [L: 8 ds_read_b128 + its share of the DMA issue | barrier | M: 16 MFMAs
+//    at raised priority | barrier]; waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave feeds the matrix pipe
+//    while its partner loads.  DMA stays in flight across the (raw) barriers behind counted vmcnt waits, never 0 inside the loop.
+// Hazard rules (cdna_hip_programming.md 5, "Read a staged buffer one phase AFTER the wait that retires it"), with phases
+// numbered per wave:  (R1) a unit waited for in L_p is first read in L_{p+1};  (R2) a slot last read in L_p is re-issued in
+// L_{p+2} or later.  With the one-barrier stagger both hold for either wave group.
+// Schedule per group g = (kt, kh, 64-channel part), 6 phases P0..P5 (phase = (kw, k half)), UB = BN / 64 DMA instructions per
+// weight tile, 2 per half position tile; ring of NB = 5 weight slots (tile index mod 5), 2 position slots:
+//   issue for group g+1:   P0: B0'   P1: A0'   P2: A1'   P3: B1'   P4: B2'   P5: -
+//   waits:  P1: B1 (of g) landed = vmcnt(2 UB + 2)   P3: B2 landed = vmcnt(2 UB + 4)   P5: B0', A0', A1' landed = vmcnt(2 UB)
+#include "igemm.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N> struct IC { static constexpr int value = N; };
+
+#define PP_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+#define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_pp_kernel(
+    const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
+    const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
+    float* __restrict__ stat_sq, const int relu, float* __restrict__ partial) {
+  constexpr int BM = 256, KW = 3, HALO = 1, OUT_ROWS = BM - 2 * HALO, NB = 5;
+  constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;
+  constexpr int UB = BN / 64;                     // DMA instructions per thread per weight tile (64 rows per pass of 512 threads)
+  constexpr int A_BASE = NB * B_SLOT;             // weight ring first: the row "-1" read of position fragment 0 stays inside LDS
+  constexpr int WAVES_N = 2, WM = 64, WN = BN / WAVES_N;
+  constexpr int IM = WM / 16, JN = WN / 16;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(BN == 128, "tile config");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                      // 0: waves 0-3, 1: waves 4-7 (the SIMD partners of 0-3), one barrier behind
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid % g.ksplit; bid /= g.ksplit;
+  const int nt = bid % g.ntiles; const int mt = bid / g.ntiles;
+  const int n0 = nt * BN;
+  const int q0 = mt * OUT_ROWS - HALO;            // padded-linear position of LDS row 0
+  const int mode = __builtin_amdgcn_readfirstlane(g.mode);      // 0 forward, 1 stride-1 input gradient
+  const int Wp = g.Wr + 2 * HALO, Mp = g.M;
+  const int cs2 = g.Cs * 2;
+  // tap offsets (kt, kh only: kw is a row shift at read time) stay non-negative in the SGPR operand: descriptor base moved back
+  const int maxlin = ((g.kT - 1) * g.Hs + (g.kH - 1)) * g.Ws;
+  const int padlin = (g.pT * g.Hs + g.pH) * g.Ws + HALO;
+  const int bias_bytes = (mode == 0 ? padlin : maxlin) * cs2;
+
+  const int rg = tid & 7, rr = tid >> 3;          // granule column / row inside a 64-row staging pass
+  const int rgl = rg ^ (rr & 7);                  // logical granule this lane fetches: LDS image is [row][granule ^ (row & 7)]
+  int row_voff[4], row_mask[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = q0 + p * 64 + rr;
+    int mask = 0, base = 0;
+    if (q >= 0 && q < Mp) {
+      const int nth = fdiv(q, g.dW), w0 = q - nth * Wp - HALO;
+      if ((unsigned)w0 < (unsigned)g.Ws) {
+        const int q2 = fdiv(nth, g.dH), hr = nth - q2 * g.Hr;
+        const int n = fdiv(q2, g.dT), tr = q2 - n * g.Tr;
+        int t0, h0;
+        if (mode == 0) { t0 = tr * g.sT - g.pT; h0 = hr * g.sH - g.pH; }
+        else { t0 = tr + g.pT; h0 = hr + g.pH; }
+        for (int k = 0; k < g.kT; ++k) { const int d = (mode == 0) ? t0 + k : t0 - k; mask |= ((unsigned)d < (unsigned)g.Ts) ? (1 << k) : 0; }
+        for (int k = 0; k < g.kH; ++k) { const int d = (mode == 0) ? h0 + k : h0 - k; mask |= ((unsigned)d < (unsigned)g.Hs) ? (1 << (8 + k)) : 0; }
+        base = ((n * g.Ts + t0) * g.Hs + h0) * g.Ws + w0;
+      }
+    }
+    row_voff[p] = base * cs2 + (mode == 0 ? bias_bytes : 0) + rgl * 16;      // >= 0 for every row with a valid tap
+    row_mask[p] = mask;
+  }
+  unsigned wrow_voff[UB];
+#pragma unroll
+  for (int p = 0; p < UB; ++p) {
+    const int r = p * 64 + rr;
+    wrow_voff[p] = (n0 + r < g.Cr) ? (unsigned)((n0 + r) * g.KG * 16 + rgl * 16) : OOB;
+  }
+  const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src) - bias_bytes;
+  const auto rs_src = make_uniform_rsrc(src_b, 0x7FFFFFFFu);
+  const auto rs_wgt = make_uniform_rsrc(wgt, 0x7FFFFFFFu);
+
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4_t acc[JN][IM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment byte offsets inside a slot; fragments i / j are 16 rows = 2048 bytes apart (same swizzle key)
+  unsigned a_off[KW][2], b_off[2];
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = wm0 + fr + (mode == 0 ? kw - HALO : HALO - kw);        // may be -1 / 256 on the two rows that are not stored
+      a_off[kw][ks] = lds_base + A_BASE + (unsigned)(row * 128 + (((ks * 4 + fq) ^ (row & 7)) * 16));
+    }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int row = wn0 + fr;
+    b_off[ks] = lds_base + (unsigned)(row * 128 + (((ks * 4 + fq) ^ (row & 7)) * 16));
+  }
+
+  // groups of this split
+  const int subs = g.cgs - 3, submask = (1 << subs) - 1;        // 64-channel parts per tap = Cs / 64
+  const int ng_all = (g.kT * g.kH) << subs;
+  const int g_beg = (int)((long)ng_all * split / g.ksplit), g_end = (int)((long)ng_all * (split + 1) / g.ksplit);
+
+  // scalar state of one group: SGPR offset of the position tile, tap-validity bits, SGPR offset of its first weight tile
+  auto group_soff = [&](int gi, unsigned& soff, int& tb, unsigned& woff) {
+    const int tk = gi >> subs, cpart = gi & submask;
+    const int kt = fdiv(tk, g.dKH), kh = tk - kt * g.kH;
+    const int lin = (kt * g.Hs + kh) * g.Ws;
+    soff = __builtin_amdgcn_readfirstlane((unsigned)((mode == 0 ? lin : maxlin - lin) * cs2 + cpart * 128));
+    tb = __builtin_amdgcn_readfirstlane((1 << kt) | (1 << (8 + kh)));
+    woff = __builtin_amdgcn_readfirstlane((unsigned)((((tk * KW) << subs) + cpart) * 128));      // kw = 0; kw adds Cs * 2 bytes
+  };
+  auto issue_a = [&](int half, unsigned slot, unsigned soff, int tb) {     // rows [128 half, 128 half + 128) of a position tile
+    unsigned char* a = smem + A_BASE + slot + wave * 1024;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int p = half * 2 + pp;
+      const unsigned off = ((row_mask[p] & tb) == tb) ? (unsigned)row_voff[p] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(a + p * 8192), 16, off, soff, 0, 0);
+    }
+  };
+  auto issue_b = [&](unsigned slot, unsigned woff) {
+    unsigned char* b = smem + slot + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < UB; ++p) {
+      const unsigned wv = wrow_voff[p];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(b + p * 8192), 16, wv, woff, 0, 0);
+    }
+  };
+
+  unsigned soff_n = 0, woff_n = 0; int tb_n = 0;
+  unsigned bq = 0;                                // ring slot (0..NB-1) of the current group's first weight tile
+  unsigned a_cur = 0;                             // byte offset of the current group's position slot (0 / A_SLOT)
+  const unsigned wstep = (unsigned)cs2;           // bytes from a (kt, kh, kw) weight tile to the (kt, kh, kw + 1) one
+
+  // ---- prologue: the whole first group, in the steady-state order, then the steady-state "P5" wait ----
+  group_soff(g_beg, soff_n, tb_n, woff_n);
+  issue_b(0 * B_SLOT, woff_n);
+  issue_a(0, 0, soff_n, tb_n);
+  issue_a(1, 0, soff_n, tb_n);
+  issue_b(1 * B_SLOT, woff_n + wstep);
+  issue_b(2 * B_SLOT, woff_n + 2 * wstep);
+  PP_VMCNT(2 * UB);
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();     // the stagger
+
+  u32x4_t fa[IM], fb[JN];
+  for (int gi = g_beg; gi < g_end; ++gi) {
+    const bool has_next = gi + 1 < g_end;
+    if (has_next) group_soff(gi + 1, soff_n, tb_n, woff_n);
+    const unsigned a_nxt = a_cur ^ (unsigned)A_SLOT;
+    const unsigned bs1 = (bq + 1 >= NB) ? bq + 1 - NB : bq + 1, bs2 = (bq + 2 >= NB) ? bq + 2 - NB : bq + 2;
+    const unsigned bn0 = (bq + 3 >= NB) ? bq + 3 - NB : bq + 3, bn1 = (bq + 4 >= NB) ? bq + 4 - NB : bq + 4, bn2 = bq;
+
+    auto phase = [&](auto PC) {
+      constexpr int P = decltype(PC)::value;
+      constexpr int kw = P >> 1, ks = P & 1;
+      // ---- L: fragments of this phase, this wave's share of the next group's DMA, the counted wait ----
+      const unsigned bslot = (kw == 0 ? bq : (kw == 1 ? bs1 : bs2)) * (unsigned)B_SLOT;
+      const unsigned aa = a_off[kw][ks] + a_cur, ba = b_off[ks] + bslot;
+      PP_DSR(fa[0], aa, 0); PP_DSR(fa[1], aa, 2048); PP_DSR(fa[2], aa, 4096); PP_DSR(fa[3], aa, 6144);
+      PP_DSR(fb[0], ba, 0); PP_DSR(fb[1], ba, 2048); PP_DSR(fb[2], ba, 4096); PP_DSR(fb[3], ba, 6144);
+      if (has_next) {
+        if constexpr (P == 0) issue_b(bn0 * B_SLOT, woff_n);
+        if constexpr (P == 1) issue_a(0, a_nxt, soff_n, tb_n);
+        if constexpr (P == 2) issue_a(1, a_nxt, soff_n, tb_n);
+        if constexpr (P == 3) issue_b(bn1 * B_SLOT, woff_n + wstep);
+        if constexpr (P == 4) issue_b(bn2 * B_SLOT, woff_n + 2 * wstep);
+        if constexpr (P == 1) PP_VMCNT(2 * UB + 2);
+        if constexpr (P == 3) PP_VMCNT(2 * UB + 4);
+        if constexpr (P == 5) PP_VMCNT(2 * UB);
+      } else {
+        if constexpr (P == 1) PP_VMCNT(UB);
+        if constexpr (P == 3) PP_VMCNT(0);
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M: one 64 x 64 x 32 product ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb[j]), __builtin_bit_cast(bf16x8_t, fa[i]),
+                                                              acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    phase(IC<0>{}); phase(IC<1>{}); phase(IC<2>{}); phase(IC<3>{}); phase(IC<4>{}); phase(IC<5>{});
+    a_cur = a_nxt;
+    bq = bn0;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();     // pairs with the last barrier of waves 4-7
+
+  // ---- epilogue (shared): rows back from padded-linear order; the halo rows and the padding columns are not stored ----
+  long orow[IM];
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int idx = wm0 + i * 16 + fr;
+    const int q = q0 + idx;
+    long o = -1;
+    if (idx >= HALO && idx < BM - HALO && q < Mp) {
+      const int nth = fdiv(q, g.dW), w0 = q - nth * Wp - HALO;
+      if ((unsigned)w0 < (unsigned)g.Wr) o = ((long)nth * g.Wr + w0) * g.Cr;
+    }
+    orow[i] = o;
+  }
+  igemm_epilogue_rows<BM, BN, IM, JN, true>(g, acc, smem, tid, fr, fq, 0, n0, wm0, wn0, split, 0, orow, out, bias, addend, stat_sum,
+                                            stat_sq, relu, partial);
+}
+
+// ------------------------------------------------------------------------------------------------------------- host side
+static long g_pp_launches = 0;
+extern "C" int64_t mscl_debug_pp_launches(void) { return g_pp_launches; }     // tests: which kernel family took a launch
+
+// Returns 0 when launched, MSCL_PP_SKIP when the shape is outside this kernel (the caller falls back to conv_igemm.hip).
+int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias, const bf16_t* addend,
+                        float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
+  constexpr int BN = 128, OUT_ROWS = 254;
+  if (g.mode == 2 || g.nclass != 0 || g.grp_rows != 0) return MSCL_PP_SKIP;
+  if (g.kW != 3 || g.pW != 1 || g.sW != 1 || g.Wr != g.Ws) return MSCL_PP_SKIP;
+  if (g.cgs < 3 || (g.Cs & 63) != 0 || (g.Cr % BN) != 0) return MSCL_PP_SKIP;
+  if (g.kT > 8 || g.kH > 8) return MSCL_PP_SKIP;
+  const long span = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
+  if (span >= (1L << 31) || (long)g.Cr * g.KG * 16 >= (1L << 31)) return MSCL_PP_SKIP;
+  const long Mp = (long)g.N * g.Tr * g.Hr * (g.Wr + 2);
+  if (Mp >= (1L << 30)) return MSCL_PP_SKIP;
+  g.M = (int)Mp;
+  g.dW = make_fastdiv(g.Wr + 2);
+  g.dKH = make_fastdiv(g.kH);
+  g.mtiles = (int)((Mp + OUT_ROWS - 1) / OUT_ROWS);
+  g.ntiles = g.Cr / BN;
+  const long blocks = (long)g.mtiles * g.ntiles;
+  const int ng = g.kT * g.kH * (g.Cs / 64);
+  g.ksplit = 1;
+  const long out_elems = (long)g.N * g.Tr * g.Hr * g.Wr * g.Cr;
+  if (ws != nullptr && g.Cr <= 512 && ilog2_exact(g.Cr / 8) >= 0 && blocks <= 128 && ng >= 4) {
+    // too few tiles for 256 CUs: split the (kt, kh, channel part) groups over the grid, one round of blocks, >= 2 groups each
+    long want = 256 / blocks;
+    if (want > ng / 2) want = ng / 2;
+    if (want > 16) want = 16;
+    if (want * out_elems > ws_floats) want = ws_floats / out_elems;
+    if (want > 1) g.ksplit = (int)want;
+  }
+  if (const char* f = getenv("MSCL_PP_KSPLIT")) {        // tuning aid
+    const long want = atol(f);
+    if (want >= 1 && want <= ng && (want == 1 || (ws != nullptr && want * out_elems <= ws_floats && g.Cr <= 512))) g.ksplit = (int)want;
+  }
+  float* partial = g.ksplit > 1 ? ws : nullptr;
+  auto kern = conv_pp_kernel<BN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const size_t lds = 5 * (size_t)BN * 128 + 2 * 256 * 128;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(512), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu,
+                     partial);
+  MSCL_LAUNCH_CHECK();
+  ++g_pp_launches;
+  if (g.ksplit > 1) return mscl_launch_splitk_finalize(partial, out, bias, addend, relu, ssum, ssq, out_elems / g.Cr, g.Cr, g.ksplit, 0, st);
+  return 0;
+}

@@ -114,6 +114,77 @@ def test_conv_fwd_dgrad_wgrad(case, dev):
     close(dw, 2 * wr.grad, F32_TOL, 'conv wgrad accumulate')
 
 
+# The layer shapes of one mscl_r18 step (B=8, T=16, 112^2) that select the big-map kernel instantiations (the 8-wave 256 x 128
+# tile, the ping-pong shared-tap kernel, conv_wgrad_kernel<128,128,2>, the parity-class input gradient at full depth): the small
+# CONV_CASES never reach them.  CPU fp32 F.conv3d is the reference (a few seconds each on the box's host cores).
+REAL_CASES = [
+    ('real_l2_128_128', 8, 8, 28, 28, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # r3d.py:16-34 layer2 convs, sepc.py Pconv level 0
+    ('real_l2_entry_64_128_s2', 8, 16, 56, 56, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ('real_l3_256_256', 8, 4, 14, 14, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('real_l4_512_512', 8, 2, 7, 7, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('real_fpn_133', 8, 8, 28, 28, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('case', REAL_CASES, ids=[c[0] for c in REAL_CASES])
+def test_conv_real_layer_shapes(case, dev):
+    test_conv_fwd_dgrad_wgrad(case, dev)
+
+
+# conv_pp.hip (ping-pong, shared W taps) forced onto small shapes: row tails, a map smaller than one tile, split-K over the
+# (kt, kh, channel part) groups with the finalize pass, kT = 1, strides along T / H (forward only: the strided input gradient is
+# the parity-class kernel's), 256 / 512 channels (2 / 4 channel tiles, 4 / 8 channel parts per tap).
+PP_CASES = [
+    ('pp_128_128', 1, 3, 9, 10, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
+    ('pp_128_128_tail', 2, 3, 13, 11, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
+    ('pp_64_128', 2, 4, 12, 12, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
+    ('pp_256_256_split', 1, 2, 7, 7, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), 0),
+    ('pp_256_256_split3', 1, 2, 7, 7, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), 3),
+    ('pp_512_512', 1, 2, 7, 7, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 0),
+    ('pp_fpn_133', 1, 4, 10, 10, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), 1),
+    ('pp_128_256_s221', 2, 4, 12, 12, 128, 256, (3, 3, 3), (2, 2, 1), (1, 1, 1), 1),
+    ('pp_w28', 1, 2, 28, 28, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
+]
+
+
+@pytest.mark.parametrize('case', PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_conv_pp_forced(case, dev, monkeypatch):
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, C, K, kern, stride, pad, ksplit = case
+    monkeypatch.setenv('MSCL_PP', '2')
+    if ksplit:
+        monkeypatch.setenv('MSCL_PP_KSPLIT', str(ksplit))
+    x = bf(rnd((N, T, H, W, C), 11)); w = bf(rnd((K, *kern, C), 12, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
+    d = K_.conv_desc(x.shape, K, kern, stride, pad)
+    xg, wg = x.to(dev), w.to(dev)
+    n0 = lib.call_raw('mscl_debug_pp_launches')
+    st = torch.zeros((K_.STAT_SLOTS, 2, K), device=dev)
+    y = K_.conv3d_fwd(xg, wg, d, stats=(st[0, 0], st[0, 1]))
+    assert lib.call_raw('mscl_debug_pp_launches') == n0 + 1, 'the forward did not take the ping-pong kernel'
+    xr = x.float().requires_grad_(True); wr = w.float()
+    yr = _conv_ref(xr, wr, stride, pad)
+    close(y, yr, BF16_TOL, 'pp fwd')
+    close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'pp bn sum')
+    close(st[:, 1].sum(0), (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'pp bn sumsq')
+    b = rnd((K,), 13); a = bf(rnd(tuple(yr.shape), 14))
+    y2 = K_.conv3d_fwd(xg, wg, d, bias=b.to(dev), addend=a.to(dev), relu=True)
+    close(y2, F.relu(yr.detach() + b + a.float()), BF16_TOL, 'pp fwd epilogue')
+    if stride == (1, 1, 1):
+        dy = bf(rnd(tuple(yr.shape), 15))
+        yr.backward(dy.float())
+        wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+        K_.weight_transpose(wg, wT, K, int(np.prod(kern)), C)
+        n1 = lib.call_raw('mscl_debug_pp_launches')
+        add = bf(rnd(tuple(x.shape), 16))
+        dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
+        assert lib.call_raw('mscl_debug_pp_launches') == n1 + 1, 'the input gradient did not take the ping-pong kernel'
+        close(dx, xr.grad + add.float(), BF16_TOL, 'pp dgrad+addend')
+    # the same launches again, many times: a race between the LDS-DMA ring and the fragment reads shows as a changed output
+    y0 = K_.conv3d_fwd(xg, wg, d)
+    for _ in range(20):
+        assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
+
+
 @pytest.mark.parametrize('W', [24, 23])
 def test_stem_w_paired_equals_plain_stem(W, dev):
     """RGB stem (r3d.py:176-184: Conv3d(3,64,(3,7,7),(1,2,2),(1,3,3))) run on W-paired input (mscl_pair_w): same outputs,
