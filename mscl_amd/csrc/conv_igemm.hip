@@ -611,12 +611,12 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     }
   }
   // ping-pong kernel with shared W taps (conv_pp.hip): kW = 3, stride 1 along W, source channels a multiple of 64, output
-  // channels a multiple of 128.  MSCL_PP: 0 = off, 1 (default) = maps of >= pp_min positions, 2 = wherever it applies.
+  // channels a multiple of 128.  MSCL_PP: 0 = off, 1 (default) = layers of >= 400 k outputs (784 positions x 512 channels and up:
+  // measured faster on every such shape of the step; the 784 x 128 pyramid level is not), 2 = wherever it applies.
   {
     const char* e_pp = getenv("MSCL_PP");                    // read per launch: tests and A/B sweeps flip it inside one process
     const int pp_level = e_pp ? atoi(e_pp) : 1;
-    static const long pp_min = [] { const char* e = getenv("MSCL_PP_MIN"); return e && atol(e) > 0 ? atol(e) : 16384L; }();
-    if (pp_level > 0 && (pp_level >= 2 || rowsM >= pp_min)) {
+    if (pp_level > 0 && (pp_level >= 2 || (long)rowsM * Cr >= 400000L)) {
       const int r = mscl_launch_conv_pp(g, src, wgt, out, bias, addend, ssum, ssq, relu, ws, ws_floats, st);
       if (r != MSCL_PP_SKIP) return r;
     }

@@ -177,7 +177,7 @@ def test_conv_pp_forced(case, dev, monkeypatch):
         n1 = lib.call_raw('mscl_debug_pp_launches')
         add = bf(rnd(tuple(x.shape), 16))
         dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
-        assert lib.call_raw('mscl_debug_pp_launches') == n1 + 1, 'the input gradient did not take the ping-pong kernel'
+        assert lib.call_raw('mscl_debug_pp_launches') == n1 + (C % 128 == 0), 'the input gradient did not take the ping-pong kernel'
         close(dx, xr.grad + add.float(), BF16_TOL, 'pp dgrad+addend')
     # the same launches again, many times: a race between the LDS-DMA ring and the fragment reads shows as a changed output
     y0 = K_.conv3d_fwd(xg, wg, d)
