@@ -261,9 +261,10 @@ class ClipPairLoader:
     def _to_device(self, slot):
         """PCIe + the GPU part; returns the data_batch.  Runs on the consumer's (current) stream."""
         dev, T = self.device, self.T
-        frames = slot.frames.to(dev, non_blocking=True)
-        flow = slot.flow.to(dev, non_blocking=True)
-        ints = slot.ints.to(dev, non_blocking=True)
+        nb = len(slot.labels)                                        # a short last batch (drop_last=False) travels as its rows only
+        frames = slot.frames[:nb].to(dev, non_blocking=True)
+        flow = slot.flow[:nb].to(dev, non_blocking=True)
+        ints = slot.ints[:nb].to(dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         slot.event = ev                                              # the filler waits for it before reusing the slot
@@ -282,33 +283,64 @@ class ClipPairLoader:
             flows = [K.crop_resize(normed, box(2), hw), K.crop_resize(normed, box(3), hw)]
         return dict(imgs=imgs, flow_imgs=flows, label=torch.tensor(slot.labels, device=dev))
 
+    def _retire_worker(self):
+        """stop and join the filler of an epoch the consumer walked away from (break / exception mid-epoch): it may be blocked
+        in q.put or on a slot, and it shares the slots and the random streams with the next epoch's filler"""
+        st = getattr(self, '_active', None)
+        if st is None:
+            return
+        stop, th, q = st
+        stop.set()
+        for slot in self._slots:
+            slot.free.set()                                          # wake a filler waiting for a slot
+        while th.is_alive():
+            try:
+                q.get_nowait()                                       # make room for a filler blocked in q.put
+            except queue.Empty:
+                pass
+            th.join(timeout=0.01)
+        for slot in self._slots:                                     # uploads already queued must finish before a slot is refilled
+            if slot.event is not None:
+                slot.event.synchronize()
+            slot.free.set()
+        self._active = None
+
     def __iter__(self):
+        self._retire_worker()
         n = len(self.store)
         order = self.order_rng.permutation(n) if self.shuffle else np.arange(n)
         order = order[self.rank::self.world]
         nb = len(self)
         batches = [order[i * self.B:(i + 1) * self.B] for i in range(nb)]
         q = queue.Queue(maxsize=max(1, len(self._slots) - 1))
+        stop = threading.Event()
 
         def worker():
             try:
                 for i, ids in enumerate(batches):
                     slot = self._slots[i % len(self._slots)]
                     slot.free.wait()                                 # the consumer has queued this slot's previous upload ...
+                    if stop.is_set():
+                        return
                     slot.free.clear()
                     if slot.event is not None:
                         slot.event.synchronize()                     # ... and the copy engine has finished reading it
                     q.put(self._fill(slot, ids))
+                    if stop.is_set():
+                        return
                 q.put(None)
             except BaseException as e:      # noqa: BLE001 -- surfaced in the consumer
                 q.put(e)
         th = threading.Thread(target=worker, daemon=True)
+        self._active = (stop, th, q)
         th.start()
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            yield self._to_device(item)
-        th.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield self._to_device(item)
+        finally:
+            self._retire_worker()           # normal end: the filler has returned; abandoned epoch (GeneratorExit): stop it

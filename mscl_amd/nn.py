@@ -560,10 +560,26 @@ class _BottleneckTrunk(nn.Module):
     def _stem(self):
         raise NotImplementedError
 
+    @torch.no_grad()
+    def forward_eval(self, x):
+        """the same trunk with BatchNorm in evaluation mode (running statistics), no autograd graph: what the reference's
+        evaluation pass runs after model.eval() (core/evaluation/eval_hooks.py:471-487; mscl_r50 ships evaluation=dict(interval=5))"""
+        conv, bn = _cb(self._stem())
+        x, _ = K.maxpool_hw_fwd(cba_eval(conv, bn, stem_input(conv, x), None, True))
+        outs = []
+        for li in range(1, 5):
+            for blk in getattr(self, f'layer{li}'):
+                (c1, b1), (c2, b2), (c3, b3) = _cb(blk.conv1), _cb(blk.conv2), _cb(blk.conv3)
+                a2 = cba_eval(c2, b2, cba_eval(c1, b1, x, None, True), None, True)
+                res = x if blk.downsample is None else cba_eval(*_cb(blk.downsample), x, None, False)
+                x = cba_eval(c3, b3, a2, res, True)
+            outs.append(x)
+        return outs
+
     def forward(self, x, bn_groups=1):
         _need_gpu(x)
         if not self.training:
-            raise MsclError('the Bottleneck trunks implement training-mode BatchNorm only (both MoCo encoders run in train())')
+            return self.forward_eval(x)        # running statistics: the groups of a batch are normalised alike
         if x.shape[0] % bn_groups:
             raise ValueError(f'batch of {x.shape[0]} does not split into {bn_groups} BatchNorm groups')
         if self._anchor is None or self._anchor.device != x.device:

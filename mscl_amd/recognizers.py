@@ -569,13 +569,18 @@ class _MSCLLossFn(torch.autograd.Function):
         elif Cf != C:
             raise ValueError(f'LMCL needs equal channel counts (rgb {C}, flow {Cf}) or a flow transform (bkb_channels)')
         lsum, hits, dpr, dpf = K.lmcl(p_rgb.view(B, t, C), flow, 1.0 / model.sup_head.T)
+        ctx.trans_rt = None
         if trans is not None:
-            # the transform's parameter gradients go straight into the arena, as every parameter gradient does; they are
-            # scaled by the incoming gradient of the loss node only through dpf below, which backward() multiplies by g
-            # (g == 1 on the training path: the total loss is what .backward() is called on)
-            dpf = K.linear_bwd(flow_in, trt['w'], flow.view(B * 2 * t, C), dpf.view(B * 2 * t, C).contiguous(), trt['dw'], trt['db'], False)
-            trt['slot_w'].touched = True
-            trt['slot_b'].touched = True
+            # The transform's parameter gradients are STAGED here and added into the arena by backward(): the step drivers follow
+            # mmcv's order -- train_step, optimizer.zero_grad(), loss.backward() (OptimizerHook.after_train_iter) -- so anything
+            # written into the arena during the forward is wiped before backward runs (round-2 advisor finding: the transform
+            # trained on weight decay alone).
+            stage = trt.get('stage')
+            if stage is None or stage[0].device != dev:
+                stage = trt['stage'] = (torch.empty_like(trt['dw']), torch.empty_like(trt['db']))
+            stage[0].zero_(); stage[1].zero_()
+            dpf = K.linear_bwd(flow_in, trt['w'], flow.view(B * 2 * t, C), dpf.view(B * 2 * t, C).contiguous(), stage[0], stage[1], False)
+            ctx.trans_rt = trt
 
         def grp(v, i):
             return v[i * B:(i + 1) * B]
@@ -597,6 +602,12 @@ class _MSCLLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _glogs):
         grads = tuple(g * t for t in ctx.saved_tensors)
+        trt = ctx.trans_rt
+        if trt is not None:                  # LMCL flow transform (mscl_r50): parameter gradients into the arena, scaled by g
+            trt['dw'].add_(trt['stage'][0] * g)
+            trt['db'].add_(trt['stage'][1] * g)
+            trt['slot_w'].touched = True
+            trt['slot_b'].touched = True
         return grads + (None, None, None, None)
 
 
@@ -688,6 +699,11 @@ class MSCLWithAug(nn.Module):
                 if buf is not None:
                     mod._buffers[bname] = buf.to(device)
         self.arena = ar
+        # base || rotated flow query clips in one pass: only the TRUNK keeps one set of BatchNorm statistics per call, so the flow
+        # neck must be parameter- and buffer-free (BaseMoCo: global average pool); anything else takes the two reference passes
+        nq = self.recognizer_flow.neck_q
+        if self.flow_batch and (any(True for _ in nq.parameters()) or any(True for _ in nq.buffers())):
+            self.flow_batch = False
         for name, rec in (('rgb', self.recognizer), ('flow', self.recognizer_flow)):
             rec._arena, rec._range = ar, tuple(ar.ranges[name])
             rec._k_refresh, rec._q_refresh = [], []

@@ -163,14 +163,17 @@ def set_random_seed(seed, deterministic=False):
 
 
 def train(model, optimizer, batches, total_epochs, base_lr=None, min_lr=0.0, start_epoch=0, log=None, step_fn=None,
-          log_interval=None, work_dir=None, checkpoint_interval=None, val_batches=None, eval_interval=1, cfg=None):
+          log_interval=None, work_dir=None, checkpoint_interval=None, val_batches=None, eval_interval=1, cfg=None, start_iter=0):
     """`batches`: callable epoch -> iterable of data_batch dicts (device tensors).  Returns the last log_vars.
     step_fn(data_batch) -> (loss, log_vars) may be a mscl_amd.graph.GraphedStep(...).step for graph replay.
     cfg (a loaded config): fills log_interval / checkpoint_interval / min_lr from `log_config`, `checkpoint_config` and
     `lr_config` unless given.  log(epoch, it, log_vars): called per record when log_interval is set (mean over the
     interval, mmcv's cadence), else per iteration with that iteration's values.  work_dir: `epoch_{n}.pth` every
     checkpoint_interval epochs (mmcv CheckpointHook naming) and `latest.pth`.  val_batches: callable epoch -> iterable;
-    evaluated every eval_interval epochs (EvalHook `interval`, by_epoch), results passed to log(epoch, 'val', res)."""
+    evaluated every eval_interval epochs (EvalHook `interval`, by_epoch), results passed to log(epoch, 'val', res).
+    start_iter: the global iteration count so far (mmcv's runner.iter; pass `resume(...)['iter']` after a resume) -- checkpoints
+    store the running count, whatever the epoch lengths were.  Records of fewer than log_interval iterations at the end of an
+    epoch are dropped, as mmcv's LoggerHook does with its default ignore_last=True."""
     if cfg is not None:
         if log_interval is None and log is not None:
             log_interval = (cfg.get('log_config') or {}).get('interval')
@@ -180,6 +183,7 @@ def train(model, optimizer, batches, total_epochs, base_lr=None, min_lr=0.0, sta
     base_lr = optimizer.param_groups[0]['lr'] if base_lr is None else base_lr
     buf = LogBuffer(log_interval) if (log is not None and log_interval) else None
     last = None
+    global_iter = int(start_iter)
     for epoch in range(start_epoch, total_epochs):
         optimizer.param_groups[0]['lr'] = cosine_lr(base_lr, epoch, total_epochs, min_lr)
         it = -1
@@ -193,6 +197,7 @@ def train(model, optimizer, batches, total_epochs, base_lr=None, min_lr=0.0, sta
                 out['loss'].backward()
                 optimizer.step()
                 last = out['log_vars']
+            global_iter += 1
             if buf is not None:
                 buf.update(last)
                 if buf.ready(it):
@@ -204,7 +209,7 @@ def train(model, optimizer, batches, total_epochs, base_lr=None, min_lr=0.0, sta
         if work_dir is not None and checkpoint_interval and (epoch + 1) % checkpoint_interval == 0 and parallel.rank() == 0:
             os.makedirs(work_dir, exist_ok=True)
             path = os.path.join(work_dir, f'epoch_{epoch + 1}.pth')
-            save_checkpoint(path, model, optimizer, epoch=epoch + 1, it=(epoch + 1 - start_epoch) * (it + 1))
+            save_checkpoint(path, model, optimizer, epoch=epoch + 1, it=global_iter)
             latest = os.path.join(work_dir, 'latest.pth')
             if os.path.lexists(latest):
                 os.remove(latest)

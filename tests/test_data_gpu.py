@@ -136,3 +136,32 @@ def test_loader_end_to_end_vs_oracle_pipeline(dev, tmp_path):
                                    dict(type='MoCoResize', scale=(32, 32))])
     vb = next(iter(ClipPairLoader(store, vpipe, B, dev, seed=7, shuffle=False)))
     assert tuple(vb['imgs'][0].shape) == (B, 3, T, 32, 32) and tuple(vb['flow_imgs'][1].shape) == (B, 2, 2 * T, 32, 32)
+
+
+def test_loader_abandoned_epoch_and_short_last_batch(dev, tmp_path):
+    """(round-2 advisor) a consumer that leaves an epoch early must not strand the filler thread on the pinned slots or the random
+    streams: the next epoch starts clean and yields every batch; with drop_last=False the short last batch carries its own rows
+    only (labels, frames and boxes of equal length)."""
+    from mscl_amd import Config
+    from mscl_amd.data import ClipPairLoader, MSCLPipeline
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    T, B, hw, fhw = 4, 2, (40, 52), (20, 26)
+    store, vids = _make_store(str(tmp_path / 'store'), 7, 120, hw, fhw, seed=2)
+    steps = [dict(s) for s in cfg.train_pipeline]
+    for s in steps:
+        if s['type'] == 'TemporalShiftChosenSampleFrames':
+            s.update(clip_len=T, frame_interval=2)
+        if s['type'] == 'MoCoResize':
+            s.update(scale=(32, 32))
+    pipe = MSCLPipeline.from_cfg(steps)
+    loader = ClipPairLoader(store, pipe, B, dev, seed=3, shuffle=False, drop_last=False, slots=2)
+    assert len(loader) == 4
+    for i, batch in enumerate(loader):          # walk away after the first batch: the filler is mid-epoch, blocked on a slot / the queue
+        break
+    full = list(loader)                         # would deadlock (or race the old filler) without the retire step
+    assert [len(b['label']) for b in full] == [2, 2, 2, 1]
+    last = full[-1]
+    assert tuple(last['imgs'][0].shape) == (1, 3, T, 32, 32) and tuple(last['flow_imgs'][1].shape) == (1, 2, 2 * T, 32, 32)
+    assert last['label'].tolist() == [vids[6]['label']]
+    assert loader._active is None
