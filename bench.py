@@ -126,7 +126,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        if 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+            raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        # called bare with --gpus N > 1: start the N ranks ourselves (one process per GPU over RCCL, as the driver's own launch line
+        # does) as a CHILD of this process, before anything here has touched the GPU, and pass its output and exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     # the GPU path needs no CPU parallelism; 128 OpenMP workers spin-waiting beside the launching thread only cost (a one-GPU job
@@ -261,6 +272,8 @@ def main():
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                          'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': traffic,
                          'traffic_unit': f'HBM bytes per launch (rocprofv3 PMC, profiles/{tname})',
+                         'traffic_source': 'file' if traffic is not None else None,       # read from the committed PMC summary, not measured in this run
+
                          'algorithmic_bytes': 2 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 2 + 64 * 27 * 64 * 2,
                          # the whole step against the same peak: executed conv GFLOP of one step / timed step duration
                          'step_gflop': round(STEP_GFLOP_EXECUTED, 1), 'step_gflop_reference': round(STEP_GFLOP_REFERENCE, 1),

@@ -56,6 +56,8 @@ int mscl_set_halo_off(int off);
 /* test aid: number of launches the ping-pong shared-tap conv kernel (conv_pp.hip) has taken in this process, so that a parity
  * test can assert which kernel family produced the result it checked */
 int64_t mscl_debug_pp_launches(void);
+/* the same for the persistent window-resident 64 -> 64 kernel (conv_win64.hip) */
+int64_t mscl_debug_win64_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);
 /* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order:

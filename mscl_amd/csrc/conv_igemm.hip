@@ -677,6 +677,15 @@ static int check_desc(const mscl_conv_desc* d) {
 
 extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream);
+extern "C" int mscl_conv_win64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
+                               const uint16_t* addend, float* ssum, float* ssq, void* stream);
+// persistent window-resident ping-pong kernel for 64 -> 64 (conv_win64.hip); MSCL_WIN64=0 falls back to conv_halo.hip
+static bool win64_enabled(const mscl_conv_desc* d) {
+  const char* e = getenv("MSCL_WIN64");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '2') return true;                        // forced (tests: small planes too)
+  return (e && e[0] == '1') && (long)d->H * (d->W + 2) >= 1024;
+}
 // layer-1 shape (3x3x3 s1 p1, 64 -> 64): halo-resident kernel, 131 / 109 us vs 156 / 135 us (fwd / dgrad) for the
 // implicit-GEMM kernel; MSCL_HALO=0 switches it off
 static int g_halo_off = 0;       // experiment switch (mscl_set_halo_off): the next launches skip the window-resident layer-1 kernel
@@ -710,6 +719,10 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
     if (e) return e;
     return mscl_bn_stats(y, ssum, ssq, (int64_t)d->N * d->To * d->Ho * d->Wo, d->K, stat_groups, stream);
   }
+  if (stat_groups == 1 && bias == nullptr && !relu && win64_enabled(d)) {
+    const int h = mscl_conv_win64(d, 0, x, w, y, addend, ssum, ssq, stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
   if (stat_groups == 1 && bias == nullptr && !relu && halo_enabled(d)) {   // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
     const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
     if (h != 0) return h == 1 ? 0 : h;
@@ -730,6 +743,10 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
                                  const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!dy || !wT || !dx) return MSCL_E_ARG;
+  if (win64_enabled(d)) {
+    const int h = mscl_conv_win64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
   if (halo_enabled(d)) {
     const int h = mscl_conv_halo64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
     if (h != 0) return h == 1 ? 0 : h;

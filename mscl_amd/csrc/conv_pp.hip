@@ -45,10 +45,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;
   constexpr int UB = BN / 64;                     // DMA instructions per thread per weight tile (64 rows per pass of 512 threads)
   constexpr int A_BASE = NB * B_SLOT;             // weight ring first: the row "-1" read of position fragment 0 stays inside LDS
-  constexpr int WAVES_N = 2, WM = 64, WN = BN / WAVES_N;
+  // 8 waves: 4 (positions) x 2 (channels) of 64 x 64 at BN = 128; 8 x 1 of 32 x 64 at BN = 64
+  constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, WM = BM / WAVES_M, WN = 64;
   constexpr int IM = WM / 16, JN = WN / 16;
   constexpr unsigned OOB = 0x80000000u;
-  static_assert(BN == 128, "tile config");
+  static_assert((BN == 128 || BN == 64) && JN == 4 && (IM == 4 || IM == 2), "tile config");
 
   if constexpr (EXP == 10) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -71,7 +72,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   const int bias_bytes = (mode == 0 ? padlin : maxlin) * cs2;
 
   const int rg = tid & 7, rr = tid >> 3;          // granule column / row inside a 64-row staging pass
-  const int rgl = rg ^ (rr & 7);                  // logical granule this lane fetches: LDS image is [row][granule ^ (row & 7)]
+  const int swzm = g.lsT;                         // PROBE: swizzle key 0 row&7, 1 (row>>1)&7, 2 none, 3 (row&3)<<1|((row>>2)&1)
+  auto skey = [&](int row) { return swzm == 0 ? (row & 7) : swzm == 1 ? ((row >> 1) & 7) : swzm == 2 ? 0 : (((row & 3) << 1) | ((row >> 2) & 1)); };
+  const int rgl = rg ^ skey(rr);                  // logical granule this lane fetches: LDS image is [row][granule ^ (row & 7)]
   unsigned wrow_voff[UB];
 #pragma unroll
   for (int p = 0; p < UB; ++p) {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
     row_voff[p] = base * cs2 + (mode == 0 ? bias_bytes : 0) + rgl * 16;      // >= 0 for every row with a valid tap
     row_mask[p] = mask;
   }
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fq = lane >> 4;
   f32x4_t acc[JN][IM];
 #pragma unroll
@@ -148,12 +151,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int row = wm0 + fr + (mode == 0 ? kw - HALO : HALO - kw);        // may be -1 / 256 on the two rows that are not stored
-      a_off[kw][ks] = lds_base + A_BASE + (unsigned)(row * 128 + (((ks * 4 + fq) ^ (row & 7)) * 16));
+      a_off[kw][ks] = lds_base + A_BASE + (unsigned)(row * 128 + (((ks * 4 + fq) ^ skey(row)) * 16));
     }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int row = wn0 + fr;
-    b_off[ks] = lds_base + (unsigned)(row * 128 + (((ks * 4 + fq) ^ (row & 7)) * 16));
+    b_off[ks] = lds_base + (unsigned)(row * 128 + (((ks * 4 + fq) ^ skey(row)) * 16));
   }
 
   auto issue_a = [&](int half, unsigned slot, unsigned soff, int tb) {     // rows [128 half, 128 half + 128) of a position tile
@@ -180,7 +183,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   if constexpr (EXP == 2 || EXP == 5 || EXP == 7 || EXP == 8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      fa[0][i] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; fa[1][i] = fa[0][i]; fb[0][i] = fa[0][i]; fb[1][i] = fa[0][i];
+      fb[0][i] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; fb[1][i] = fb[0][i];
+      if (i < IM) { fa[0][i] = fb[0][i]; fa[1][i] = fb[0][i]; }
     }
   }
   for (int gi = g_beg; gi < (EXP == 9 || EXP == 11 || EXP == 12 ? g_beg : g_end); ++gi) {
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const unsigned aa = a_off[kw][ks] + a_cur, ba = b_off[ks] + bslot;
-          PP_DSR(fa[ks][0], aa, 0); PP_DSR(fa[ks][1], aa, 2048); PP_DSR(fa[ks][2], aa, 4096); PP_DSR(fa[ks][3], aa, 6144);
+          PP_DSR(fa[ks][0], aa, 0); PP_DSR(fa[ks][1], aa, 2048);
+          if constexpr (IM == 4) { PP_DSR(fa[ks][2], aa, 4096); PP_DSR(fa[ks][3], aa, 6144); }
           PP_DSR(fb[ks][0], ba, 0); PP_DSR(fb[ks][1], ba, 2048); PP_DSR(fb[ks][2], ba, 4096); PP_DSR(fb[ks][3], ba, 6144);
         }
       }
@@ -211,17 +216,22 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
         if constexpr (kw == 0) PP_VMCNT(UB);
         if constexpr (kw == 1) PP_VMCNT(0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]),
-                     "+v"(fb[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1]),
-                     "+v"(fb[1][2]), "+v"(fb[1][3]));
+      if constexpr (IM == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]),
+                       "+v"(fb[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1]),
+                       "+v"(fb[1][2]), "+v"(fb[1][3]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fa[1][0]),
+                       "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---- M: one 64 x 64 x 64 product ----
       __builtin_amdgcn_s_setprio(1);
       if constexpr (EXP == 3 || (EXP >= 5 && EXP != 8)) {
 #pragma unroll
-        for (int i = 0; i < IM; ++i) { asm volatile("" ::"v"(fa[0][i])); asm volatile("" ::"v"(fb[0][i])); asm volatile("" ::"v"(fa[1][i])); asm volatile("" ::"v"(fb[1][i])); }
+        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fb[0][i])); asm volatile("" ::"v"(fb[1][i])); if (i < IM) { asm volatile("" ::"v"(fa[0][i])); asm volatile("" ::"v"(fa[1][i])); } }
       } else
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -270,10 +280,11 @@ extern "C" int64_t mscl_debug_pp_launches(void) { return g_pp_launches; }     //
 // Returns 0 when launched, MSCL_PP_SKIP when the shape is outside this kernel (the caller falls back to conv_igemm.hip).
 int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias, const bf16_t* addend,
                         float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
-  constexpr int BN = 128, OUT_ROWS = 254;
+  constexpr int OUT_ROWS = 254;
+  const int BN = (g.Cr % 128 == 0) ? 128 : 64;
   if (g.mode == 2 || g.nclass != 0 || g.grp_rows != 0) return MSCL_PP_SKIP;
   if (g.kW != 3 || g.pW != 1 || g.sW != 1 || g.Wr != g.Ws) return MSCL_PP_SKIP;
-  if (g.cgs < 3 || (g.Cs & 63) != 0 || (g.Cr % BN) != 0) return MSCL_PP_SKIP;
+  if (g.cgs < 3 || (g.Cs & 63) != 0 || (g.Cr % 64) != 0) return MSCL_PP_SKIP;
   if (g.kT > 8 || g.kH > 8) return MSCL_PP_SKIP;
   const long span = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
   if (span >= (1L << 31) || (long)g.Cr * g.KG * 16 >= (1L << 31)) return MSCL_PP_SKIP;
@@ -282,6 +293,7 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   g.M = (int)Mp;
   g.dW = make_fastdiv(g.Wr + 2);
   g.dKH = make_fastdiv(g.kH);
+  { const char* e = getenv("MSCL_PP_SWZ"); g.lsT = e ? atoi(e) : 0; }
   g.mtiles = (int)((Mp + OUT_ROWS - 1) / OUT_ROWS);
   g.ntiles = g.Cr / BN;
   const long blocks = (long)g.mtiles * g.ntiles;
@@ -302,6 +314,7 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   }
   float* partial = g.ksplit > 1 ? ws : nullptr;
   const size_t lds = 4 * (size_t)BN * 128 + 2 * 256 * 128;
+  const bool n64 = BN == 64;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(512), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu,
@@ -309,19 +322,20 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   };
   const char* ex = getenv("MSCL_PP_EXP");
   const int exp_ = ex ? atoi(ex) : 0;
-  if (exp_ == 1) go(conv_pp_kernel<BN, 1>);
-  else if (exp_ == 2) go(conv_pp_kernel<BN, 2>);
-  else if (exp_ == 3) go(conv_pp_kernel<BN, 3>);
-  else if (exp_ == 4) go(conv_pp_kernel<BN, 4>);
-  else if (exp_ == 5) go(conv_pp_kernel<BN, 5>);
-  else if (exp_ == 6) go(conv_pp_kernel<BN, 6>);
-  else if (exp_ == 7) go(conv_pp_kernel<BN, 7>);
-  else if (exp_ == 8) go(conv_pp_kernel<BN, 8>);
-  else if (exp_ == 9) go(conv_pp_kernel<BN, 9>);
-  else if (exp_ == 10) go(conv_pp_kernel<BN, 10>);
-  else if (exp_ == 11) go(conv_pp_kernel<BN, 11>);
-  else if (exp_ == 12) go(conv_pp_kernel<BN, 12>);
-  else go(conv_pp_kernel<BN, 0>);
+  if (n64) go(conv_pp_kernel<64, 0>);
+  else if (exp_ == 1) go(conv_pp_kernel<128, 1>);
+  else if (exp_ == 2) go(conv_pp_kernel<128, 2>);
+  else if (exp_ == 3) go(conv_pp_kernel<128, 3>);
+  else if (exp_ == 4) go(conv_pp_kernel<128, 4>);
+  else if (exp_ == 5) go(conv_pp_kernel<128, 5>);
+  else if (exp_ == 6) go(conv_pp_kernel<128, 6>);
+  else if (exp_ == 7) go(conv_pp_kernel<128, 7>);
+  else if (exp_ == 8) go(conv_pp_kernel<128, 8>);
+  else if (exp_ == 9) go(conv_pp_kernel<128, 9>);
+  else if (exp_ == 10) go(conv_pp_kernel<128, 10>);
+  else if (exp_ == 11) go(conv_pp_kernel<128, 11>);
+  else if (exp_ == 12) go(conv_pp_kernel<128, 12>);
+  else go(conv_pp_kernel<128, 0>);
   MSCL_LAUNCH_CHECK();
   ++g_pp_launches;
   if (g.ksplit > 1) return mscl_launch_splitk_finalize(partial, out, bias, addend, relu, ssum, ssq, out_elems / g.Cr, g.Cr, g.ksplit, 0, st);

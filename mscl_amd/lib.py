@@ -34,6 +34,7 @@ _SIGS = {
     'mscl_set_deterministic': [c_int],
     'mscl_set_halo_off': [c_int],
     'mscl_debug_pp_launches': [],
+    'mscl_debug_win64_launches': [],
     'mscl_get_deterministic': [],
     'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P],
     'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],
@@ -86,7 +87,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches')
+_INT64_RESULT = ('mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches')
 EXPORTS = tuple(_SIGS)
 
 _lib = None

@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -390,3 +391,26 @@ def test_augmentation_draws_match_reference_golden():
     rows = aug.draw(16)['aug_params'][0]
     sig = {round(float(v), 6) for v in rows[:, 10] if float(v) > 0}
     assert len(sig) == 1 and 0.1 <= next(iter(sig)) <= 2.0 and set(rows[:, 0].tolist()) <= {0.0, 1.0}
+
+
+def test_bench_called_bare_with_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a torch.distributed.run environment must still measure: it starts the N ranks itself as a
+    child process (127.0.0.1 rendezvous, its own arguments passed through) before touching the GPU, and exits with the child's code"""
+    import subprocess
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, 'call', lambda cmd: calls.append(cmd) or 7)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '3'])
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd = calls[0]
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd and '127.0.0.1' in cmd
+    assert cmd[-4:] == ['--gpus', '2', '--steps', '3'] and cmd[-5].endswith('bench.py')
+    # under a launcher whose world size disagrees it still refuses
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=4' in str(e.value.code)

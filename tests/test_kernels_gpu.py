@@ -144,6 +144,9 @@ PP_CASES = [
     ('pp_fpn_133', 1, 4, 10, 10, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), 1),
     ('pp_128_256_s221', 2, 4, 12, 12, 128, 256, (3, 3, 3), (2, 2, 1), (1, 1, 1), 1),
     ('pp_w28', 1, 2, 28, 28, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
+    ('pp_64_64', 2, 3, 13, 11, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),            # 64 output channels: the 8 x 1 wave layout
+    ('pp_64_64_plane56', 1, 3, 56, 56, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
+    ('pp_128_64', 1, 3, 9, 10, 128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1),
 ]
 
 
@@ -152,6 +155,7 @@ def test_conv_pp_forced(case, dev, monkeypatch):
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K, kern, stride, pad, ksplit = case
     monkeypatch.setenv('MSCL_PP', '2')
+    monkeypatch.setenv('MSCL_HALO', '0')          # (the window-resident layer-1 kernel would take the 64 -> 64 cases first)
     if ksplit:
         monkeypatch.setenv('MSCL_PP_KSPLIT', str(ksplit))
     x = bf(rnd((N, T, H, W, C), 11)); w = bf(rnd((K, *kern, C), 12, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
@@ -177,11 +181,63 @@ def test_conv_pp_forced(case, dev, monkeypatch):
         n1 = lib.call_raw('mscl_debug_pp_launches')
         add = bf(rnd(tuple(x.shape), 16))
         dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
-        assert lib.call_raw('mscl_debug_pp_launches') == n1 + (C % 128 == 0), 'the input gradient did not take the ping-pong kernel'
+        assert lib.call_raw('mscl_debug_pp_launches') == n1 + (C % 64 == 0), 'the input gradient did not take the ping-pong kernel'
         close(dx, xr.grad + add.float(), BF16_TOL, 'pp dgrad+addend')
     # the same launches again, many times: a race between the LDS-DMA ring and the fragment reads shows as a changed output
     y0 = K_.conv3d_fwd(xg, wg, d)
     for _ in range(20):
+        assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
+
+
+# conv_win64.hip (persistent window-resident ping-pong kernel, 64 -> 64, 3x3 in plane): tiles that straddle planes and samples,
+# a map smaller than one tile, more tiles than blocks would need on a small grid (the persistent walk), kT = 1, the widest plane
+# (W = 61), the real layer-1 map (1654 tiles over 256 blocks: 6-7 tiles per block, windows prefetched across tile boundaries).
+WIN64_CASES = [
+    ('win64_small', 2, 3, 13, 11, (3, 3, 3), (1, 1, 1)),
+    ('win64_tail', 3, 5, 13, 11, (3, 3, 3), (1, 1, 1)),
+    ('win64_tiny', 1, 2, 5, 6, (3, 3, 3), (1, 1, 1)),
+    ('win64_plane56', 1, 3, 56, 56, (3, 3, 3), (1, 1, 1)),
+    ('win64_133', 2, 4, 14, 14, (1, 3, 3), (0, 1, 1)),
+    ('win64_w61', 1, 2, 10, 61, (3, 3, 3), (1, 1, 1)),
+    ('win64_many_tiles', 6, 16, 56, 56, (3, 3, 3), (1, 1, 1)),
+    ('win64_layer1', 8, 16, 56, 56, (3, 3, 3), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('case', WIN64_CASES, ids=[c[0] for c in WIN64_CASES])
+def test_conv_win64_forced(case, dev, monkeypatch):
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, kern, pad = case
+    C = K = 64
+    stride = (1, 1, 1)
+    monkeypatch.setenv('MSCL_WIN64', '2')
+    x = bf(rnd((N, T, H, W, C), 21)); w = bf(rnd((K, *kern, C), 22, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
+    d = K_.conv_desc(x.shape, K, kern, stride, pad)
+    xg, wg = x.to(dev), w.to(dev)
+    n0 = lib.call_raw('mscl_debug_win64_launches')
+    st = torch.zeros((K_.STAT_SLOTS, 2, K), device=dev)
+    y = K_.conv3d_fwd(xg, wg, d, stats=(st[0, 0], st[0, 1]))
+    assert lib.call_raw('mscl_debug_win64_launches') == n0 + 1, 'the forward did not take the window kernel'
+    xr = x.float().requires_grad_(True); wr = w.float()
+    yr = _conv_ref(xr, wr, stride, pad)
+    close(y, yr, BF16_TOL, 'win64 fwd')
+    close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'win64 bn sum')
+    close(st[:, 1].sum(0), (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'win64 bn sumsq')
+    a = bf(rnd(tuple(yr.shape), 24))
+    y2 = K_.conv3d_fwd(xg, wg, d, addend=a.to(dev))
+    close(y2, yr.detach() + a.float(), BF16_TOL, 'win64 fwd + addend')
+    dy = bf(rnd(tuple(yr.shape), 25))
+    yr.backward(dy.float())
+    wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(wg, wT, K, int(np.prod(kern)), C)
+    add = bf(rnd(tuple(x.shape), 26))
+    n1 = lib.call_raw('mscl_debug_win64_launches')
+    dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
+    assert lib.call_raw('mscl_debug_win64_launches') == n1 + 1, 'the input gradient did not take the window kernel'
+    close(dx, xr.grad + add.float(), BF16_TOL, 'win64 dgrad + addend')
+    # race screen: the outputs (not the atomically summed statistics) are a fixed function of the inputs
+    y0 = K_.conv3d_fwd(xg, wg, d)
+    for _ in range(10):
         assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
 
 

@@ -12,6 +12,9 @@ from mscl_amd import kernels as K  # noqa: E402
 SHAPES = [
     # name, (N,T,H,W,C), K, kernel, stride, pad
     ('l1_64_64', (8, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('l1n1_64_64', (1, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # 207 / 414 / 827 tiles: per-tile cost of the persistent layer-1 kernel
+    ('l1n2_64_64', (2, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('l1n4_64_64', (4, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('l2_64_128_s2', (8, 16, 56, 56, 64), 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     ('l2_128_128', (8, 8, 28, 28, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('l3_128_256_s2', (8, 8, 28, 28, 128), 256, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
