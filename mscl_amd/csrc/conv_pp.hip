@@ -33,10 +33,7 @@ template <int N> struct IC { static constexpr int value = N; };
 #define PP_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
 #define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
 
-// EXP (timing probes, wrong results): 1 no DMA inside the loop, 2 no fragment reads, 3 no MFMAs, 4 no stagger,
-// 5 DMA + barriers only, 6 fragment reads + barriers only, 7 barriers only, 8 MFMAs + barriers only, 9 no loop at all,
-// 10 return at once (launch cost), 11 no loop and no epilogue (set-up + first group's DMA), 12 no loop, epilogue without stores
-template <int BN, int EXP>
+template <int BN>
 __global__ __launch_bounds__(512) void conv_pp_kernel(
     const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
     const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
@@ -51,7 +48,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   constexpr unsigned OOB = 0x80000000u;
   static_assert((BN == 128 || BN == 64) && JN == 4 && (IM == 4 || IM == 2), "tile config");
 
-  if constexpr (EXP == 10) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
 
@@ -72,9 +68,11 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   const int bias_bytes = (mode == 0 ? padlin : maxlin) * cs2;
 
   const int rg = tid & 7, rr = tid >> 3;          // granule column / row inside a 64-row staging pass
-  const int swzm = g.lsT;                         // PROBE: swizzle key 0 row&7, 1 (row>>1)&7, 2 none, 3 (row&3)<<1|((row>>2)&1)
-  auto skey = [&](int row) { return swzm == 0 ? (row & 7) : swzm == 1 ? ((row >> 1) & 7) : swzm == 2 ? 0 : (((row & 3) << 1) | ((row >> 2) & 1)); };
-  const int rgl = rg ^ skey(rr);                  // logical granule this lane fetches: LDS image is [row][granule ^ (row & 7)]
+  // LDS images are [row][granule ^ (row & 7)]: conflict-free ds_read_b128 fragments under the -1 / 0 / +1 row shifts of the shared
+  // taps (measured against (row >> 1) & 7, which the two-barrier kernels use: 2-way conflicts on the odd shifts, +16 % on the
+  // read-only loop; no swizzle: 3.3x)
+  auto skey = [&](int row) { return row & 7; };
+  const int rgl = rg ^ skey(rr);                  // logical granule this lane fetches
   unsigned wrow_voff[UB];
 #pragma unroll
   for (int p = 0; p < UB; ++p) {
@@ -177,80 +175,80 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   issue_a(1, 0, soff_n, tb_n);
   PP_VMCNT(0);
   __builtin_amdgcn_s_barrier();
-  if (EXP != 4 && grp == 1) __builtin_amdgcn_s_barrier();     // the stagger
 
   u32x4_t fa[2][IM], fb[2][JN];
-  if constexpr (EXP == 2 || EXP == 5 || EXP == 7 || EXP == 8) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fb[0][i] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; fb[1][i] = fb[0][i];
-      if (i < IM) { fa[0][i] = fb[0][i]; fa[1][i] = fb[0][i]; }
-    }
-  }
-  for (int gi = g_beg; gi < (EXP == 9 || EXP == 11 || EXP == 12 ? g_beg : g_end); ++gi) {
-    const bool has_next = gi + 1 < g_end;
+  // per-group scalar state: weight ring slots of this group's tiles (bq, bq+1, bq+2 mod 4) and of the next group's (bq+3, bq,
+  // bq+1 mod 4), position slots, and the next group's SGPR offsets (has_next)
+  int gi = g_beg;
+  bool has_next = gi + 1 < g_end;
+  if (has_next) group_soff(gi + 1, soff_n, tb_n, woff_n);
+  auto advance = [&]() {
+    a_cur ^= (unsigned)A_SLOT;
+    bq = (bq + 3) & 3;
+    ++gi;
+    has_next = gi + 1 < g_end;
     if (has_next) group_soff(gi + 1, soff_n, tb_n, woff_n);
+  };
+  // ---- L: fragments of K tile kw of the current group, this wave's share of the next group's DMA, the counted wait; the
+  // fragment reads are retired before the section ends (rule R2) ----
+  auto Lsec = [&](auto PC) {
+    constexpr int kw = decltype(PC)::value;
     const unsigned a_nxt = a_cur ^ (unsigned)A_SLOT;
-    // weight slots of this group's tiles (bq, bq+1, bq+2 mod 4) and of the next group's (bq+3, bq, bq+1 mod 4)
     const unsigned bs1 = (bq + 1) & 3, bs2 = (bq + 2) & 3, bn0 = (bq + 3) & 3, bn1 = bq, bn2 = bs1;
-
-    auto phase = [&](auto PC) {
-      constexpr int kw = decltype(PC)::value;
-      // ---- L: fragments of this K tile, this wave's share of the next group's DMA, the counted wait ----
-      const unsigned bslot = (kw == 0 ? bq : (kw == 1 ? bs1 : bs2)) * (unsigned)B_SLOT;
-      if constexpr (EXP != 2 && EXP != 5 && EXP != 7 && EXP != 8) {
+    const unsigned bslot = (kw == 0 ? bq : (kw == 1 ? bs1 : bs2)) * (unsigned)B_SLOT;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const unsigned aa = a_off[kw][ks] + a_cur, ba = b_off[ks] + bslot;
-          PP_DSR(fa[ks][0], aa, 0); PP_DSR(fa[ks][1], aa, 2048);
-          if constexpr (IM == 4) { PP_DSR(fa[ks][2], aa, 4096); PP_DSR(fa[ks][3], aa, 6144); }
-          PP_DSR(fb[ks][0], ba, 0); PP_DSR(fb[ks][1], ba, 2048); PP_DSR(fb[ks][2], ba, 4096); PP_DSR(fb[ks][3], ba, 6144);
-        }
-      }
-      if constexpr (EXP == 1 || EXP == 6 || EXP == 7 || EXP == 8) {
-      } else if (has_next) {
-        if constexpr (kw == 0) { issue_a(0, a_nxt, soff_n, tb_n); issue_a(1, a_nxt, soff_n, tb_n); PP_VMCNT(UB + 4); }
-        if constexpr (kw == 1) { issue_b(bn0 * B_SLOT, woff_n); issue_b(bn1 * B_SLOT, woff_n + wstep); PP_VMCNT(2 * UB + 4); }
-        if constexpr (kw == 2) { issue_b(bn2 * B_SLOT, woff_n + 2 * wstep); PP_VMCNT(2 * UB); }
-      } else {
-        if constexpr (kw == 0) PP_VMCNT(UB);
-        if constexpr (kw == 1) PP_VMCNT(0);
-      }
-      if constexpr (IM == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]),
-                       "+v"(fb[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1]),
-                       "+v"(fb[1][2]), "+v"(fb[1][3]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fa[1][0]),
-                       "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- M: one 64 x 64 x 64 product ----
-      __builtin_amdgcn_s_setprio(1);
-      if constexpr (EXP == 3 || (EXP >= 5 && EXP != 8)) {
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned aa = a_off[kw][ks] + a_cur, ba = b_off[ks] + bslot;
+      PP_DSR(fa[ks][0], aa, 0); PP_DSR(fa[ks][1], aa, 2048);
+      if constexpr (IM == 4) { PP_DSR(fa[ks][2], aa, 4096); PP_DSR(fa[ks][3], aa, 6144); }
+      PP_DSR(fb[ks][0], ba, 0); PP_DSR(fb[ks][1], ba, 2048); PP_DSR(fb[ks][2], ba, 4096); PP_DSR(fb[ks][3], ba, 6144);
+    }
+    if (has_next) {
+      if constexpr (kw == 0) { issue_a(0, a_nxt, soff_n, tb_n); issue_a(1, a_nxt, soff_n, tb_n); PP_VMCNT(UB + 4); }
+      if constexpr (kw == 1) { issue_b(bn0 * B_SLOT, woff_n); issue_b(bn1 * B_SLOT, woff_n + wstep); PP_VMCNT(2 * UB + 4); }
+      if constexpr (kw == 2) { issue_b(bn2 * B_SLOT, woff_n + 2 * wstep); PP_VMCNT(2 * UB); }
+    } else {
+      if constexpr (kw == 0) PP_VMCNT(UB);
+      if constexpr (kw == 1) PP_VMCNT(0);
+    }
+    if constexpr (IM == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]),
+                     "+v"(fb[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[1][0]), "+v"(fb[1][1]),
+                     "+v"(fb[1][2]), "+v"(fb[1][3]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fa[1][0]),
+                     "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- M: one WM x 64 x 64 product from the fragments the last L section read ----
+  auto Msec = [&]() {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fb[0][i])); asm volatile("" ::"v"(fb[1][i])); if (i < IM) { asm volatile("" ::"v"(fa[0][i])); asm volatile("" ::"v"(fa[1][i])); } }
-      } else
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int j = 0; j < JN; ++j)
-#pragma unroll
-          for (int i = 0; i < IM; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb[ks][j]),
-                                                                __builtin_bit_cast(bf16x8_t, fa[ks][i]), acc[j][i], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_s_barrier();
-    };
-    phase(IC<0>{}); phase(IC<1>{}); phase(IC<2>{});
-    a_cur = a_nxt;
-    bq = bn0;
+        for (int i = 0; i < IM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb[ks][j]),
+                                                              __builtin_bit_cast(bf16x8_t, fa[ks][i]), acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int ng = g_end - g_beg;
+  // Two barriers per phase: [L | barrier | M | barrier], waves 4-7 one barrier behind.  (Measured and dropped: ONE barrier per
+  // phase with the second group's sections rotated -- waves 0-3 [L_p M_p | barrier], waves 4-7 [M_{p-1} L_p | barrier] -- which
+  // would make an interval L + M instead of 2 max(L, M): 52.4 vs 46.9 us on the 128 -> 128 layer, slower on every shape; without
+  // the barrier between the sections the partners of a SIMD drift into loading together and multiplying together.)
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int n = 0; n < ng; ++n) {
+    Lsec(IC<0>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
+    Lsec(IC<1>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
+    Lsec(IC<2>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
+    advance();
   }
-  if (EXP != 4 && grp == 0) __builtin_amdgcn_s_barrier();     // pairs with the last barrier of waves 4-7
-  if constexpr (EXP == 1 || EXP == 6 || EXP == 7 || EXP == 8 || EXP == 9 || EXP == 11 || EXP == 12) PP_VMCNT(0);
-  if constexpr (EXP == 11) { if (acc[0][0][0] == 123.f) out[tid] = 1; return; }
+  if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with the last barrier of waves 4-7
 
   // ---- epilogue (shared): rows back from padded-linear order; the halo rows and the padding columns are not stored ----
   long orow[IM];
@@ -264,10 +262,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
       if ((unsigned)w0 < (unsigned)g.Wr) o = ((long)nth * g.Wr + w0) * g.Cr;
     }
     orow[i] = o;
-  }
-  if constexpr (EXP == 12) {
-#pragma unroll
-    for (int i = 0; i < IM; ++i) orow[i] = (acc[0][0][0] == 123.f) ? orow[i] : -1;
   }
   igemm_epilogue_rows<BM, BN, IM, JN, true>(g, acc, smem, tid, fr, fq, 0, n0, wm0, wn0, split, 0, orow, out, bias, addend, stat_sum,
                                             stat_sq, relu, partial);
@@ -293,7 +287,6 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   g.M = (int)Mp;
   g.dW = make_fastdiv(g.Wr + 2);
   g.dKH = make_fastdiv(g.kH);
-  { const char* e = getenv("MSCL_PP_SWZ"); g.lsT = e ? atoi(e) : 0; }
   g.mtiles = (int)((Mp + OUT_ROWS - 1) / OUT_ROWS);
   g.ntiles = g.Cr / BN;
   const long blocks = (long)g.mtiles * g.ntiles;
@@ -316,26 +309,15 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   const size_t lds = 4 * (size_t)BN * 128 + 2 * 256 * 128;
   const bool n64 = BN == 64;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static bool attr_done = false;              // (one static per instantiation of this lambda = per kernel)
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(512), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu,
                        partial);
   };
-  const char* ex = getenv("MSCL_PP_EXP");
-  const int exp_ = ex ? atoi(ex) : 0;
-  if (n64) go(conv_pp_kernel<64, 0>);
-  else if (exp_ == 1) go(conv_pp_kernel<128, 1>);
-  else if (exp_ == 2) go(conv_pp_kernel<128, 2>);
-  else if (exp_ == 3) go(conv_pp_kernel<128, 3>);
-  else if (exp_ == 4) go(conv_pp_kernel<128, 4>);
-  else if (exp_ == 5) go(conv_pp_kernel<128, 5>);
-  else if (exp_ == 6) go(conv_pp_kernel<128, 6>);
-  else if (exp_ == 7) go(conv_pp_kernel<128, 7>);
-  else if (exp_ == 8) go(conv_pp_kernel<128, 8>);
-  else if (exp_ == 9) go(conv_pp_kernel<128, 9>);
-  else if (exp_ == 10) go(conv_pp_kernel<128, 10>);
-  else if (exp_ == 11) go(conv_pp_kernel<128, 11>);
-  else if (exp_ == 12) go(conv_pp_kernel<128, 12>);
-  else go(conv_pp_kernel<128, 0>);
+  if (n64) go(conv_pp_kernel<64>); else go(conv_pp_kernel<128>);
   MSCL_LAUNCH_CHECK();
   ++g_pp_launches;
   if (g.ksplit > 1) return mscl_launch_splitk_finalize(partial, out, bias, addend, relu, ssum, ssq, out_elems / g.Cr, g.Cr, g.ksplit, 0, st);
