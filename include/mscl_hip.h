@@ -50,9 +50,6 @@ int mscl_abi_version(void);
  * index order), so two runs on the same inputs give bit-identical results.  Costs one extra read of each conv output (the
  * statistics pass, mscl_bn_stats) and a slab pass per weight gradient.  Process-wide; set it before the first step.
  * Not covered: mscl_conv_halo64 called directly with statistics pointers, mscl_conv_halo64_dgrad_bn (both opt-in paths). */
-/* tuning aid: while non-zero, mscl_conv3d_fwd / _dgrad do not take the window-resident layer-1 kernel (host-side switch read at
- * launch time: brackets the launches of one chain) */
-int mscl_set_halo_off(int off);
 /* test aid: number of launches the ping-pong shared-tap conv kernel (conv_pp.hip) has taken in this process, so that a parity
  * test can assert which kernel family produced the result it checked */
 int64_t mscl_debug_pp_launches(void);

@@ -43,20 +43,7 @@ __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-#ifdef HALO_CLOCK        // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz per block (MI355X_MICROARCH.md, DVFS item 6)
-__device__ unsigned long long halo_clock_dbg[2 * 4096];
-__device__ unsigned long long halo_seg_dbg[5 * 256];
-extern "C" int mscl_halo_seg_read(unsigned long long* dst, int n) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(halo_seg_dbg), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
-}
-extern "C" int mscl_halo_clock_read(unsigned long long* dst, int n) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(halo_clock_dbg), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
-#ifndef HALO_CLOCK
-#define HSTAMP(I) do {} while (0)
-#endif
 
 constexpr int HBM = 256;           // padded-linear positions per block
 constexpr int HC = 64;             // channels (in = out)
@@ -99,11 +86,6 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
   const int t = plane % g.T;
   const int q0 = g.Wp + tile * BM;                         // first padded-linear position of this tile (hp = 1, wp = 0)
   const int mode = __builtin_amdgcn_readfirstlane(g.mode);
-#ifdef HALO_CLOCK
-  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0;   // HALO_CLOCK=2: where a tap's cycles go (wave 0)
-#define HSTAMP(I) do { if (HALO_CLOCK == 2) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); seg[I] += tn - tprev; tprev = tn; } } while (0)
-#endif
 
 #ifdef HALO_PROBE      // timing-only builds: 1 = weight loads dropped by the range check, 2 = window loads dropped, 3 = both
   const auto rs_src = halo_rsrc(src, (HALO_PROBE & 2) ? 0u : 0x7FFFFFFFu);
@@ -205,9 +187,6 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap) {
     const int cur = tap & 1;
-#ifdef HALO_CLOCK
-    if (HALO_CLOCK == 2 && tap == 0) tprev = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -219,7 +198,6 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       // would drain vmcnt as well.)  Everything issued AFTER the awaited tile may stay in flight -- later weight tiles
       // and the window pieces of the last RING - 1 taps; the count is a compile-time constant per tap (fully unrolled
       // loop).  The piece schedule ends three taps before a plane's first use, so in-order retirement has it landed.
-      HSTAMP(0);
       {
         auto pieces_at = [](int tp) {
           if (tp >= 0 && tp < 5) { const int lo = PPT1 * tp, hi = PPT1 * (tp + 1) < NPS ? PPT1 * (tp + 1) : NPS; return hi > lo ? hi - lo : 0; }
@@ -240,10 +218,8 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
           default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
         }
       }
-      HSTAMP(1);
       if (!(HALO_EXP & 1)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      HSTAMP(2);
       if (!(HALO_EXP & 2)) read_operands(tap + 1, cur ^ 1);
       // weight tile of tap + RING first, then this tap's share of window planes 2 and 3 (in-order retirement: see the wait)
       if (!(HALO_EXP & 4)) {
@@ -259,7 +235,6 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
         }
       }
     }
-    HSTAMP(3);
     __builtin_amdgcn_sched_barrier(0);          // keep the next tap's operand reads ABOVE this tap's second k step
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -267,7 +242,6 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       for (int i = 0; i < IM; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    HSTAMP(4);
   }
   __syncthreads();                  // the epilogue reuses the window memory
 
@@ -385,286 +359,12 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
     }
   }
-#ifdef HALO_CLOCK
-  if (tid == 0 && blockIdx.x < 4096) {
-    halo_clock_dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
-    halo_clock_dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
-    if (HALO_CLOCK == 2 && blockIdx.x < 256) { for (int q_ = 0; q_ < 5; ++q_) halo_seg_dbg[5 * blockIdx.x + q_] = seg[q_]; }
-  }
-#endif
 }
 
-// =====================================================================================================================
-// Persistent plane-walking variant (MSCL_HALO_PERSIST=1).  In-kernel s_memtime stamps on the kernel above
-// (profiles/r01_pmc_layer1.md): of the 42 k cycles a block slot costs, 13.8 k are MFMAs, 9 k tap-loop overhead, 9 k the
-// exposed window prologue + epilogue and 10 k the dispatch gap of a 160-KB block.  Here the grid is one block per CU and
-// a block walks a contiguous range of (n, tile, t) items with t fastest:
-//  * moving from output plane t to t+1 keeps two of the three source planes in LDS (ring slot = (plane + 1) % 3) and
-//    streams only plane t+2, one DMA piece per tap, so there is neither a prologue nor a dispatch gap inside a chain;
-//  * a tile is 192 positions (3 position tiles per wave): three 320-row planes leave room for a FOUR-stage weight ring,
-//    so a weight tile is issued three taps before use (with two stages every tap waited ~200 cycles for it) -- and 17
-//    tiles of 192 cover a 56 x 58 plane with 0.5 % waste (13 x 256: 2.4 %);
-//  * the tap pipeline runs across the item boundary: the last taps of an item issue the next item's first weight tiles
-//    and fetch its first operands, so the MFMA stream only pauses for the epilogue's stores;
-//  * right after the per-tap barrier the next tap's 14 operand reads are interleaved one-to-one with this tap's first 12
-//    MFMAs (sched_group_barrier): issued as one burst by all four waves they saturate the LDS for ~250 cycles with the
-//    MFMA pipes idle, which is what the first version of this kernel did (560 instead of 360 cycles for that segment);
-//  * taps are visited in WINDOW order (plane t-1, t, t+1; row shift a*(W+2)+b); the weight tap is idx (forward) or
-//    26 - idx (input gradient), so plane t-1 is always the first one released;
-//  * BatchNorm statistics accumulate in registers over all items of the block: one reduction + 128 atomics per BLOCK.
-// 27 taps per item: the ring stage of a tap is (taps done so far + idx) & 3 (runtime base, LDS addresses are runtime
-// anyway); the operand register double-buffer is re-based by a 28-register copy at the item boundary.
-constexpr int PBM = 192;                     // padded-linear positions per item
-constexpr int NHP = 320;                     // window rows: PBM + 2 * (W + 2) + 2 = 310 at W = 56, in 32-row DMA passes
-constexpr int PPLANE = NHP * 128;
-constexpr int PNPASS = NHP / 32;             // 10
-constexpr int PIM = PBM / 64;                // position tiles per wave (3)
-
-__global__ __launch_bounds__(256, 1) void conv_halo64p_kernel(const HaloGeom g, const int total_items,
-                                                              const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
-                                                              bf16_t* __restrict__ out, const bf16_t* __restrict__ addend,
-                                                              float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const Hs = smem;                          // [3][NHP][128 B] plane ring
-  unsigned char* const Ws = smem + 3 * PPLANE;             // [4][64][128 B] weight ring
-  float* const red = reinterpret_cast<float*>(smem + 3 * PPLANE + 4 * 64 * 128);      // [2][64] statistics scratch
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mode = __builtin_amdgcn_readfirstlane(g.mode);
-#ifdef HALO_CLOCK
-  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = 0;
-#endif
-  const int it_beg = (int)((long)total_items * blockIdx.x / gridDim.x);
-  const int it_end = (int)((long)total_items * (blockIdx.x + 1) / gridDim.x);
-  const auto rs_src = halo_rsrc(src, 0x7FFFFFFFu);
-  const auto rs_wgt = halo_rsrc(wgt, 0x7FFFFFFFu);
-  const int fr = lane & 15, fq = lane >> 4;
-  const int arow0 = wave * (PBM / 4) + fr;
-  const int b_addr0 = fr * 128 + ((0 + fq) ^ (fr & 7)) * 16;
-  const int b_addr1 = fr * 128 + ((4 + fq) ^ (fr & 7)) * 16;
-  const int w_row = tid >> 3, w_lg = tid & 7;
-  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);
-  const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
-
-  unsigned win_voff[PNPASS];                 // per-pass source offsets inside a plane (depend on the tile only)
-  int opos[PIM];                             // output offset inside a plane (elements), -1 = pad column / beyond the plane
-  float ssum[4][4], ssq[4][4];               // [j][r] running BatchNorm sums of this lane's rows
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
-
-  auto slot_of = [&](int tt) { const int s3 = (tt + 1) % 3; return s3; };          // tt >= -1
-  auto issue_plane_piece = [&](int n_t0, int tt, int ps) {                          // n_t0 = n * T
-    const bool pok = (unsigned)tt < (unsigned)g.T;
-    const unsigned so = __builtin_amdgcn_readfirstlane(pok ? (unsigned)((n_t0 + tt) * g.HW) * (HC * 2) : 0u);
-    const unsigned vo = pok ? win_voff[ps] : HOOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + slot_of(tt) * PPLANE + (ps * 256 + wave * 64) * 16), 16, vo, so, 0, 0);
-  };
-  auto issue_weights = [&](int idx, int stage) {                                    // idx = window-order tap
-    const int tapw = mode ? 26 - idx : idx;
-    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tapw * HC * 2));
-    unsigned char* dst = Ws + stage * (64 * 128) + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
-  };
-  bf16x8_t fa[2][2][PIM], fb[2][2][4];                     // [buffer][ks][fragment]
-  auto read_operands = [&](int idx, int buf, int stage, int t) {                    // operands of window tap idx of output plane t
-    const int gq = idx / 9, a = (idx % 9) / 3, b = idx % 3;
-    const unsigned char* wb = Ws + stage * (64 * 128);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      fb[buf][0][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr0 + j * 2048);
-      fb[buf][1][j] = *reinterpret_cast<const bf16x8_t*>(wb + b_addr1 + j * 2048);
-    }
-    const int row = arow0 + a * g.Wp + b;
-    const int key = row & 7;
-    const unsigned char* hb = Hs + slot_of(t - 1 + gq) * PPLANE + row * 128;
-    const int g0 = (fq ^ key) * 16, g1 = ((4 + fq) ^ key) * 16;
-#pragma unroll
-    for (int i = 0; i < PIM; ++i) {
-      fa[buf][0][i] = *reinterpret_cast<const bf16x8_t*>(hb + g0 + i * 2048);
-      fa[buf][1][i] = *reinterpret_cast<const bf16x8_t*>(hb + g1 + i * 2048);
-    }
-  };
-
-  int sbase = 0;                             // ring stage of the current item's tap 0  (= taps done so far, mod 4)
-  bool cont = false;                         // this item continues the previous item's chain (operands prefetched)
-  for (int it = it_beg; it < it_end; ++it) {
-    const int chain = fdiv(it, g.dT), t = it - chain * g.T;          // chain = n * tiles + tile
-    const int n = fdiv(chain, g.dTiles), tile = chain - n * g.tiles;
-    const int n_t0 = n * g.T;
-    const int q0 = g.Wp + tile * PBM;
-    const bool next_cont = (it + 1 < it_end) && (t + 1 < g.T);
-    if (!cont) {
-      // ---- chain start: window offsets of this tile, all three planes, first three weight tiles ----
-#pragma unroll
-      for (int ps = 0; ps < PNPASS; ++ps) {
-        const int j = ps * 32 + (tid >> 3), pg = tid & 7;
-        const int lg = pg ^ (j & 7);
-        const int q = q0 - g.Wp - 1 + j;
-        const int hp = fdiv(q < 0 ? 0 : q, g.dWp), wp = q - hp * g.Wp;
-        const bool ok = q >= 0 && hp >= 1 && hp <= g.H && wp >= 1 && wp <= g.W;
-        win_voff[ps] = ok ? (unsigned)((((hp - 1) * g.W + (wp - 1)) * HC + lg * 8) * 2) : HOOB;
-      }
-#pragma unroll
-      for (int i = 0; i < PIM; ++i) {
-        const int q = q0 + wave * (PBM / 4) + i * 16 + fr;
-        const int hp = fdiv(q, g.dWp), wp = q - hp * g.Wp;
-        opos[i] = (hp <= g.H && wp >= 1 && wp <= g.W) ? ((hp - 1) * g.W + (wp - 1)) * HC : -1;
-      }
-      // a slower wave may still be fetching the previous item's last operands (issued after the tap-25 barrier)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t - 1, ps);
-      issue_weights(0, sbase & 3);
-#pragma unroll
-      for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t, ps);
-#pragma unroll
-      for (int ps = 0; ps < PNPASS; ++ps) issue_plane_piece(n_t0, t + 1, ps);
-      issue_weights(1, (sbase + 1) & 3);
-      issue_weights(2, (sbase + 2) & 3);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      read_operands(0, 0, sbase & 3, t);
-      if (HALO_EXP & 2) read_operands(0, 1, sbase & 3, t);
-    }
-    f32x4_t acc[4][PIM];                                   // [j: channel tile][i: position tile]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < PIM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#ifdef HALO_CLOCK
-    tprev = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-    for (int idx = 0; idx < 27; ++idx) {
-      const int cur = idx & 1;
-      const bool more = idx < 26 || next_cont;             // another tap follows in this chain
-      if (more) {
-        // The weight tile of the next tap was issued two taps ago (or at the chain start); everything younger may stay in
-        // flight: the window pieces of the two previous taps and the weight tile issued a tap ago.  The barrier then
-        // publishes it and says every wave holds this tap's fragments, so the stage three taps ahead may be refilled.
-        HSTAMP(0);
-        {
-          const int p2 = (idx - 2 >= 9 && idx - 2 < 9 + PNPASS && next_cont) ? 1 : 0;
-          const int p1 = (idx - 1 >= 9 && idx - 1 < 9 + PNPASS && next_cont) ? 1 : 0;
-          const int w1 = (idx + 2 < 27 || next_cont) ? 2 : 0;       // the tile issued a tap ago (or, at tap 0, by the previous item / the chain start) is W(idx + 2)
-          const int younger = p2 + w1 + p1;
-          if (younger == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          else if (younger == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-          else if (younger == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-          else if (younger == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        }
-        HSTAMP(1);
-        if (!(HALO_EXP & 1)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        HSTAMP(2);
-        if (!(HALO_EXP & 2)) {
-          if (idx < 26) read_operands(idx + 1, cur ^ 1, (sbase + idx + 1) & 3, t);
-          else read_operands(0, 1, (sbase + 27) & 3, t + 1);                          // next item's first tap
-        }
-        if (!(HALO_EXP & 4)) {
-          if (idx + 3 < 27) issue_weights(idx + 3, (sbase + idx + 3) & 3);
-          else if (next_cont) issue_weights(idx + 3 - 27, (sbase + idx + 3) & 3);
-        }
-        if (!(HALO_EXP & 8) && idx >= 9 && idx < 9 + PNPASS && next_cont) issue_plane_piece(n_t0, t + 2, idx - 9);    // slot of plane t-1: free since tap 8
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < PIM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][0][j], fa[cur][0][i], acc[j][i], 0, 0, 0);
-      // one LDS read after each of the first MFMAs, the DMA instructions after them
-#pragma unroll
-      for (int u = 0; u < 4 * PIM; ++u) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (4 + PIM) - 4 * PIM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-      HSTAMP(3);
-      __builtin_amdgcn_sched_barrier(0);        // keep the next tap's operand reads ABOVE this tap's second k step
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < PIM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][1][j], fa[cur][1][i], acc[j][i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      HSTAMP(4);
-    }
-
-    // ---- item epilogue: statistics into registers, (+addend) -> bf16, 8-byte stores ----
-    if ((HALO_EXP & 16) && it + 1 < it_end) { if (next_cont) {} sbase = (sbase + 27) & 3; cont = next_cont; continue; }
-    const long pbase = (long)(n_t0 + t) * g.HW * HC;
-#pragma unroll
-    for (int i = 0; i < PIM; ++i) {
-      if (opos[i] < 0) continue;
-      const long o0 = pbase + opos[i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nn = j * 16 + fq * 4;
-        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ssum[j][r] += v[r]; ssq[j][r] += v[r] * v[r]; }
-        if (addend != nullptr) {
-          const uint2 av = *reinterpret_cast<const uint2*>(addend + o0 + nn);
-          v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
-          v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
-        }
-        uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(out + o0 + nn) = pv;
-      }
-    }
-    if (next_cont) {                         // 27 taps: the prefetched operands sit in buffer 1, the next item starts on buffer 0
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int f = 0; f < PIM; ++f) fa[0][ks][f] = fa[1][ks][f];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) fb[0][ks][f] = fb[1][ks][f];
-      }
-    }
-    sbase = (sbase + 27) & 3;
-    cont = next_cont;
-  }
-
-#ifdef HALO_CLOCK
-  if (tid == 0 && blockIdx.x < 4096) {
-    halo_clock_dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
-    halo_clock_dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
-    if (HALO_CLOCK == 2 && blockIdx.x < 256) { for (int q_ = 0; q_ < 5; ++q_) halo_seg_dbg[5 * blockIdx.x + q_] = seg[q_] / (unsigned long long)(it_end - it_beg); }
-  }
-#endif
-  // ---- block epilogue: BatchNorm statistics, one reduction and 128 atomics per block ----
-  if (stat_sum != nullptr) {
-    for (int i = tid; i < 2 * HC; i += 256) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float sv = ssum[j][r], qv = ssq[j][r];
-        sv = row16_sum(sv); qv = row16_sum(qv);
-        if (fr == 0) {
-          const int nl = j * 16 + fq * 4 + r;
-          atomicAdd(&red[nl], sv);
-          atomicAdd(&red[HC + nl], qv);
-        }
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < HC; i += 256) {
-      const int so = (int)(blockIdx.x % MSCL_STAT_ACTIVE) * 2 * HC;
-      atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
-    }
-  }
-}
+// (A persistent plane-walking variant of this kernel -- one block per CU walking 192-position items, two of three planes kept
+// resident, statistics once per block -- was measured in rounds 1 and 2: faster alone on the forward conv, 112 vs 125-134 us at
+// the time, slower inside the three-stream step, 785-793 vs 804-808 clip-pairs/s, and was removed in round 3.  Its successor is
+// conv_win64.hip, which shows the same pattern: 101 vs 107 us alone, 970 vs 1007 clip-pairs/s in the step.)
 
 // returns 1 if launched, 0 if the shape is not covered (caller falls back to the implicit-GEMM kernel), <0 / >0 on error
 static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
@@ -702,64 +402,17 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
   g.dWp = make_fastdiv(g.Wp);
   g.dT = make_fastdiv(d->T); g.dTiles = make_fastdiv(g.tiles);
   g.stat_stride = stat_stride;
-  // opt-in: alone it is faster on the forward conv (112 vs 125-134 us: statistics once per block) and about equal on
-  // the gradient (106-113 vs 112-114 us), but inside the three-stream step its 256 long-lived blocks schedule worse
-  // against the other streams' kernels (785-793 vs 804-808 clip-pairs/s)
-  const char* pv = getenv("MSCL_HALO_PERSIST");
-  if (pv && pv[0] == '1' && PBM + 2 * g.Wp + 2 <= NHP && bn.y == nullptr) {
-    g.tiles = (d->H * g.Wp + PBM - 1) / PBM; g.dTiles = make_fastdiv(g.tiles);
-    static int cus = 0;
-    static bool attr_done_p = false;
-    if (!attr_done_p) {
-      int dev = 0; (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (cus <= 0) cus = 256;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done_p = true;
-    }
-    const int items = d->N * d->T * g.tiles;
-    const int grid = items < cus ? items : cus;
-    const size_t ldsp = (size_t)3 * PPLANE + 4 * 64 * 128 + 2 * HC * sizeof(float);
-    hipLaunchKernelGGL(conv_halo64p_kernel, dim3((unsigned)grid), dim3(256), ldsp, (hipStream_t)stream, g, items, src, w, out, addend,
-                       ssum, ssq);
-    MSCL_LAUNCH_CHECK();
-    return 1;
-  }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4, 256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<8, 256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<4, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const char* w8 = getenv("MSCL_HALO_WAVES");
-  const char* bm = getenv("MSCL_HALO_BM");
-  hipStream_t st = (hipStream_t)stream;
-  if (bm && atoi(bm) == 128) {
-    g.tiles = (d->H * g.Wp + 127) / 128;
-    const size_t lds = (size_t)2 * 256 * 128 + 2 * 64 * 128;          // 80 KB: two blocks per CU
-    hipLaunchKernelGGL((conv_halo64_kernel<4, 128, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
-                       addend, ssum, ssq, bn);
-  } else if (getenv("MSCL_HALO_RING") && getenv("MSCL_HALO_RING")[0] == '2') {
-    // A/B: a 2-stage weight ring leaves 48 KB of the CU's LDS free (112 KB per block), enough for a 35-KB block of another
-    // chain's implicit-GEMM kernel to run on the same CU
-    static bool a2 = false;
-    if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_kernel<8, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
-    const size_t lds = (size_t)2 * 384 * 128 + 2 * 64 * 128;
-    hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 2>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, st, g, src, w, out,
-                       addend, ssum, ssq, bn);
-  } else if (!(w8 && w8[0] == '4')) {
-    // default since round 2: two waves per SIMD.  Measured inside the three-stream step, three alternating pairs in one call:
-    // 927 / 928 / 931 vs 920 / 920 / 923 clip-pairs/s, forward launch 104.2 vs 109.5 us, input gradient 102 vs 109 us
-    // (round 1 measured no gain: the other chains of the step were longer then).  MSCL_HALO_WAVES=4 selects one wave per SIMD.
-    const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
-    hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, st, g, src, w, out,
-                       addend, ssum, ssq, bn);
-  } else {
-    const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
-    hipLaunchKernelGGL((conv_halo64_kernel<4, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(256), lds, st, g, src, w, out,
-                       addend, ssum, ssq, bn);
-  }
+  // Two waves per SIMD, 256-position tiles, 4-stage weight ring.  Measured and dropped (all inside the three-stream step, alternating
+  // pairs in one call): one wave per SIMD (920-923 vs 927-931 clip-pairs/s), 128-position tiles at two blocks per CU (901-902 vs
+  // 903-907), a 2-stage ring that leaves room for another chain's block on the CU (no gain).
+  const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
+  hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, (hipStream_t)stream, g, src, w,
+                     out, addend, ssum, ssq, bn);
   MSCL_LAUNCH_CHECK();
   return 1;
 }

@@ -42,9 +42,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   constexpr int IM = WM / 16, JN = WN / 16;
   constexpr int KSUB = BK / 32;
   static_assert(WAVES_M * WAVES_N == 4 && IM >= 1 && JN >= 1 && AP >= 1, "tile config");
-  // a 3-stage ring waits with a counted vmcnt, so every wave must issue the same number of DMA instructions
-  // per tile: the B tile has to span at least one 1-KiB chunk per wave per pass
-  static_assert(STAGES == 2 || (BN * BK * 2) % 4096 == 0, "3-stage ring needs BN*BK*2 to be a multiple of 4 KiB");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [STAGES][BM*BK]
@@ -218,38 +215,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     }
   };
 
-  if constexpr (STAGES == 2) {
-    if (k_beg < k_end) {
-      issue_tiles(k_beg, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    for (int kt = k_beg; kt < k_end; ++kt) {
-      const int cur = (kt - k_beg) & 1;
-      if (kt + 1 < k_end) issue_tiles(kt + 1, cur ^ 1);
-      compute_tile(cur);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-    // 3-stage ring: tile kt+2 is issued while tile kt is computed; the wait before the barrier retires only
-    // tile kt (counted vmcnt: ND DMA instructions per wave per tile stay in flight), and the barrier is a raw
-    // s_barrier -- __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise load and compute.
-    constexpr int ND = AP + BP;
-    const int nkt = k_end - k_beg;
-    if (nkt > 0) issue_tiles(k_beg, 0);
-    if (nkt > 1) issue_tiles(k_beg + 1, 1);
-    int buf = 0, nxt = 2;
-    for (int i = 0; i < nkt; ++i) {
-      if (i + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ND) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (i + 2 < nkt) issue_tiles(k_beg + i + 2, nxt);
-      compute_tile(buf);
-      buf = (buf == STAGES - 1) ? 0 : buf + 1;
-      nxt = (nxt == STAGES - 1) ? 0 : nxt + 1;
-    }
-    __builtin_amdgcn_s_barrier();             // the epilogue reuses the tile memory
+  static_assert(STAGES == 2, "two LDS stages (a deeper ring never paid: see conv_igemm_fast_kernel)");
+  if (k_beg < k_end) {
+    issue_tiles(k_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int kt = k_beg; kt < k_end; ++kt) {
+    const int cur = (kt - k_beg) & 1;
+    if (kt + 1 < k_end) issue_tiles(kt + 1, cur ^ 1);
+    compute_tile(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 
   igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, dW, dH, dT, TrS, HrS, WrS, rsT, rsH, rsW,
@@ -262,9 +239,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // buffer instruction's SGPR offset and the per-lane VGPR offset of a row never changes.  A K step then costs 3 VALU
 // per A piece (tap-validity test + select of the zero-fill sentinel) and none per B piece, instead of the ~30 the
 // general kernel spends on table lookups and address arithmetic (measured there: 7.8 VALU per MFMA, 22 % MFMA busy).
-// STAGES: depth of the LDS ring.  2 = issue tile k+1, compute tile k, drain, barrier.  3 / 4 = tiles k+1 .. k+STAGES-1 stay
-// in flight across the (raw) barrier behind a counted vmcnt: for grids of about one block per CU, where no second block hides
-// the global -> LDS round trip of every K step.
+// Two LDS stages: issue tile k+1, compute tile k, drain, barrier.  (A 3- / 4-stage ring with counted vmcnt waits and a raw barrier
+// was built in round 2 and never beat two blocks per CU at depth 2 -- 57 vs 82 us on 128 -> 128 x 50176 positions; removed in round
+// 3.  What does beat this loop on the big maps is the ping-pong structure of conv_pp.hip.)
 // WAVES_M x WAVES_N = 4 (256 threads) or 8 (512 threads, the WIDE tiles 256 x 128 / 128 x 256: 48 KB staged per 4.2 MFLOP
 // instead of 32 KB per 2.1).  Measured round 2 (tools/bench_conv.py --sweep, one process): ring depth 3 / 4 never beats two
 // blocks per CU at depth 2 (128 -> 128 on 50176 positions: 57 us at depth 2, 82 at depth 3 with one block per CU); the
@@ -397,42 +374,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
     }
   };
 
-  if constexpr (STAGES == 2) {
-    if (k_beg < k_end) {
-      issue(k_beg, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    for (int kt = k_beg; kt < k_end; ++kt) {
-      const int cur = (kt - k_beg) & 1;
-      if (kt + 1 < k_end) issue(kt + 1, cur ^ 1);
-      compute(cur);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-    // Ring of STAGES slots: iteration i waits until tile i has landed (every wave issues ND = AP + BP DMA instructions per
-    // tile, so "all but the youngest (STAGES-2)*ND" is exactly tile i), passes a raw s_barrier (a __syncthreads() would
-    // drain the DMA queue), refills the slot tile i-1 was read from -- every wave has finished those reads, it is past the
-    // barrier -- and computes tile i while tiles i+1 .. i+STAGES-1 are in flight.
-    constexpr int ND = AP + BP;
-    const int nkt = k_end - k_beg;
-#pragma unroll
-    for (int s_ = 0; s_ < STAGES - 1; ++s_)
-      if (s_ < nkt) issue(k_beg + s_, s_);
-    int buf = 0, nxt = STAGES - 1;
-    for (int i = 0; i < nkt; ++i) {
-      const int rem = nkt - 1 - i;                    // tiles issued after tile i so far: min(rem, STAGES - 2)
-      if (rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((STAGES - 2) * ND) : "memory");
-      else if (STAGES == 4 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ND) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (i + STAGES - 1 < nkt) issue(k_beg + i + STAGES - 1, nxt);
-      compute(buf);
-      buf = (buf == STAGES - 1) ? 0 : buf + 1;
-      nxt = (nxt == STAGES - 1) ? 0 : nxt + 1;
-    }
-    __builtin_amdgcn_s_barrier();                   // the epilogue reuses the tile memory
+  static_assert(STAGES == 2, "two LDS stages");
+  if (k_beg < k_end) {
+    issue(k_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int kt = k_beg; kt < k_end; ++kt) {
+    const int cur = (kt - k_beg) & 1;
+    if (kt + 1 < k_end) issue(kt + 1, cur ^ 1);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
   igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, g.dW, g.dH, g.dT, g.Tr, g.Hr, g.Wr, 1, 1, 1,
                                  0, 0, 0, out, bias, addend, stat_sum, stat_sq, relu, partial);
@@ -490,7 +443,7 @@ int mscl_launch_splitk_finalize(const float* partial, bf16_t* out, const float* 
                                 float* ssq, long rows, int C, int nslab, long grp_rows, hipStream_t st) {
   const int RP = 256 / (C / 8);
   const int ngrp = grp_rows > 0 ? (int)(rows / grp_rows) : 1;
-  static const long fin_cap = [] { const char* e = getenv("MSCL_FINALIZE_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }();   // tuning aid
+  constexpr long fin_cap = 2048;
   long fb = (rows / ngrp + RP - 1) / RP; if (fb > fin_cap / ngrp) fb = fin_cap / ngrp; if (fb < 1) fb = 1;
   hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)fb, ngrp), dim3(256), 0, st, partial, out, bias, addend, relu, ssum, ssq,
                      rows, C, nslab, grp_rows);
@@ -500,19 +453,6 @@ int mscl_launch_splitk_finalize(const float* partial, bf16_t* out, const float* 
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static constexpr bool fast_tile() { return BK == 64 && STAGES == 2 && BM % (8 * WAVES_M * WAVES_N) == 0 && BN % (8 * WAVES_M * WAVES_N) == 0; }
-static bool fast_disabled() { const char* e = getenv("MSCL_IGEMM_FAST"); return e && e[0] == '0'; }
-// MSCL_IGEMM_WIDE: 0 = no 8-wave tiles, 1 = only on the 256-channel maps of a few thousand positions (the round-1 choice, from
-// kernels timed alone), 2 (default) = wherever they apply: 256 x 128 on the 128-channel maps too.  Measured inside the step, three
-// alternating pairs in one call: 922 / 925 / 927 vs 915 / 915 / 914 clip-pairs/s.
-static int wide_level() { const char* e = getenv("MSCL_IGEMM_WIDE"); return e ? atoi(e) : 2; }
-// ring depth of the uniform-tap kernel for a grid of `nblk` blocks with `stage_bytes` of LDS per stage
-// (MSCL_FAST_STAGES = 2 / 3 / 4 forces it: tuning aid, read per launch)
-static int fast_stages(long nblk, int stage_bytes) {
-  if (const char* e = getenv("MSCL_FAST_STAGES")) { const int v = atoi(e); if (v >= 2 && v <= 4) return v; }
-  (void)nblk; (void)stage_bytes;
-  return 2;
-}
-
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
 static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias,
                       const bf16_t* addend, float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
@@ -530,8 +470,7 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   if (ws != nullptr && blocks <= 256 && nk >= 32) {           // too few tiles for 256 CUs and a long K loop
     // measured on the 6272- and 784-position layers (tools/sweep_ksplit.sh): one round of <= 2 blocks per CU beats more
     // splits (98 tiles x 6 = 588 blocks ran 52 us, x 4 = 392 blocks 44 us), and a block wants >= 12 K steps
-    static const long ks_target = [] { const char* e = getenv("MSCL_KSPLIT_TARGET"); return e && atol(e) > 0 ? atol(e) : 448L; }();    // tuning aids
-    static const long ks_steps = [] { const char* e = getenv("MSCL_KSPLIT_MINSTEPS"); return e && atol(e) > 0 ? atol(e) : 12L; }();
+    constexpr long ks_target = 448, ks_steps = 12;        // swept in round 2 (320 / 448 / 640 blocks, 8 / 12 / 18 steps): kept
     long want = (WAVES_M * WAVES_N == 8 ? ks_target * 256 / 448 : ks_target) / blocks;      // wide tiles: one 96-KB block per CU
     const long minsteps = WAVES_M * WAVES_N == 8 ? (ks_steps + 1) / 2 : ks_steps;
     if (want > nk / minsteps) want = nk / minsteps;
@@ -548,23 +487,17 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   if constexpr (fast_tile<BM, BN, BK, WAVES_M, WAVES_N, STAGES>()) {
     // uniform-tap kernel: whole 64-channel K steps of one tap, no parity classes, offsets below 2^31
     const long span = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
-    if (g.mode != 2 && g.cgs >= 3 && span < (1L << 31) && !fast_disabled()) {
+    if (g.mode != 2 && g.cgs >= 3 && span < (1L << 31)) {
       g.dKW = make_fastdiv(g.kW); g.dKH = make_fastdiv(g.kH);
       const long nblk = blocks * g.ksplit;
-      int stages = fast_stages(nblk, (BM + BN) * BK * 2);
-      auto go = [&](auto kern, int nst) {
-        static bool attr_done_f = false;            // (one static per instantiation of this lambda = per kernel)
-        if (!attr_done_f) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attr_done_f = true;
-        }
-        const size_t lds = (size_t)nst * (BM + BN) * BK * 2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), lds, st, g, src, wgt, out, bias, addend, ssum, ssq,
-                           relu, partial);
-      };
-      if (stages == 4 && 4 * (BM + BN) * BK * 2 <= 160 * 1024) go(conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 4>, 4);
-      else if (stages >= 3) go(conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 3>, 3);
-      else go(conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 2>, 2);
+      auto kern = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 2>;
+      static bool attr_done_f = false;
+      if (!attr_done_f) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done_f = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), (size_t)2 * (BM + BN) * BK * 2, st, g, src, wgt, out, bias,
+                         addend, ssum, ssq, relu, partial);
       MSCL_LAUNCH_CHECK();
       launched = true;
     }
@@ -601,9 +534,9 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
 #define GO3(BM, BN, BK, WMv, WNv, ST) return launch_cfg<BM, BN, BK, WMv, WNv, ST>(g, src, wgt, out, bias, addend, ssum, ssq, relu, ws, ws_floats, st)
 #define GO(BM, BN, BK, WMv, WNv) GO3(BM, BN, BK, WMv, WNv, 2)
   if (const char* force = getenv("MSCL_IGEMM_CFG")) {       // tuning aid: "BM,BN,BK"
-    int bm = 0, bn = 0, bk = 0, stg = 2;
-    if (sscanf(force, "%d,%d,%d,%d", &bm, &bn, &bk, &stg) >= 3 && (bk == 32 || bk64) && bn <= (Cr < 16 ? 16 : Cr)) {
-#define TRY(BM, BN, BK, WMv, WNv) if (bm == BM && bn == BN && bk == BK) { if (stg == 3) GO3(BM, BN, BK, WMv, WNv, 3); GO(BM, BN, BK, WMv, WNv); }
+    int bm = 0, bn = 0, bk = 0;
+    if (sscanf(force, "%d,%d,%d", &bm, &bn, &bk) == 3 && (bk == 32 || bk64) && bn <= (Cr < 16 ? 16 : Cr)) {
+#define TRY(BM, BN, BK, WMv, WNv) if (bm == BM && bn == BN && bk == BK) { GO(BM, BN, BK, WMv, WNv); }
       TRY(128, 128, 64, 2, 2); TRY(64, 128, 64, 2, 2); TRY(256, 64, 64, 4, 1); TRY(128, 64, 64, 2, 2); TRY(64, 64, 64, 2, 2);
       TRY(128, 128, 32, 2, 2); TRY(256, 64, 32, 4, 1); TRY(128, 64, 32, 2, 2); TRY(64, 64, 32, 2, 2);
       TRY(256, 128, 32, 4, 1); TRY(64, 128, 32, 2, 2);
@@ -624,23 +557,20 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   const bool can_split = ws != nullptr;
   // wide tiles (uniform-tap kernel only: whole 64-channel steps of one tap, no parity classes, 32-bit offsets)
   const long span_w = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
-  const int wide = wide_level();
-  const bool wide_ok = bk64 && g.mode != 2 && g.cgs >= 3 && span_w < (1L << 31) && !fast_disabled() && wide > 0;
+  const bool wide_ok = bk64 && g.mode != 2 && g.cgs >= 3 && span_w < (1L << 31);
   if (wide_ok && Cr >= 128) {
     const int nk = g.ntaps << (g.cgs - 3);
     // 128 output channels: 256 positions x 128 (196 tiles on the 50176-position maps) -- a tie at best, A/B only
-    static const long w128_min = [] { const char* e = getenv("MSCL_IGEMM_W128_MIN"); return e && atol(e) > 0 ? atol(e) : 160L; }();         // tuning aid
-    if (wide >= 2 && Cr == 128 && (blocks(256, 128) >= w128_min || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
+    if (Cr == 128 && (blocks(256, 128) >= 160 || (can_split && nk >= 32 && blocks(256, 128) >= 8))) GO(256, 128, 64, 4, 2);
     // 256 output channels on maps of a few thousand positions: 128 positions x 256 channels, K split over the grid
-    if (Cr >= 256 && Cr % 256 == 0 && can_split && nk >= 32 && blocks(128, 256) <= 128 && (wide >= 2 || (Cr == 256 && blocks(128, 256) >= 24)))
+    if (Cr >= 256 && Cr % 256 == 0 && can_split && nk >= 32 && blocks(128, 256) <= 128)
       GO(128, 256, 64, 2, 4);
   }
   if (bk64) {
     if (Cr >= 128) {
       // a few dozen 128 x 128 tiles (784-position maps): 64-row tiles double the tiles per split, so fewer fp32 slabs
       // make the same number of blocks (512 -> 512 3x3x3 on 784 positions: 34 -> 32 us, 128 -> 128 on 6272: 30 -> 25 us)
-      static const long small_max = [] { const char* e = getenv("MSCL_IGEMM_SMALLTILE_MAX"); return e && atol(e) > 0 ? atol(e) : 64L; }();   // tuning aid
-      if (can_split && g.nclass == 0 && blocks(128, 128) <= small_max) GO(64, 128, 64, 2, 2);
+      if (can_split && g.nclass == 0 && blocks(128, 128) <= 64) GO(64, 128, 64, 2, 2);
       if (blocks(128, 128) >= 384 || can_split) GO(128, 128, 64, 2, 2);
       GO(64, 128, 64, 2, 2);
     }
@@ -688,10 +618,7 @@ static bool win64_enabled(const mscl_conv_desc* d) {
 }
 // layer-1 shape (3x3x3 s1 p1, 64 -> 64): halo-resident kernel, 131 / 109 us vs 156 / 135 us (fwd / dgrad) for the
 // implicit-GEMM kernel; MSCL_HALO=0 switches it off
-static int g_halo_off = 0;       // experiment switch (mscl_set_halo_off): the next launches skip the window-resident layer-1 kernel
-extern "C" int mscl_set_halo_off(int off) { g_halo_off = off; return 0; }
 static bool halo_enabled(const mscl_conv_desc* d) {
-  if (g_halo_off) return false;
   const char* e = getenv("MSCL_HALO");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;                        // forced (tests: small planes too)

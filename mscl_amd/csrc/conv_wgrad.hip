@@ -332,7 +332,6 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   const long tiles = (long)g.co_tiles * g.col_tiles;
   long target = (CO + NCOL) > 128 ? 512 : 768;            // blocks overall: 2 per CU with the 68-KB 128 x 128 tile, ~3 otherwise
   if (g.C <= 8) target = 2048;                            // stems: 16-byte gathers per position, the DMA latency wants more waves (95 -> 81 us)
-  if (const char* f = getenv("MSCL_WGRAD_TARGET")) { if (atoi(f) > 0) target = atoi(f); }   // tuning aid
   long want = (CO + NCOL) > 128 ? (target / tiles > 0 ? target / tiles : 1) : (target + tiles - 1) / tiles;
   long maxs = (g.M + 255) / 256;                          // at least 4 steps per block
   if (want > maxs) want = maxs;
@@ -411,14 +410,13 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
     dws = ws; dfl = ws_floats - tail;
     if (dfl < 0) return MSCL_E_ARG;
   }
-  bool wide = false;     // NCOL = 192 (three taps share one dy tile) measured slower than 64: fewer blocks per CU
-  if (const char* f = getenv("MSCL_WGRAD_NCOL")) wide = atoi(f) == 192;
+  // (NCOL = 192, three taps sharing one dy tile, measured slower than 64 -- fewer blocks per CU -- and was dropped)
   if (hres == 1) e = 0;
   else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st, dws, dfl);
-  else if (d->K >= 64) e = wide ? launch_w<64, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<64, 64>(g, x, dy, dw, st, dws, dfl);
-  else if (d->K == 32) e = wide ? launch_w<32, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<32, 64>(g, x, dy, dw, st, dws, dfl);
+  else if (d->K >= 64) e = launch_w<64, 64>(g, x, dy, dw, st, dws, dfl);
+  else if (d->K == 32) e = launch_w<32, 64>(g, x, dy, dw, st, dws, dfl);
   // K == 8 (the 8-channel layers of r2d_50): the 16-row tile with its upper half zero-filled by the range check and never stored
-  else if (d->K == 16 || d->K == 8) e = wide ? launch_w<16, 192>(g, x, dy, dw, st, dws, dfl) : launch_w<16, 64>(g, x, dy, dw, st, dws, dfl);
+  else if (d->K == 16 || d->K == 8) e = launch_w<16, 64>(g, x, dy, dw, st, dws, dfl);
   else return MSCL_E_SHAPE;
   if (e) return e;
   if (dbias) {

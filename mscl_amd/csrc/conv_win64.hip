@@ -18,6 +18,12 @@
 //  * K SPLIT BETWEEN SIMD PARTNERS: waves w and w + 4 own the SAME 64 x 64 output tile and half of each tap's 64-deep reduction
 //    (k 0..31 / 32..63): 4 + 4 fragment reads per 16 MFMAs instead of 4 + 8.  At the end of a tile the partners exchange half
 //    of their partial sums through 32 KB of LDS (w gives rows 32..63, w + 4 gives rows 0..31) and each stores 32 rows.
+// Status (round 3): OPT-IN (MSCL_WIN64=1).  Alone: 101 vs 107 us forward, 96 vs 94 us gradient against conv_halo.hip on the
+// (8,16,56,56,64) map; inside the three-stream step 970 vs 1007 clip-pairs/s -- 256 long-lived 160-KB blocks leave the other two
+// chains nothing to run on, the pattern the earlier persistent variant of conv_halo.hip showed.  Timing builds (compile-time
+// switches, since removed): without the DMA issue 77 us, without the fragment reads 80, without the MFMAs 70 -- three comparable
+// costs that overlap poorly at 16 MFMAs per barrier pair (an interval lasts ~590 cycles for 256 cycles of MFMA); dropping all
+// memory traffic but keeping the DMA instructions saves 11 us, so issue cost, not bandwidth, is what the loads cost.
 // Hazard rules as in conv_pp.hip: (R1) a DMA unit waited for in L_p is first read in L_{p+1}; (R2) a slot last read in L_p is
 // re-issued in L_{p+1} or later (every wave retires its reads before the barrier that ends its L section).
 // DMA schedule, tap counter c (9 per group), weight ring of 4 slots (c & 3), window slots u & 1:
@@ -38,7 +44,6 @@ struct Win64Geom {
   int kT, pT, mode;                // taps along time and their padding; 0 forward, 1 stride-1 input gradient (taps mirrored)
   int ntiles, Mg;                  // 256-row tiles over Mg = NT * PL padded-linear rows
   int KG;                          // 16-byte granules per weight row (taps * 8)
-  int probe;                       // timing probes (MSCL_WIN64_PROBE): 1 weight loads dropped by the range check, 2 window loads, 3 both
   FastDiv dPL, dWp, dT;
 };
 
@@ -47,9 +52,6 @@ constexpr int WN_BM = 256, WN_ROWS = 384, WN_WSLOT = WN_ROWS * 128, WN_BSLOT = 6
 constexpr int WN_B_BASE = 0, WN_W_BASE = WN_NB * WN_BSLOT, WN_X_BASE = WN_W_BASE + 2 * WN_WSLOT, WN_LDS = WN_X_BASE + 32 * 1024;
 static_assert(WN_LDS == 160 * 1024, "LDS plan");
 
-// EXP (timing probes, wrong results): 1 no DMA issue in the loop, 2 no fragment reads, 3 no MFMAs, 4 no exchange / stores,
-// 5 = 1 + 2, 6 = 1 + 3, 7 = 1 + 2 + 3 + 4 (barrier skeleton)
-template <int EXP>
 __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
                                                          bf16_t* __restrict__ out, const bf16_t* __restrict__ addend,
                                                          float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, cons
   const int plane_bytes = g.HW * 128;
   // time taps travel in the SGPR offset, kept non-negative by moving the descriptor base back
   const int bias_bytes = (mode == 0 ? g.pT : (kT - 1 - g.pT)) * plane_bytes;
-  const auto rs_src = make_uniform_rsrc(reinterpret_cast<const unsigned char*>(src) - bias_bytes, (g.probe & 2) ? 0u : 0x7FFFFFFFu);
-  const auto rs_wgt = make_uniform_rsrc(wgt, (g.probe & 1) ? 0u : 0x7FFFFFFFu);
+  const auto rs_src = make_uniform_rsrc(reinterpret_cast<const unsigned char*>(src) - bias_bytes, 0x7FFFFFFFu);
+  const auto rs_wgt = make_uniform_rsrc(wgt, 0x7FFFFFFFu);
   const auto rs_out = make_uniform_rsrc(out, 0x7FFFFFFFu);
   const unsigned wrow_voff = (unsigned)(rr * g.KG * 16 + rgl * 16);          // weight row rr (output channel / input channel for wT)
   unsigned win_voff[6]; int win_mask[6];
@@ -142,8 +144,6 @@ __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, cons
   if (grp == 1) __builtin_amdgcn_s_barrier();      // the stagger
 
   u32x4_t fa[4], fb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { fa[i] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; fb[i] = fa[i]; }
   int tile = b0, kt = 0;
   for (int u = 0; u < n_groups; ++u) {
     const bool has_next = u + 1 < n_groups;
@@ -169,10 +169,8 @@ __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, cons
         WN_DSR(fa[0], aa, 0); WN_DSR(fa[1], aa, 2048); WN_DSR(fa[2], aa, 4096); WN_DSR(fa[3], aa, 6144);
         WN_DSR(fb[0], ba, 0); WN_DSR(fb[1], ba, 2048); WN_DSR(fb[2], ba, 4096); WN_DSR(fb[3], ba, 6144);
       };
-      constexpr bool NO_DMA = EXP == 1 || EXP == 5 || EXP == 6 || EXP == 7, NO_RD = EXP == 2 || EXP == 5 || EXP == 7, NO_MM = EXP == 3 || EXP == 6 || EXP == 7;
-      if constexpr (!NO_RD) reads();
-      if constexpr (NO_DMA) {
-      } else if (has_next) {
+      reads();
+      if (has_next) {
         if constexpr (P < 6) issue_win(P, wslot_n, so_n, ktbit_n);
         if constexpr (P + 3 <= 8) issue_wgt(c0 + P + 3, kt * 9 + P + 3); else issue_wgt(c0 + P + 3, kt_n * 9 + P - 6);
         if constexpr (P == 0) { if (after_tile) WN_VMCNT(3 + WN_NST); else WN_VMCNT(3); }
@@ -193,10 +191,6 @@ __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, cons
       __builtin_amdgcn_sched_barrier(0);
       // ---- M: 64 positions x 64 channels x 32 deep ----
       __builtin_amdgcn_s_setprio(1);
-      if constexpr (NO_MM) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[i])); asm volatile("" ::"v"(fb[i])); }
-      } else
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -271,9 +265,7 @@ __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, cons
           }
         }
       };
-      if constexpr (EXP == 4 || EXP == 7) {
-        __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
-      } else if (grp == 0) {
+      if (grp == 0) {
         xwrite(2);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
@@ -297,7 +289,6 @@ __global__ __launch_bounds__(512) void conv_win64_kernel(const Win64Geom g, cons
     kt = kt_n; tile = tile_n;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();      // pairs with the last barrier of waves 4-7
-  if constexpr (EXP != 0) WN_VMCNT(0);
 
   // ---- BatchNorm statistics: one reduction per block ----
   if (stat_sum != nullptr) {
@@ -339,7 +330,6 @@ extern "C" int mscl_conv_win64(const mscl_conv_desc* d, int mode, const uint16_t
   g.Mg = g.NT * g.PL;
   g.ntiles = (g.Mg + WN_BM - 1) / WN_BM;
   g.KG = d->kT * 9 * 8;
-  { const char* e = getenv("MSCL_WIN64_PROBE"); g.probe = e ? atoi(e) : 0; }
   g.dPL = make_fastdiv(g.PL); g.dWp = make_fastdiv(g.Wp); g.dT = make_fastdiv(d->T);
   static int cus = 0;
   if (cus == 0) {
@@ -348,21 +338,12 @@ extern "C" int mscl_conv_win64(const mscl_conv_desc* d, int mode, const uint16_t
     if (cus <= 0) cus = 256;
   }
   const int grid = g.ntiles < cus ? g.ntiles : cus;
-  auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), WN_LDS, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
-  };
-  const char* ex = getenv("MSCL_WIN64_EXP");
-  switch (ex ? atoi(ex) : 0) {
-    case 1: go(conv_win64_kernel<1>); break;
-    case 2: go(conv_win64_kernel<2>); break;
-    case 3: go(conv_win64_kernel<3>); break;
-    case 4: go(conv_win64_kernel<4>); break;
-    case 5: go(conv_win64_kernel<5>); break;
-    case 6: go(conv_win64_kernel<6>); break;
-    case 7: go(conv_win64_kernel<7>); break;
-    default: go(conv_win64_kernel<0>);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS);
+    attr_done = true;
   }
+  hipLaunchKernelGGL(conv_win64_kernel, dim3((unsigned)grid), dim3(512), WN_LDS, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
   MSCL_LAUNCH_CHECK();
   ++g_win64_launches;
   return 1;

@@ -3,7 +3,7 @@
 #include "common.h"
 #include <cstdlib>
 // grid cap of the elementwise passes (MSCL_EW_CAP: tuning aid)
-static long ew_cap() { static const long c = [] { const char* e = getenv("MSCL_EW_CAP"); return e && atol(e) > 0 ? atol(e) : 2048L; }(); return c; }
+static long ew_cap() { return 2048; }        // grid cap of the element-wise passes (swept inside the step: 1024 / 2048 / 4096, no gain)
 
 // ---------------------------------------------------------------- input packing NCTHW fp32 -> NDHWC8 bf16
 // frames [t_off, t_off+T) of a clip holding T_total frames (the base / rotated halves of the flow clip,

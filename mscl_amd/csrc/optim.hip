@@ -2,7 +2,7 @@
 // key-encoder EMA, gradient sum of squares, clip + SGD-momentum, bf16 shadow refresh.
 #include "common.h"
 #include <cstdlib>
-static long ema_cap() { static const long c = [] { const char* e = getenv("MSCL_EMA_CAP"); return e && atol(e) > 0 ? atol(e) : 4096L; }(); return c; }   // tuning aid
+static long ema_cap() { return 4096; }       // grid cap of the EMA / SGD passes (swept inside the step: no gain from 2048 / 8192)
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq,
                                                   bf16_t* __restrict__ pkb, long n, float m_val, const float* __restrict__ m_dev) {

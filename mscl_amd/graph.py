@@ -36,10 +36,7 @@ class GraphedStep:
         model._upload_step_words()
         optimizer.sync_lr()
         calls = [(g, g.calls) for g in list(model._key_graph) + list(model._query_graph)]
-        import os
-        prio = os.environ.get('MSCL_MAIN_PRIORITY')       # A/B: capture the main chain on a stream of another priority (-1 = high)
-        cap = dict(stream=torch.cuda.Stream(priority=int(prio))) if prio else {}
-        with torch.cuda.graph(self.graph, **cap):
+        with torch.cuda.graph(self.graph):            # (capturing the main chain on a high-priority stream measured no gain)
             flips = self.static.get('flip_mask', (None, None))
             rows = self.static.get('aug_params', (None, None))
             loss, logs = model._device_step(self.static[model.im_key][0], self.static[model.im_key][1],

@@ -32,7 +32,6 @@ P = c_void_p
 _SIGS = {
     'mscl_abi_version': [],
     'mscl_set_deterministic': [c_int],
-    'mscl_set_halo_off': [c_int],
     'mscl_debug_pp_launches': [],
     'mscl_debug_win64_launches': [],
     'mscl_get_deterministic': [],

@@ -223,27 +223,14 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
 
 
 # Weight gradients are leaves of the backward dependency chain (only the input gradient feeds the next layer), so
-# the convs whose backward runs on a stream registered here launch their wgrad kernel on the paired side stream:
-# the dgrad / BN-backward chain no longer waits for them.  {stream handle: side torch.cuda.Stream}
-PAIR_STEM = os.environ.get('MSCL_PAIR_STEM', '1') != '0'     # RGB stem on W-paired input (kernels.pair_w): K 1176 -> 672
-MASK_FROM_Y_MIN = int(os.environ.get('MSCL_MASK_FROM_Y_MIN', 1 << 24))    # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
-WGRAD_SIDE = {}
+PAIR_STEM = True            # RGB stem on W-paired input (kernels.pair_w): K 1176 -> 672 (round 1: forward 126 -> 81 us; the plain stem stays testable via Conv3dHip(pair_w=False))
+MASK_FROM_Y_MIN = 1 << 24   # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
 
 
 def _wgrad(conv, x, dy):
-    if not WGRAD_SIDE:
-        conv.wgrad(x, dy)
-        return
-    cur = torch.cuda.current_stream()
-    side = WGRAD_SIDE.get(cur.cuda_stream)
-    if side is None:
-        conv.wgrad(x, dy)
-        return
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        conv.wgrad(x, dy)
-    x.record_stream(side)
-    dy.record_stream(side)
+    """(weight gradients on a side stream, off the dgrad / BatchNorm-backward chain, were measured in rounds 1 and 2: -6 ... -13 %
+    on the step -- two MFMA-heavy kernels side by side do not pay -- and removed in round 3)"""
+    conv.wgrad(x, dy)
 
 
 HOLD_BUCKETS = [False]          # True while a branch's backward is being captured into a sub-graph (recognizers.QueryGraph)
@@ -254,11 +241,6 @@ def _bucket_done(mod):
     if HOLD_BUCKETS[0]:
         return                  # nothing executes during capture; the replaying node fires the trigger itself
     buckets = getattr(mod, '_grad_buckets', ())
-    if buckets and not parallel.single():
-        cur = torch.cuda.current_stream()
-        side = WGRAD_SIDE.get(cur.cuda_stream)
-        if side is not None:
-            cur.wait_stream(side)               # the bucket's weight gradients were written on the side stream
     for red, i in buckets:
         red.bucket_done(i)
 

@@ -41,16 +41,6 @@ LOG_KEYS = ('top1_acc', 'top5_acc', 'loss_cls', 'top1_acc_flow', 'top5_acc_flow'
 LOG_KEYS_NO_AUG_MX = tuple(k for k in LOG_KEYS if not k.endswith('_mx_aug') and not k.endswith('_mx_r_aug'))
 
 
-# experiment: the key encoder's layer-1 convs on the implicit-GEMM kernel (64 KB of LDS, co-resident with other chains' kernels)
-# instead of the window-resident one (144 KB: nothing else runs on the CU meanwhile)
-KEY_NO_HALO = os.environ.get('MSCL_KEY_NO_HALO', '0') == '1'
-
-
-# under whole-step capture the RGB query chain (main stream, the step's critical chain) is recorded before the side chains:
-# 932.4-933.0 vs 928.8-931.2 clip-pairs/s in three alternating pairs; =0 records it last (eager launches always issue it last)
-ISSUE_QUERY_FIRST = os.environ.get('MSCL_ISSUE_QUERY_FIRST', '1') == '1'
-
-
 def momentum_at(iters, max_iters, m_base):
     """ref: moco.py:413-415."""
     factor = min(iters / max_iters, 1)
@@ -190,15 +180,7 @@ class MoCoV2(nn.Module):
     def encode_k(self, x, levels=()):
         """key forward (moco.py:535-545).  k_mlvl has no reader on the MSCL path once the dead unshuffle all-gathers are
         dropped, so by default the key neck computes the embedding only."""
-        if KEY_NO_HALO:
-            from . import lib as _lib
-            _lib.call('mscl_set_halo_off', 1)
-            try:
-                feats = self.encoder_k(x)
-            finally:
-                _lib.call('mscl_set_halo_off', 0)
-        else:
-            feats = self.encoder_k(x)
+        feats = self.encoder_k(x)
         emb_maps, _ = self.neck_k(feats, levels=levels)
         emb, maps = emb_maps
         return mlp_head(self.mlp_k, emb), maps
@@ -655,7 +637,6 @@ class MSCLWithAug(nn.Module):
         # Also NOT safe under whole-step capture: the final loss of those runs sat 1.2 below the default's (36.0 vs 37.2 +- 0.2) --
         # tensor.record_stream() is what keeps dy / x alive for the side stream, and the allocator does not honour it for
         # allocations of a graph's private pool.
-        self.wgrad_stream = os.environ.get('MSCL_WGRAD_STREAM', '0')
         self._side = None
 
     # ------------------------------------------------------------------ device placement
@@ -891,8 +872,7 @@ class MSCLWithAug(nn.Module):
         import time
         from .streams import pick_side_streams
         dev = self.arena.device
-        prio = int(os.environ.get('MSCL_SIDE_PRIORITY', '0'))          # HIP: larger = lower priority than the main chain
-        cand = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n if os.environ.get('MSCL_STREAM_PROBE') == '0' else 12)]
+        cand = [torch.cuda.Stream(device=dev) for _ in range(n if os.environ.get('MSCL_STREAM_PROBE') == '0' else 12)]
         if len(cand) == n or torch.cuda.is_current_stream_capturing():
             return cand[:n]
         main = torch.cuda.current_stream()
@@ -1005,16 +985,13 @@ class MSCLWithAug(nn.Module):
         # also serves both queue writes (moco.py:426) -- 4 collectives per step in the forward instead of 9.
         main = torch.cuda.current_stream()
         multi = self.two_streams
-        nn_hip.WGRAD_SIDE.clear()
-        if multi and self.wgrad_stream != '0':
-            nn_hip.WGRAD_SIDE[main.cuda_stream] = self._side_stream({'1': 2, 'flow': 0, 'key': 1}[self.wgrad_stream])   # RGB backward: wgrad off the dgrad chain
         s_fq = self._side_stream(0) if multi else main       # flow query passes (base, rotated): share BN running stats -> in order
-        s_fk = self._side_stream(2) if (multi and os.environ.get('MSCL_FLOWK_STREAM') == '1') else s_fq    # flow key passes share the flow stream (a 4th stream measured 3 % slower in round 1)
+        s_fk = s_fq                                          # flow key passes share the flow stream (a 4th stream measured 3-6 % slower)
         side = s_fq
         for st in (s_fq, s_fk):
             if st is not main:
                 st.wait_stream(main)
-        side_k = self._side_stream(0 if os.environ.get('MSCL_KEY_ON_FLOW') == '1' else 1) if side is not main else main   # (=1: A/B with two streams)
+        side_k = self._side_stream(1) if side is not main else main   # RGB key chain on its own stream (on the flow stream: -7 %)
         if side_k is not main:
             side_k.wait_stream(main)
         if dp:
@@ -1041,7 +1018,9 @@ class MSCLWithAug(nn.Module):
             return rec.encode_q(x_q, levels=(ids[0],))       # LMCL reads one pyramid level (local_cl_head.py:59)
         # (only while a whole-step capture records: there the order is just the graph's node order.  Eager launches keep the query
         #  chain last -- its ~250 host-side launches would otherwise delay the side chains' cheap sub-graph replays by ~2.5 ms)
-        q_first = ISSUE_QUERY_FIRST and torch.cuda.is_current_stream_capturing()
+        # under whole-step capture the RGB query chain (the step's critical chain) is recorded before the side chains (+0.3 %);
+        # eager launches always issue it last
+        q_first = torch.cuda.is_current_stream_capturing()
         if q_first:
             q_rgb, maps_rgb = issue_query()
         with torch.cuda.stream(s_fq):

@@ -108,7 +108,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--modes', default='fwd,dgrad,wgrad')
     ap.add_argument('--sweep', default=None, help='NAME=v1,v2,..: A/B an environment tuning hook that the library reads per '
-                    'launch (e.g. MSCL_FAST_STAGES=2,3,4), variants interleaved per shape in ONE process')
+                    'launch (e.g. MSCL_PP=0,1,2), variants interleaved per shape in ONE process')
     ap.add_argument('--rounds', type=int, default=3, help='rounds per variant with --sweep (min is reported)')
     ap.add_argument('--r50', action='store_true', help='the ResNet3dSlowOnly-50 shapes at 8 x 32 x 224^2 instead (adds a GB/s column: x + y bytes)')
     ap.add_argument('--no-stats', action='store_true', help='forward without the BatchNorm statistics epilogue')
