@@ -310,6 +310,16 @@ int mscl_rowdot(const float* a, const float* b, float* out, int rows, int dim, v
 int mscl_nce_pos_bwd(const float* kpos, const float* pos, const float* lse, const float* row_scale, float* dq,
                      int R, int dim, float inv_T, void* stream);
 
+/* Loss-phase layout in two launches (recognizers/mscl.py:239-261, heads/moco_head_v2.py:38-53, local_cl_head.py:59): pack the
+ * query / key rows of the RGB-queue pass (A) and the post-enqueue flow-queue pass (C), their row scales and the LMCL flow frames
+ * into one workspace  QA[n B D] KA[n B D] QC[n B D] KC[n B D] sA[n B] sC[n B] ones[B] flow[B 2t Cf]  (n = 3 with use_aug, else 2);
+ * unpack: out = dq_rgb[B D] dq_fb[B D] dq_fa[B D] dp_rgb[B t C] dp_fb[B t Cf] dp_fa[B t Cf] from the passes' query gradients. */
+int mscl_loss_pack(const float* q_rgb, const float* q_fb, const float* q_fa, const float* k_rgb, const float* k_fb,
+                   const float* k_fa, const float* p_fb, const float* p_fa, float* ws, int B, int D, int t, int Cf,
+                   int use_aug, float w_intra, void* stream);
+int mscl_loss_unpack(const float* dA, const float* dB, const float* dC, const float* dpr, const float* dpf, float* out,
+                     int B, int D, int t, int C, int Cf, int use_aug, void* stream);
+
 /* queue bookkeeping, bit-exact int64: count += 1; queue[:, ptr:ptr+n] = keys^T; count[ptr:ptr+n] = 1;
  * ptr = (ptr+n) % K.   recognizers/moco.py:423-440.  keys: (n, dim) fp32, ptr: int64[1] on device. */
 int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, const float* keys, int n, int dim, int K, void* stream);

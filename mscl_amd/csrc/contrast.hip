@@ -516,3 +516,79 @@ extern "C" int mscl_nce_pos_bwd(const float* kpos, const float* pos, const float
   MSCL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Loss-phase glue in two launches (was ~20 torch.cat / repeat / add / slice kernels between the InfoNCE passes):
+// mscl_loss_pack lays the query / key rows of the three queue passes, their row scales and the LMCL flow frames out in ONE
+// workspace; mscl_loss_unpack sums the passes' query gradients per input and splits the LMCL flow gradient back.
+// Row groups (B rows each), in the order the reference builds its logits (recognizers/mscl.py:239-261, heads/moco_head_v2.py:38-53):
+//   pass A (RGB queue, pre-enqueue):      queries [q_rgb | q_fb | q_fa*], keys k_rgb for every group            (* with aug_mx only)
+//   pass C (flow queue, post-enqueue):    queries [q_fa | q_rgb | q_rgb*], keys [k_fa | k_fb | k_fa*], scales [w_intra/B | 1/B | 1/B*]
+// Workspace (floats): QA[nA B D] KA[nA B D] QC[nC B D] KC[nC B D] sA[nA B] sC[nC B] ones[B] flow[B 2t Cf]
+struct LossPackArgs {
+  const float *q_rgb, *q_fb, *q_fa, *k_rgb, *k_fb, *k_fa, *p_fb, *p_fa;
+  float* ws;
+  int B, D, t, Cf, n;        // n = 3 with the aug cross-modal terms, else 2
+  float w_intra;
+};
+__global__ __launch_bounds__(256) void loss_pack_kernel(const LossPackArgs a) {
+  const int BD = a.B * a.D, n = a.n;
+  const long oQA = 0, oKA = (long)n * BD, oQC = 2L * n * BD, oKC = 3L * n * BD, osA = 4L * n * BD, osC = osA + (long)n * a.B,
+             oone = osC + (long)n * a.B, oflow = oone + a.B;
+  const long total = oflow + (long)a.B * 2 * a.t * a.Cf;
+  const float invB = 1.f / (float)a.B;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    if (i < oKA) { const int gq = (int)(i / BD); const long e = i - (long)gq * BD; v = (gq == 0 ? a.q_rgb : gq == 1 ? a.q_fb : a.q_fa)[e]; }
+    else if (i < oQC) { v = a.k_rgb[(i - oKA) % BD]; }
+    else if (i < oKC) { const long r = i - oQC; const int gq = (int)(r / BD); v = (gq == 0 ? a.q_fa : a.q_rgb)[r - (long)gq * BD]; }
+    else if (i < osA) { const long r = i - oKC; const int gq = (int)(r / BD); v = (gq == 1 ? a.k_fb : a.k_fa)[r - (long)gq * BD]; }
+    else if (i < osC) v = invB;
+    else if (i < oone) v = (i - osC < a.B) ? a.w_intra * invB : invB;
+    else if (i < oflow) v = invB;
+    else {                      // flow[b][f][c]: frames 0..t-1 of the base pass, t..2t-1 of the rotated pass (local_cl_head.py:59)
+      const long r = i - oflow; const int c = (int)(r % a.Cf); const long bf = r / a.Cf; const int f = (int)(bf % (2 * a.t)), b = (int)(bf / (2 * a.t));
+      v = f < a.t ? a.p_fb[((long)b * a.t + f) * a.Cf + c] : a.p_fa[((long)b * a.t + f - a.t) * a.Cf + c];
+    }
+    a.ws[i] = v;
+  }
+}
+extern "C" int mscl_loss_pack(const float* q_rgb, const float* q_fb, const float* q_fa, const float* k_rgb, const float* k_fb,
+                              const float* k_fa, const float* p_fb, const float* p_fa, float* ws, int B, int D, int t, int Cf,
+                              int use_aug, float w_intra, void* stream) {
+  if (!q_rgb || !q_fb || !q_fa || !k_rgb || !k_fb || !k_fa || !p_fb || !p_fa || !ws || B <= 0 || D <= 0 || t <= 0 || Cf <= 0) return MSCL_E_ARG;
+  LossPackArgs a{q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa, p_fb, p_fa, ws, B, D, t, Cf, use_aug ? 3 : 2, w_intra};
+  hipLaunchKernelGGL(loss_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, a);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+// out (floats): dq_rgb[B D] dq_fb[B D] dq_fa[B D] dp_rgb[B t C] dp_fb[B t Cf] dp_fa[B t Cf]
+//   dq_rgb = dA[0] + dC[1] (+ dC[2]),  dq_fb = dA[1] + dB,  dq_fa = dC[0] (+ dA[2])      (dA, dC: [n B D], dB: [B D])
+//   dp_fb / dp_fa = frames 0..t-1 / t..2t-1 of dpf [B 2t Cf];  dp_rgb = dpr [B t C]
+__global__ __launch_bounds__(256) void loss_unpack_kernel(const float* __restrict__ dA, const float* __restrict__ dB,
+                                                          const float* __restrict__ dC, const float* __restrict__ dpr,
+                                                          const float* __restrict__ dpf, float* __restrict__ out, int B, int D, int t,
+                                                          int C, int Cf, int n) {
+  const long BD = (long)B * D, o1 = BD, o2 = 2 * BD, o3 = 3 * BD, o4 = o3 + (long)B * t * C, o5 = o4 + (long)B * t * Cf, total = o5 + (long)B * t * Cf;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    if (i < o1) v = dA[i] + dC[BD + i] + (n == 3 ? dC[2 * BD + i] : 0.f);
+    else if (i < o2) v = dA[BD + (i - o1)] + dB[i - o1];
+    else if (i < o3) v = dC[i - o2] + (n == 3 ? dA[2 * BD + (i - o2)] : 0.f);
+    else if (i < o4) v = dpr[i - o3];
+    else {
+      const bool aug = i >= o5; const long r = i - (aug ? o5 : o4);
+      const int c = (int)(r % Cf); const long bf = r / Cf; const int f = (int)(bf % t), b = (int)(bf / t);
+      v = dpf[((long)b * 2 * t + f + (aug ? t : 0)) * Cf + c];
+    }
+    out[i] = v;
+  }
+}
+extern "C" int mscl_loss_unpack(const float* dA, const float* dB, const float* dC, const float* dpr, const float* dpf, float* out,
+                                int B, int D, int t, int C, int Cf, int use_aug, void* stream) {
+  if (!dA || !dB || !dC || !dpr || !dpf || !out || B <= 0 || D <= 0 || t <= 0 || C <= 0 || Cf <= 0) return MSCL_E_ARG;
+  hipLaunchKernelGGL(loss_unpack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, dA, dB, dC, dpr, dpf, out, B, D, t, C, Cf, use_aug ? 3 : 2);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}

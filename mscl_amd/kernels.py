@@ -452,6 +452,30 @@ def rowdot(a, b):
     return out
 
 
+def loss_pack(q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa, p_fb, p_fa, t, use_aug, w_intra):
+    """one launch for the loss phase's row layout (mscl_loss_pack): returns views QA, KA, sA, QC, KC, sC, ones, flow of one buffer"""
+    B, D = q_rgb.shape
+    Cf = p_fb.shape[1]
+    n = 3 if use_aug else 2
+    sizes = [n * B * D] * 4 + [n * B, n * B, B, B * 2 * t * Cf]
+    ws = torch.empty((sum(sizes),), dtype=torch.float32, device=q_rgb.device)
+    call('mscl_loss_pack', ptr(q_rgb), ptr(q_fb), ptr(q_fa), ptr(k_rgb), ptr(k_fb), ptr(k_fa), ptr(p_fb), ptr(p_fa), ptr(ws),
+         B, D, t, Cf, int(use_aug), float(w_intra), stream_ptr())
+    parts, o = [], 0
+    for sz in sizes:
+        parts.append(ws[o:o + sz]); o += sz
+    QA, KA, QC, KC, sA, sC, ones, flow = parts
+    return (QA.view(n * B, D), KA.view(n * B, D), sA, QC.view(n * B, D), KC.view(n * B, D), sC, ones, flow.view(B, 2 * t, Cf), ws)
+
+
+def loss_unpack(dA, dB, dC, dpr, dpf, B, D, t, C, Cf, use_aug):
+    """one launch for the loss node's input gradients (mscl_loss_unpack): flat buffer + views dq_rgb, dq_fb, dq_fa, dp_rgb, dp_fb, dp_fa"""
+    sizes = [B * D] * 3 + [B * t * C, B * t * Cf, B * t * Cf]
+    out = torch.empty((sum(sizes),), dtype=torch.float32, device=dA.device)
+    call('mscl_loss_unpack', ptr(dA), ptr(dB), ptr(dC), ptr(dpr), ptr(dpf), ptr(out), B, D, t, C, Cf, int(use_aug), stream_ptr())
+    return out, sizes
+
+
 def nce_pos_bwd(kpos, pos, lse, row_scale, dq, inv_T):
     call('mscl_nce_pos_bwd', ptr(kpos), ptr(pos), ptr(lse), ptr(row_scale), ptr(dq), dq.shape[0], dq.shape[1], inv_T, stream_ptr())
 

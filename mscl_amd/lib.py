@@ -77,6 +77,8 @@ _SIGS = {
     'mscl_nce_bwd': [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_float, P],
     'mscl_rowdot': [P, P, P, c_int, c_int, P],
     'mscl_nce_pos_bwd': [P, P, P, P, P, c_int, c_int, c_float, P],
+    'mscl_loss_pack': [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P],
+    'mscl_loss_unpack': [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     'mscl_queue_enqueue': [P, P, P, P, c_int, c_int, c_int, P],
     'mscl_lmcl': [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'mscl_ema_update': [P, P, P, c_int64, c_float, P],

@@ -485,7 +485,12 @@ class _MSCLLossFn(torch.autograd.Function):
         if not model.same_kn:
             raise NotImplementedError('same_kn=False is not used by the MSCL configs')
         dev = q_rgb.device
-        ones = torch.full((B,), 1.0 / B, device=dev)
+        t = p_rgb.shape[0] // B
+        C, Cf = p_rgb.shape[1], p_fb.shape[1]
+        # every row layout of this phase in ONE launch (was ~10 torch.cat / repeat / full kernels): kernels.loss_pack
+        QA, KA, sA, QC, KC, sC, ones, flow, pack_ws = K.loss_pack(q_rgb.contiguous(), q_fb.contiguous(), q_fa.contiguous(), k_rgb.contiguous(),
+                                                                 k_fb.contiguous(), k_fa.contiguous(), p_fb.contiguous(), p_fa.contiguous(),
+                                                                 t, use_aug_mx, w_intra)
 
         def run(queue_owner, Q, Kp, scale, virt=None):
             pos = K.rowdot(Q, Kp)
@@ -494,34 +499,29 @@ class _MSCLLossFn(torch.autograd.Function):
             K.nce_pos_bwd(Kp, pos, lse, scale, dq, inv_T)
             return loss_rows, rank, dq
 
-        # pass A: RGB queue before this step's enqueue (moco.py:484-488 snapshot; fr logits moco_head_v2.py:44,47).
-        # It shares nothing with passes B -> enqueue -> C on the flow queue, and this phase is a string of small launches
-        # with every other chain already joined: A runs on the (now idle) RGB-key stream beside B / C.
-        rowsA = [q_rgb, q_fb] + ([q_fa] if use_aug_mx else [])
+        # pass A: RGB queue before this step's enqueue (moco.py:484-488 snapshot; fr logits moco_head_v2.py:44,47): query rows
+        # [q_rgb | q_fb | q_fa] against k_rgb.  It shares nothing with passes B -> enqueue -> C on the flow queue, and this phase is
+        # a string of small launches with every other chain already joined: A runs on the (now idle) RGB-key stream beside B / C.
         main = torch.cuda.current_stream()
         fork = model._side_stream(1) if (model.two_streams and model.loss_fork) else None
         if fork is not None:
             fork.wait_stream(main)
-            for tns in rowsA + [k_rgb, ones]:
-                tns.record_stream(fork)
+            pack_ws.record_stream(fork)
         with torch.cuda.stream(fork if fork is not None else main):
-            QA = torch.cat(rowsA, 0)
-            lossA, rankA, dA = run(rec, QA, k_rgb.repeat(len(rowsA), 1), ones.repeat(len(rowsA)))
+            lossA, rankA, dA = run(rec, QA, KA, sA)
         kg = model._kglobal
-        # pass C reads the flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug.  It takes that
-        # snapshot "virtually" -- ages + 1, the columns the enqueue will write replaced by the keys it will write
+        # pass C reads the flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug -- query rows
+        # [q_fa | q_rgb | q_rgb] against keys [k_fa | k_fb | k_fa], the first group scaled by weight_aug_flow[0].  With loss_fork_c it
+        # takes that snapshot "virtually" -- ages + 1, the columns the enqueue will write replaced by the keys it will write
         # (kernels.nce_forward(virt=)) -- so it does not wait for pass B and the write: it runs on the idle flow stream beside B
-        rowsC = [q_fa, q_rgb] + ([q_rgb] if use_aug_mx else [])
-        keysC = [k_fa, k_fb] + ([k_fa] if use_aug_mx else [])
         forkC = model._side_stream(0) if (model.two_streams and model.loss_fork_c) else None
         newk = kg.get('fb') if kg.get('fb') is not None else k_fb          # what dequeue_and_enqueue will write (gathered at W > 1)
         if forkC is not None:
             forkC.wait_stream(main)
-            for tns in rowsC + keysC + [ones, newk]:
+            for tns in (pack_ws, newk):
                 tns.record_stream(forkC)
             with torch.cuda.stream(forkC):
-                scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
-                lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC, virt=(newk.contiguous(), recf.queue_ptr))
+                lossC, rankC, dC = run(recf, QC, KC, sC, virt=(newk.contiguous(), recf.queue_ptr))
         # pass B: flow queue before enqueue -> loss_cls_flow
         lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
         if forkC is not None:
@@ -530,8 +530,7 @@ class _MSCLLossFn(torch.autograd.Function):
                 tns.record_stream(main)
         recf.dequeue_and_enqueue(k_fb, kg.get('fb'))                     # base pass: update_queue=True (mscl.py:239)
         if forkC is None:
-            scaleC = torch.cat([ones * w_intra, ones] + ([ones] if use_aug_mx else []))
-            lossC, rankC, dC = run(recf, torch.cat(rowsC, 0), torch.cat(keysC, 0), scaleC)
+            lossC, rankC, dC = run(recf, QC, KC, sC)
         if model.update_aug_flow:
             recf.dequeue_and_enqueue(k_fa, kg.get('fa'))
         if fork is not None:
@@ -539,10 +538,7 @@ class _MSCLLossFn(torch.autograd.Function):
             for tns in (lossA, rankA, dA):
                 tns.record_stream(main)
         rec.dequeue_and_enqueue(k_rgb, kg.get('rgb'))
-        # LMCL (local_cl_head.py:57-73): RGB frame-slot features vs [base flow | rotated flow] frames
-        t = p_rgb.shape[0] // B
-        C, Cf = p_rgb.shape[1], p_fb.shape[1]
-        flow = torch.cat([p_fb.view(B, t, Cf), p_fa.view(B, t, Cf)], dim=1).contiguous()
+        # LMCL (local_cl_head.py:57-73): RGB frame-slot features vs [base flow | rotated flow] frames (`flow`, laid out by loss_pack)
         trans = getattr(model.sup_head, 'trans_flow', None)
         if trans is not None:                 # Conv1d(Cf, 128, 1) over the frame axis == a linear map per frame (local_cl_head.py:65)
             trt = trans._rt
@@ -564,26 +560,26 @@ class _MSCLLossFn(torch.autograd.Function):
             dpf = K.linear_bwd(flow_in, trt['w'], flow.view(B * 2 * t, C), dpf.view(B * 2 * t, C).contiguous(), stage[0], stage[1], False)
             ctx.trans_rt = trt
 
-        def grp(v, i):
-            return v[i * B:(i + 1) * B]
         # the 17 / 23 log entries (heads/moco_head.py:60-77 per group, base.py:297-298 total) in one launch
         logs = K.step_logs(rankA, lossA, rankB, lossB, rankC, lossC, lsum, hits, B, 3 if use_aug_mx else 2, w_intra, float(B * t))
         ctx.log_keys = LOG_KEYS if use_aug_mx else LOG_KEYS_NO_AUG_MX
         total = logs[-1]
-        # gradients w.r.t. the differentiable inputs (loss weights folded in by the row scales)
-        dq_rgb = grp(dA, 0) + grp(dC, 1) + (grp(dC, 2) if use_aug_mx else 0)
-        dq_fb = grp(dA, 1) + dB
-        dq_fa = grp(dC, 0) + (grp(dA, 2) if use_aug_mx else 0)
-        dpf = dpf.view(B, 2 * t, Cf)
-        ctx.save_for_backward(dq_rgb, dq_fb, dq_fa, dpr.view(B * t, C), dpf[:, :t].reshape(B * t, Cf),
-                              dpf[:, t:].reshape(B * t, Cf))
+        # gradients w.r.t. the differentiable inputs (loss weights folded in by the row scales), summed over the passes and laid
+        # out in ONE buffer by one launch (kernels.loss_unpack): backward() then scales it once
+        flat, sizes = K.loss_unpack(dA, dB, dC, dpr.reshape(B * t, C), dpf.reshape(B * 2 * t, Cf), B, dim, t, C, Cf, use_aug_mx)
+        ctx.save_for_backward(flat)
+        ctx.sizes, ctx.shapes = sizes, ((B, dim), (B, dim), (B, dim), (B * t, C), (B * t, Cf), (B * t, Cf))
         ctx.mark_non_differentiable(logs)
         model._log_keys = ctx.log_keys
         return total.clone(), logs
 
     @staticmethod
     def backward(ctx, g, _glogs):
-        grads = tuple(g * t for t in ctx.saved_tensors)
+        flat = ctx.saved_tensors[0] * g
+        grads, o = [], 0
+        for sz, shp in zip(ctx.sizes, ctx.shapes):
+            grads.append(flat[o:o + sz].view(shp)); o += sz
+        grads = tuple(grads)
         trt = ctx.trans_rt
         if trt is not None:                  # LMCL flow transform (mscl_r50): parameter gradients into the arena, scaled by g
             trt['dw'].add_(trt['stage'][0] * g)
