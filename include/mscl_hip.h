@@ -182,6 +182,10 @@ int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out, const uint
  * along W = the horizontal flip of common/ssl_aug_v2.py:107-118 given its Bernoulli draw. */
 int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
                     const float* mean3, const float* std3, const uint8_t* flip_mask, void* stream);
+/* the same with the clip's device address read from device memory at kernel time (*xpp): a launch captured into a HIP graph whose
+ * input batch changes per replay -- the caller rewrites the pointer word, in stream order, before each replay */
+int mscl_pack_input_ind(const float* const* xpp, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
+                        const float* mean3, const float* std3, const uint8_t* flip_mask, void* stream);
 /* (rows, W, 8) bf16 packed 3-channel clip -> (rows, (W+1)/2 + 1, 8): pair j = pixels 2j-1 and 2j of the row as channels
  * [3p + c], zeros outside.  Turns the RGB stem (torchvision BasicStem == backbones/r3d.py:176-184: Conv3d(3, 64, (3,7,7),
  * stride (1,2,2), padding (1,3,3))) into a (3,7,4) / stride (1,2,1) / padding (1,3,1) convolution over the pairs with

@@ -11,7 +11,10 @@ static long ew_cap() { return 2048; }        // grid cap of the element-wise pas
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B,
                                                          int Cin, long THW, long THW_total, long off, float m0, float m1,
                                                          float m2, float i0, float i1, float i2,
-                                                         const unsigned char* __restrict__ flip, int W) {
+                                                         const unsigned char* __restrict__ flip, int W,
+                                                         const float* const* __restrict__ xind) {
+  // xind != NULL: the clip's address is read from device memory (mscl_pack_input_ind: a captured launch whose input changes per replay)
+  if (xind != nullptr) x = *xind;
   // blockIdx.y = sample: no per-element division
   const long b = blockIdx.y;
   const bool fl = flip != nullptr && flip[b];
@@ -37,7 +40,22 @@ extern "C" int mscl_pack_input(const float* x, uint16_t* out, int B, int Cin, in
   const long THW = (long)T * H * W;
   long blocks = (THW + 255) / 256; if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out, B, Cin, THW,
-                     (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2], flip_mask, W);
+                     (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2], flip_mask, W,
+                     (const float* const*)nullptr);
+  MSCL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mscl_pack_input_ind(const float* const* xpp, uint16_t* out, int B, int Cin, int T, int H, int W, int T_total, int t_off,
+                                   const float* mean3, const float* std3, const uint8_t* flip_mask, void* stream) {
+  if (!xpp || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t_off < 0 || t_off + T > T_total) return MSCL_E_ARG;
+  if (Cin < 1 || Cin > 3) return MSCL_E_SHAPE;
+  float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
+  if (mean3 && std3) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; iv[i] = 1.f / std3[i]; }
+  const long THW = (long)T * H * W;
+  long blocks = (THW + 255) / 256; if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, out, B,
+                     Cin, THW, (long)T_total * H * W, (long)t_off * H * W, m[0], m[1], m[2], iv[0], iv[1], iv[2], flip_mask, W, xpp);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -206,6 +206,21 @@ def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, r
     return dy, dres
 
 
+class IndirectInput:
+    """A (B,C,T,H,W) contiguous fp32 clip whose device address is read from a device word (`slot`, one int64) at kernel time:
+    what a whole-step HIP graph takes as its inputs, so that a new batch costs a pointer upload instead of a copy into static
+    buffers (graph.py).  Quacks like the tensor for the few attributes the step touches before mscl_pack_input reads it."""
+
+    def __init__(self, slot, shape, device):
+        self.slot, self.shape, self.device = slot, tuple(shape), device
+
+    def contiguous(self):
+        return self
+
+    def is_contiguous(self):
+        return True
+
+
 def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None, out=None):
     """frames [t_off, t_off+T) of (B,C<=3,Ttot,H,W) fp32 -> (B,T,H,W,8) bf16, optional (x-mean)/std, optional
     per-sample horizontal flip (uint8 mask of B entries on the device)."""
@@ -219,7 +234,10 @@ def pack_input(x, mean=None, std=None, t_off=0, T=None, flip=None, out=None):
         raise lib.MsclError('pack_input: `out` must be a contiguous (B,T,H,W,8) bf16 tensor')
     m = (ctypes.c_float * 3)(*mean) if mean is not None else None
     s = (ctypes.c_float * 3)(*std) if std is not None else None
-    call('mscl_pack_input', ptr(x), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, ptr(flip), stream_ptr())
+    if isinstance(x, IndirectInput):
+        call('mscl_pack_input_ind', ptr(x.slot), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, ptr(flip), stream_ptr())
+    else:
+        call('mscl_pack_input', ptr(x), ptr(out), B, C, T, H, W, Ttot, t_off, m, s, ptr(flip), stream_ptr())
     return out
 
 

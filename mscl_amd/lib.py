@@ -50,6 +50,7 @@ _SIGS = {
     'mscl_bn_act_fwd_groups': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, c_int, P],
     'mscl_bn_act_bwd_groups': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, c_int, P],
     'mscl_pack_input': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P],
+    'mscl_pack_input_ind': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P],
     'mscl_pair_w': [P, P, c_int64, c_int, P],
     'mscl_flow_visualize': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     'mscl_flow_fra_visualize': [P, P, c_float, c_float, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P, P],

@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B of one environment switch on the whole step, alternating pairs inside one call.  usage: VAR=MSCL_PP A=0 B=1 bash tools/r03_step_ab.sh
+# A/B of one environment switch on the whole step, alternating rounds inside one call.
+# usage: VAR=MSCL_PP VALS="0 1 2" N=2 bash tools/r03_step_ab.sh
 set -o pipefail
 mkdir -p gpurun_out
-VAR=${VAR:-MSCL_PP}; A=${A:-0}; B=${B:-1}; N=${N:-2}
+VAR=${VAR:-MSCL_PP}; VALS=${VALS:-"0 1"}; N=${N:-2}
 for i in $(seq 1 $N); do
-  for v in $A $B; do
+  for v in $VALS; do
     env $VAR=$v timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2> gpurun_out/ab_err.log | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']
