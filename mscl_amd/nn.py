@@ -245,6 +245,29 @@ def _bucket_done(mod):
         red.bucket_done(i)
 
 
+class BucketCounter:
+    """Order-independent trigger for a gradient bucket whose modules are applied several times per step in an order autograd
+    does not promise (the FPN / SEPC convs shared across pyramid levels, the projection MLP): every forward application made
+    under autograd counts up, every backward counts down, and the bucket's all-reduce starts when the count returns to zero --
+    i.e. when the last of this step's applications has written its weight gradient.  An application whose output nothing reads
+    never runs backward: the count then stays positive and GradReducer.finish() sends the bucket (and resets the count)."""
+
+    def __init__(self, reducer, idx):
+        self.red, self.idx, self.pending = reducer, idx, 0
+        reducer.counters.append(self)
+
+    def fwd(self):
+        if torch.is_grad_enabled():
+            self.pending += 1
+            return True
+        return False
+
+    def bwd(self):
+        self.pending -= 1
+        if self.pending == 0 and not HOLD_BUCKETS[0]:
+            self.red.bucket_done(self.idx)
+
+
 def stem_input(conv, x):
     """the packed clip as the stem's kernels read it: pixel pairs along W for a pair_w stem (one 3-us pass)"""
     return K.pair_w(x) if conv.pair_w else x
@@ -658,9 +681,9 @@ class _ConvBiasFn(torch.autograd.Function):
     """out = relu?(conv(x) + bias + addend)"""
 
     @staticmethod
-    def forward(ctx, x, addend, conv, relu):
+    def forward(ctx, x, addend, conv, relu, counted):
         out = conv.fwd(x, addend=addend, relu=relu)
-        ctx.conv, ctx.relu, ctx.has_add = conv, relu, addend is not None
+        ctx.conv, ctx.relu, ctx.has_add, ctx.counted = conv, relu, addend is not None, counted
         ctx.save_for_backward(x, out)
         return out
 
@@ -669,12 +692,16 @@ class _ConvBiasFn(torch.autograd.Function):
         x, out = ctx.saved_tensors
         dz = K.relu_bwd(dout.contiguous(), out) if ctx.relu else dout.contiguous()
         ctx.conv.wgrad(x, dz)
+        if ctx.counted:
+            ctx.conv._bucket_counter.bwd()           # data-parallel: the last application of the bucket starts its all-reduce
         dx = ctx.conv.dgrad(dz, x.shape) if ctx.needs_input_grad[0] else None
-        return dx, (dz if ctx.has_add else None), None, None
+        return dx, (dz if ctx.has_add else None), None, None, None
 
 
 def conv_bias(conv, x, addend=None, relu=False):
-    return _ConvBiasFn.apply(x, addend, conv, relu)
+    c = getattr(conv, '_bucket_counter', None)
+    counted = c is not None and (x.requires_grad or (addend is not None and addend.requires_grad)) and c.fwd()
+    return _ConvBiasFn.apply(x, addend, conv, relu, counted)
 
 
 class _UpsampleFn(torch.autograd.Function):
@@ -715,12 +742,12 @@ class _MlpHeadFn(torch.autograd.Function):
     """q = normalize(Linear(ReLU(Linear(emb)))).  ref: recognizers/moco.py:367-372,528-529."""
 
     @staticmethod
-    def forward(ctx, emb, mlp):
+    def forward(ctx, emb, mlp, counted):
         l1, l2 = mlp[0], mlp[2]
         h = K.linear_fwd(emb, l1._rt['w'], l1._rt['b'], True)
         z = K.linear_fwd(h, l2._rt['w'], l2._rt['b'], False)
         q, norms = K.l2norm_fwd(z)
-        ctx.mlp = mlp
+        ctx.mlp, ctx.counted = mlp, counted
         ctx.save_for_backward(emb, h, z, q, norms)
         return q
 
@@ -734,11 +761,15 @@ class _MlpHeadFn(torch.autograd.Function):
         for l in (l1, l2):
             l._rt['slot_w'].touched = True
             l._rt['slot_b'].touched = True
-        return demb, None
+        if ctx.counted:
+            ctx.mlp._bucket_counter.bwd()
+        return demb, None, None
 
 
 def mlp_head(mlp, emb):
-    return _MlpHeadFn.apply(emb, mlp)
+    c = getattr(mlp, '_bucket_counter', None)
+    counted = c is not None and emb.requires_grad and c.fwd()
+    return _MlpHeadFn.apply(emb, mlp, counted)
 
 
 class LinearHip(nn.Module):

@@ -182,6 +182,7 @@ class GradReducer:
         self.flat, self.ranges = flat, list(ranges)
         self.need = list(need) if need is not None else [1] * len(self.ranges)   # trigger calls that complete a bucket
         self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)
+        self.counters = []                          # nn.BucketCounter objects that fire buckets of this reducer (reset in finish())
         self.transport = transport or os.environ.get('MSCL_GRAD_TRANSPORT', 'fp32')
         if self.transport not in ('fp32', 'bf16'):
             raise ValueError(f'gradient transport {self.transport!r}: fp32 or bf16')
@@ -215,6 +216,21 @@ class GradReducer:
             if seg is not None:
                 seg.div_(world_size())
         self.works, self.launched, self.hits = [], set(), [0] * len(self.ranges)
+        for c in self.counters:
+            c.pending = 0
+
+
+def exposed_wire_ms(bucket_bytes, fire_ms, backward_ms, world, link_gbps=153.0):
+    """The rule behind the gradient transport and the bucket split, checkable without a multi-GPU node:
+    buckets travel one after the other on the communicator's stream, a ring all-reduce moves 2 (W-1)/W of a bucket's bytes over
+    one xGMI link (~153 GB/s), bucket i starts when its trigger fires (`fire_ms` into backward, from the
+    measured chain) or when its predecessor is done.  Returns the milliseconds of wire time left after backward ends -- what the
+    step actually pays.  fp32 is kept while this stays under ~1 % of the step; bf16 transport halves `bucket_bytes`."""
+    t = 0.0
+    for nbytes, fire in sorted(zip(bucket_bytes, fire_ms), key=lambda p: p[1]):
+        wire = 2.0 * (world - 1) / world * nbytes / (link_gbps * 1e9) * 1e3
+        t = max(t, fire) + wire
+    return max(0.0, t - backward_ms)
 
 
 @torch.no_grad()

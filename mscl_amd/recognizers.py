@@ -703,15 +703,24 @@ class MSCLWithAug(nn.Module):
             return (min(s.off for s in slots), max(s.off + (s.numel + 63) // 64 * 64 for s in slots))
         rgb, flw = self.recognizer, self.recognizer_flow
         eq = rgb.encoder_q
-        # (range, trigger module whose backward completes it, traversals per step).  The neck / MLP bucket rides the
-        # RGB stem trigger: autograd's ready-queue order of neck nodes vs trunk nodes is not a contract.
-        buckets = [(span([eq.layer4]), eq.layer4[0], 1), (span([eq.layer3]), eq.layer3[0], 1),
-                   (span([eq.stem, eq.layer1, eq.layer2]), eq.stem, 1), (span([rgb.neck_q, rgb.mlp_q]), eq.stem, 1),
+        # (range, trigger module whose backward completes it, traversals per step).  Order = the order backward completes them:
+        # neck + projection MLP (14 MB; counted trigger: its convs are applied several times per step in an order autograd does
+        # not promise -- nn.BucketCounter fires when the last application has run backward), layer 4 (100 MB), layer 3, layer 2,
+        # stem + layer 1 (1.8 MB: all that is left to send when backward ends), the flow trunk.  Rule for the transport (DESIGN.md
+        # section 5, parallel.exposed_wire_ms): what matters is the wire time of the buckets that fire with less backward left than
+        # they take to send -- with this split 1.8 MB, 20 us on a 7-link ring at fp32 -- so gradients travel as fp32.
+        buckets = [(span([eq.layer4]), eq.layer4[0], 1), (span([eq.layer3]), eq.layer3[0], 1), (span([eq.layer2]), eq.layer2[0], 1),
+                   (span([eq.stem, eq.layer1]), eq.stem, 1), (span([rgb.neck_q, rgb.mlp_q]), None, 1),
                    (span([flw.encoder_q, flw.neck_q, flw.mlp_q, self.sup_head]), flw.encoder_q.stem,
                     1 if self.flow_batch else 2)]            # head group follows the flow group
         self.reducer = parallel.GradReducer(ar.G, [b[0] for b in buckets], need=[b[2] for b in buckets])
         for i, (_, trig, _n) in enumerate(buckets):
-            trig._grad_buckets = getattr(trig, '_grad_buckets', ()) + ((self.reducer, i),)
+            if trig is not None:
+                trig._grad_buckets = getattr(trig, '_grad_buckets', ()) + ((self.reducer, i),)
+        neck_counter = nn_hip.BucketCounter(self.reducer, 4)
+        for m in list(rgb.neck_q.modules()) + [rgb.mlp_q]:
+            if isinstance(m, Conv3dHip) or m is rgb.mlp_q:
+                m._bucket_counter = neck_counter
         self.sync_shadows()
         return self
 

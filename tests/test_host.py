@@ -414,3 +414,34 @@ def test_bench_called_bare_with_gpus_n_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'WORLD_SIZE=4' in str(e.value.code)
+
+
+def test_bucket_counter_and_transport_rule():
+    """nn.BucketCounter: a bucket whose modules run several times per step in any order fires exactly once, when the last recorded
+    application has run backward; applications made without autograd (the key encoder) do not count; finish() resets a count a dead
+    branch left open.  parallel.exposed_wire_ms: the rule behind the fp32 transport and the bucket split."""
+    from mscl_amd import nn as nn_hip, parallel
+
+    class FakeReducer:
+        def __init__(self):
+            self.counters, self.fired = [], []
+
+        def bucket_done(self, i):
+            self.fired.append(i)
+    red = FakeReducer()
+    c = nn_hip.BucketCounter(red, 4)
+    assert c.fwd() and c.fwd() and c.fwd()
+    with torch.no_grad():
+        assert not c.fwd()                       # key branch: not counted
+    c.bwd(); c.bwd()
+    assert red.fired == []
+    c.bwd()
+    assert red.fired == [4] and c.pending == 0
+    # layer 4 (100 MB) fires 0.9 ms into a 3.8-ms backward, layer 3 at 1.25, layer 2 at 1.8, the flow trunk at 1.7, neck + MLP at 0.5,
+    # stem + layer 1 when backward ends: fp32 over a 7-link ring leaves ~20 us exposed at 8 ranks; one bucket for everything, sent
+    # at the end, would leave 1.7 ms
+    sizes = [100.8e6, 25.2e6, 6.2e6, 1.8e6, 14.0e6, 2.8e6]
+    fires = [0.9, 1.25, 1.8, 3.78, 0.5, 1.7]
+    assert parallel.exposed_wire_ms(sizes, fires, 3.78, 8) < 0.03
+    assert 1.6 < parallel.exposed_wire_ms([sum(sizes)], [3.78], 3.78, 8) < 1.8
+    assert parallel.exposed_wire_ms(sizes, fires, 3.78, 2) < 0.02

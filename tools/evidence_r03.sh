@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-3 evidence from ONE gpurun call on the final code.  usage (dev container):
+#   gpurun --timeout 1200 -- "GIT_HEAD=$(git rev-parse --short HEAD) bash tools/evidence_r03.sh"
+# Every file it writes carries the commit (GIT_HEAD) it was measured on; copy gpurun_out/ev_r03/* to profiles/r03_*.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev_r03; rm -rf $O; mkdir -p $O
+H=${GIT_HEAD:-unknown}; echo "$H" > $O/HEAD
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_line_under_rocprof.json 2> $O/stats.err
+for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  n=$(echo $c | cut -d' ' -f1)
+  MSCL_STREAMS=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$n -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph > $O/pmc_$n.json 2> $O/pmc_$n.err
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/l1_$c -- python3 $R/tools/bench_conv.py --only l1_64_64 --iters 3 --modes fwd > $O/l1_$c.log 2>&1
+done
+cd $R
+{ echo "# commit $H: per-kernel MFMA busy and HBM traffic of the whole step (three PMC passes, single stream, eager)"; python3 tools/pmc_step_summary.py $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE 11; } > $O/step_utilisation.md 2> $O/step_utilisation.err
+{ echo "# commit $H: every conv stage alone (tools/bench_conv.py --iters 20), TFLOP/s against the 2500 TFLOP/s dense bf16 peak"; python3 tools/bench_conv.py --iters 20 2>/dev/null | grep -v amdgpu; } > $O/conv_stage.log
+{ echo "# commit $H"; python3 tools/chain_times.py 2>/dev/null | grep -v amdgpu; } > $O/chain_times.txt
+python3 tools/bench_trunk.py > $O/trunk_r18.json 2>/dev/null
+python3 tools/bench_trunk.py --r50 > $O/trunk_r50.json 2>/dev/null
+python3 bench.py --deterministic --no-cpu-baseline > $O/bench_line_deterministic.json 2>/dev/null
+f=$(ls $O/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
+rm -rf $O/stats $O/pmc_*/*/*.db 2>/dev/null
+ls -la $O | head -40; echo finished
