@@ -48,7 +48,7 @@ int mscl_abi_version(void);
  * epilogues, the BatchNorm-backward sums, weight / bias gradients over position splits, the small linear layers' input
  * gradient, the InfoNCE gradient, the LMCL loss -- is taken in a fixed order (per-block partials in slots or slabs, added in
  * index order), so two runs on the same inputs give bit-identical results.  Costs one extra read of each conv output (the
- * statistics pass, mscl_bn_stats) and a slab pass per weight gradient.  Process-wide; set it before the first step.
+ * statistics pass, mscl_bn_stats), a fold launch per BatchNorm sum and a slab pass per weight gradient.  Process-wide; set it before the first step.
  * Not covered: mscl_conv_halo64 called directly with statistics pointers, mscl_conv_halo64_dgrad_bn (both opt-in paths). */
 /* test aid: number of launches the ping-pong shared-tap conv kernel (conv_pp.hip) has taken in this process, so that a parity
  * test can assert which kernel family produced the result it checked */
@@ -57,11 +57,21 @@ int64_t mscl_debug_pp_launches(void);
 int64_t mscl_debug_win64_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);
-/* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order:
- * block x of MSCL_STAT_SLOTS plain-stores the sums of its row share into slot x of ssum / ssq ([group][slot][2][C]) */
-int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, void* stream);
-/* floats of workspace mscl_conv3d_wgrad needs for this layer in deterministic mode (0 otherwise) */
+/* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order and stored
+ * into slot 0 of ssum / ssq ([group][slot][2][C], ssq = ssum + C; the other slots must hold zeros and do so afterwards).
+ * Two levels: per-block partials over contiguous row shares, then one add per channel in partial order; the number of partials
+ * depends on (rows, C, groups) alone.  `parts`: scratch of >= mscl_det_parts_floats(rows, C, groups, 2) floats for the partials
+ * (up to MSCL_DET_PARTS = 128 blocks per group); NULL or smaller: the MSCL_STAT_SLOTS slots hold them (16 blocks, several
+ * times slower on the large maps). */
+int64_t mscl_det_parts_floats(int64_t rows, int C, int groups, int vecs);
+int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, float* parts, int64_t parts_floats,
+                  void* stream);
+/* floats of workspace mscl_conv3d_wgrad wants for this layer: the slabs of the shared-tap kernel (conv_wgrad_pp.hip) where it
+ * applies, the per-split slabs of deterministic mode otherwise (0: none needed) */
 int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias);
+int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
+/* test aid: launches taken by the shared-tap weight-gradient kernel (conv_wgrad_pp.hip) in this process */
+int64_t mscl_debug_wgrad_pp_launches(void);
 
 /* ---- Conv3d as implicit GEMM on MFMA (bf16 in, fp32 accumulate) --------------------------------
  * replaces nn.Conv3d forward in r3d.py:16-34,176-184,285-288 / fastonly.py:61-80,185-193 /
@@ -165,14 +175,17 @@ int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y
                     float* scratch, int64_t rows, int C, int relu, void* stream);
 
 /* with statistics groups: save_mean / save_invstd (and the residual's) are [G][C], scratch is [G][MSCL_STAT_SLOTS][4*C];
- * dgamma / dbeta receive the sum over the groups (relu = 2 is not available with G > 1) */
+ * dgamma / dbeta receive the sum over the groups (relu = 2 is not available with G > 1).
+ * det_parts: deterministic mode's scratch for the per-block partial sums, >= mscl_det_parts_floats(rows, C, groups, 4) floats
+ * (NULL or smaller: the slots of `scratch` hold them, 16 blocks); ignored outside deterministic mode. */
 int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out, const uint16_t* y,
                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                            float* dgamma, float* dbeta,
                            const uint16_t* res_y, const float* res_gamma, const float* res_mean, const float* res_invstd,
                            float* res_dgamma, float* res_dbeta,
                            uint16_t* dy, uint16_t* dres, int want_identity_dres,
-                           float* scratch, int64_t rows, int C, int relu, int groups, void* stream);
+                           float* scratch, int64_t rows, int C, int relu, int groups, float* det_parts, int64_t det_parts_floats,
+                           void* stream);
 
 /* ---- layout / elementwise ---------------------------------------------------------------------
  * frames [t_off, t_off+T) of (B,Cin<=3,T_total,H,W) fp32 NCTHW -> (B,T,H,W,8) bf16 NDHWC, channels Cin..7

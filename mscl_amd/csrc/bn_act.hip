@@ -143,14 +143,17 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
 }
 
 // ---- BatchNorm statistics of a stored map in a fixed summation order (deterministic mode; also a stand-alone entry point) ----
-// grid (MSCL_STAT_SLOTS, channel chunks, groups): block x of a group reduces the x-th contiguous share of the group's rows and
-// plain-stores its sums into slot x; bn_prepare adds the slots in slot order.  No atomics anywhere.
-__global__ __launch_bounds__(256) void bn_stats_det_kernel(const bf16_t* __restrict__ y, float* __restrict__ ssum,
-                                                           float* __restrict__ ssq, long rows, int C, int ldc) {
+// Two levels, no atomics anywhere.  Level 1, grid (P, channel chunks, groups): block x of a group reduces the x-th contiguous share
+// of the group's rows and plain-stores its sums as partial x.  Level 2 (det_fold_kernel): one thread per channel adds the P
+// partials in index order into slot 0.  P depends on the shape alone (mscl_det_parts), so the order of every sum is fixed.
+// The partials live in caller scratch (`parts`); without it they live in the MSCL_STAT_SLOTS slots themselves (P = slots: 16 blocks
+// for the whole map -- the round-2 form of this pass, 5x slower on the large maps) and the fold zeroes slots 1.. again.
+__global__ __launch_bounds__(256) void bn_stats_det_kernel(const bf16_t* __restrict__ y, float* __restrict__ part, long rows, int C,
+                                                           int ldc, long part_gstride) {
   extern __shared__ float sm[];     // red[2][4 waves][C]
   const int ch = blockIdx.y * C;
   y += ch + (long)blockIdx.z * rows * ldc;
-  const long go = ((long)blockIdx.z * MSCL_STAT_SLOTS + blockIdx.x) * 2 * ldc + ch;
+  const long go = blockIdx.z * part_gstride + (long)blockIdx.x * 2 * ldc + ch;      // partial [group][x][2][ldc]
   const int G = C >> 3;
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   const long per = (rows + gridDim.x - 1) / gridDim.x;
@@ -176,17 +179,65 @@ __global__ __launch_bounds__(256) void bn_stats_det_kernel(const bf16_t* __restr
   block_channel_sum(q, sm, G, C, 2, 1);
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += 256) {
-    ssum[go + i] = (sm[i] + sm[C + i]) + (sm[2 * C + i] + sm[3 * C + i]);
-    ssq[go + i] = (sm[4 * C + i] + sm[5 * C + i]) + (sm[6 * C + i] + sm[7 * C + i]);
+    part[go + i] = (sm[i] + sm[C + i]) + (sm[2 * C + i] + sm[3 * C + i]);
+    part[go + ldc + i] = (sm[4 * C + i] + sm[5 * C + i]) + (sm[6 * C + i] + sm[7 * C + i]);
   }
 }
 
-extern "C" int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, void* stream) {
+// level 2 of every deterministic BatchNorm sum: dst[group][v][c] = sum over p (in index order) of part[group][p][v][c], v < nvec;
+// part rows are [pvec][ldc] wide, dst rows [ldc]; dst_gstride = floats between the groups' slot 0.  zero_tail > 0: the partials
+// ARE slots 0 .. P-1 of dst (in place): slots 1 .. P-1 are zeroed again so that consumers may add any number of slots.
+__global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__ part, float* __restrict__ dst, int P, int nvec, int pvec,
+                                                       int ldc, long part_gstride, long dst_gstride, int zero_tail) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec * ldc) return;
+  const float* src = part + blockIdx.y * part_gstride + i;
+  float t = 0.f;
+  int p = 0;
+  for (; p + 8 <= P; p += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long)(p + u) * pvec * ldc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; p < P; ++p) t += src[(long)p * pvec * ldc];
+  float* d = dst + blockIdx.y * dst_gstride;
+  d[i] = t;
+  if (zero_tail)
+    for (int q = 1; q < P; ++q) d[(long)q * pvec * ldc + i] = 0.f;
+}
+
+// partial blocks of a deterministic pass over `rows_g` rows of a C-channel map: enough rows per block that its loads overlap
+// (a few trips of the unrolled loop), at most MSCL_DET_PARTS
+static inline int det_parts_of(long rows_g, int C) {
+  const int Cc = C > 512 ? 512 : C, RP = 256 / (Cc / 8);
+  long p = (rows_g + RP * 8 - 1) / (RP * 8);
+  if (p > MSCL_DET_PARTS) p = MSCL_DET_PARTS;
+  return p < 1 ? 1 : (int)p;
+}
+
+extern "C" int64_t mscl_det_parts_floats(int64_t rows, int C, int groups, int vecs) {
+  if (rows <= 0 || C <= 0 || groups < 1 || vecs < 1) return 0;
+  return (int64_t)groups * det_parts_of(rows / groups, C) * vecs * C;
+}
+
+extern "C" int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, float* parts,
+                             int64_t parts_floats, void* stream) {
   if (!y || !ssum || !ssq || rows <= 0 || C <= 0 || groups < 1 || rows % groups) return MSCL_E_ARG;
   if (C % 8 || ilog2_exact(C / 8) < 0 || C > 4096) return MSCL_E_SHAPE;
+  if (ssq != ssum + C) return MSCL_E_ARG;           // [slot][2][C]: the two sums of a slot are adjacent rows
   const int Cc = C > 512 ? 512 : C;
-  hipLaunchKernelGGL(bn_stats_det_kernel, dim3(MSCL_STAT_SLOTS, C / Cc, groups), dim3(256), (size_t)8 * Cc * sizeof(float),
-                     (hipStream_t)stream, y, ssum, ssq, (long)(rows / groups), Cc, C);
+  hipStream_t st = (hipStream_t)stream;
+  const bool own = parts != nullptr && parts_floats >= mscl_det_parts_floats(rows, C, groups, 2);
+  const int P = own ? det_parts_of(rows / groups, C) : MSCL_STAT_SLOTS;
+  float* part = own ? parts : ssum;
+  const long pgs = (long)P * 2 * C;                  // (in place: P = MSCL_STAT_SLOTS, the slots' own group stride)
+  hipLaunchKernelGGL(bn_stats_det_kernel, dim3(P, C / Cc, groups), dim3(256), (size_t)8 * Cc * sizeof(float), st, y, part,
+                     (long)(rows / groups), Cc, C, pgs);
+  MSCL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(det_fold_kernel, dim3((2 * C + 255) / 256, groups), dim3(256), 0, st, (const float*)part, ssum, P, 2, 2, C, pgs,
+                     (long)MSCL_STAT_SLOTS * 2 * C, own ? 0 : 1);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -197,7 +248,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const bf16_t* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ inv, const bf16_t* __restrict__ ry,
     const float* __restrict__ rmean, const float* __restrict__ rinv, float* __restrict__ scratch, long rows, int C,
-    int relu, const float* __restrict__ gamma, const float* __restrict__ beta, int ldc, int det) {
+    int relu, const float* __restrict__ gamma, const float* __restrict__ beta, int ldc, float* __restrict__ det_part,
+    long part_gstride) {
   extern __shared__ float sm[];     // red[3][4 waves][C]
   // maps wider than 512 channels (Bottleneck trunks, up to 2048) are cut into 512-channel chunks along blockIdx.y: C is the
   // chunk width the thread layout sees, ldc the row pitch of the maps and the channel count of the scratch layout
@@ -216,6 +268,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     if (ry) { ry += ro; rmean += blockIdx.z * ldc; rinv += blockIdx.z * ldc; }
     mean += blockIdx.z * ldc; inv += blockIdx.z * ldc;
     scratch += (long)blockIdx.z * MSCL_STAT_SLOTS * 4 * ldc;
+    if (det_part) det_part += ch + blockIdx.z * part_gstride + (long)blockIdx.x * 4 * ldc;      // partial [group][x][4][ldc]
   }
   const int G = C >> 3;             // threads per row; 256 % G == 0 required (C/8 power of two)
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
@@ -283,9 +336,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int w = 0; w < 4; ++w) t += sm[(vv * 4 + w) * C + c];
     // 16 slots: with one, the 1024 blocks of the layer-1 map each ended on the same 128 addresses, and same-address float
     // atomics serialise in L2 at ~25 ns apiece -- a 25-us tail on a 45-us pass
-    // deterministic mode: at most MSCL_STAT_SLOTS blocks per group, block x owns slot x (plain store; the apply pass adds the
-    // slots in slot order)
-    if (det) scratch[blockIdx.x * 4 * ldc + vv * ldc + c] = t;
+    // deterministic mode: block x plain-stores partial x; det_fold_kernel adds the partials in index order into slot 0
+    if (det_part) det_part[vv * ldc + c] = t;
     else atomicAdd(&scratch[(blockIdx.x % MSCL_STAT_ACTIVE) * 4 * ldc + vv * ldc + c], t);
   }
 }
@@ -381,7 +433,8 @@ extern "C" int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const 
                                uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
                                void* stream) {
   return mscl_bn_act_bwd_groups(dout, out, y, gamma, beta, save_mean, save_invstd, dgamma, dbeta, res_y, res_gamma, res_mean,
-                                res_invstd, res_dgamma, res_dbeta, dy, dres, want_identity_dres, scratch, rows, C, relu, 1, stream);
+                                res_invstd, res_dgamma, res_dbeta, dy, dres, want_identity_dres, scratch, rows, C, relu, 1, nullptr, 0,
+                                stream);
 }
 
 extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out, const uint16_t* y, const float* gamma,
@@ -389,7 +442,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
                                       float* dbeta, const uint16_t* res_y, const float* res_gamma, const float* res_mean,
                                       const float* res_invstd, float* res_dgamma, float* res_dbeta, uint16_t* dy,
                                       uint16_t* dres, int want_identity_dres, float* scratch, int64_t rows, int C, int relu,
-                                      int groups, void* stream) {
+                                      int groups, float* det_parts, int64_t det_parts_floats, void* stream) {
   if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
   if (groups < 1 || groups > 2 || rows % groups != 0) return MSCL_E_SHAPE;
   if (groups > 1 && relu == 2) return MSCL_E_ARG;
@@ -412,12 +465,21 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   constexpr long red_cap = 512;                // see mscl_bn_act_fwd_groups
   const long cap = red_cap / (chunks * groups);                    // wider grids measured slower (more atomics)
   if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
-  const int det = mscl_det() ? 1 : 0;
-  if (det && blocks > MSCL_STAT_SLOTS) blocks = MSCL_STAT_SLOTS;
+  // deterministic mode: partial x of block x (in the caller's `det_parts`, or in the slots themselves: 16 blocks), folded into slot 0
+  const bool det = mscl_det();
+  const bool own = det && det_parts != nullptr && det_parts_floats >= mscl_det_parts_floats(rows, C, groups, 4);
+  if (det) blocks = own ? det_parts_of(rows_g, C) : (blocks > MSCL_STAT_SLOTS ? MSCL_STAT_SLOTS : blocks);
   if (!pre) {
+    float* part = det ? (own ? det_parts : scratch) : nullptr;
+    const long pgs = (own ? blocks : (long)MSCL_STAT_SLOTS) * 4 * C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, chunks, groups), dim3(256), (size_t)12 * Cc * sizeof(float), st, dout,
-                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C, det);
+                       out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C, part, pgs);
     MSCL_LAUNCH_CHECK();
+    if (det) {
+      hipLaunchKernelGGL(det_fold_kernel, dim3((3 * C + 255) / 256, groups), dim3(256), 0, st, (const float*)part, scratch, (int)blocks,
+                         res_y ? 3 : 2, 4, C, pgs, (long)MSCL_STAT_SLOTS * 4 * C, own ? 0 : 1);
+      MSCL_LAUNCH_CHECK();
+    }
   }
   int Ca = Cc, achunks = chunks;                                 // the apply pass's own chunking
   if (Ca * groups > 1024) {      // 10 * C floats of constants per group: past the 64-KB default for dynamic LDS

@@ -100,12 +100,14 @@ static inline int mscl_det_flag_value() { return g_mscl_deterministic; }
 // Of the MSCL_STAT_SLOTS slots a statistics buffer holds, the atomic producers spread over the first MSCL_STAT_ACTIVE only and the
 // consumers add just those: every block of a consuming pass re-reads all active slots of every channel in its prologue, which costs
 // more than the contention the extra slots avoid (measured inside the step with 1 / 2 / 4 / 8 / 16 / 32 slots: 948 / 964 / 970 / 971 /
-// 956 / 897 clip-pairs/s).  The deterministic mode writes one slot per block (plain stores) and its consumers add all
-// MSCL_STAT_SLOTS: the `nslots` argument of the consuming kernels says which.
+// 956 / 897 clip-pairs/s).  The deterministic mode's producers plain-store per-block partials (up to MSCL_DET_PARTS of them, in
+// caller scratch) and fold them in index order into slot 0 (bn_act.hip, det_fold_kernel): its consumers read slot 0 alone.  The
+// `nslots` argument of the consuming kernels says which.
 #ifndef MSCL_STAT_ACTIVE
 #define MSCL_STAT_ACTIVE 4
 #endif
-static inline int mscl_stat_nslots() { return mscl_det_flag_value() ? MSCL_STAT_SLOTS : MSCL_STAT_ACTIVE; }
+#define MSCL_DET_PARTS 128
+static inline int mscl_stat_nslots() { return mscl_det_flag_value() ? 1 : MSCL_STAT_ACTIVE; }
 
 // exact floor(n / d) for 0 <= n < 2^31 via one 32x32->64 multiply (Granlund-Montgomery round-up method)
 struct FastDiv { uint32_t magic; int shift; };

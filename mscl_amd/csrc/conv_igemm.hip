@@ -641,10 +641,11 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
   if (stat_groups > 2) return MSCL_E_SHAPE;         // the epilogue splits a tile over two statistics groups at most
   if (ssum != nullptr && mscl_det()) {
     // deterministic mode: no statistics in the epilogue (LDS and global float atomics); a fixed-order pass over the stored map
-    // fills the slots instead (one block per slot, plain stores) -- the statistics of the bf16 values the next layer reads
+    // fills slot 0 instead (per-block partials in the workspace, folded in index order: bn_act.hip) -- the statistics of the bf16
+    // values the next layer reads.  The workspace is free again by then: the split-K finalize ran before on this stream.
     e = mscl_conv3d_fwd_groups(d, x, w, y, bias, addend, relu, nullptr, nullptr, 1, splitk_ws, splitk_ws_floats, stream);
     if (e) return e;
-    return mscl_bn_stats(y, ssum, ssq, (int64_t)d->N * d->To * d->Ho * d->Wo, d->K, stat_groups, stream);
+    return mscl_bn_stats(y, ssum, ssq, (int64_t)d->N * d->To * d->Ho * d->Wo, d->K, stat_groups, splitk_ws, splitk_ws_floats, stream);
   }
   if (stat_groups == 1 && bias == nullptr && !relu && win64_enabled(d)) {
     const int h = mscl_conv_win64(d, 0, x, w, y, addend, ssum, ssq, stream);

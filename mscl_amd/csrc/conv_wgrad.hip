@@ -370,6 +370,17 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
 
 int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                       hipStream_t st);           // conv_wgrad_halo.hip
+int mscl_wgrad_pp(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
+                  hipStream_t st);               // conv_wgrad_pp.hip
+// shared-tap ping-pong kernel (conv_wgrad_pp.hip): MSCL_WGRAD_PP 0 (default) = off, 1 = maps of >= 16384 positions, 2 = wherever it
+// applies.  Opt-in: alone it ties the 128 x 128 kernel below on layer 2 (82.5 vs 81.0 us) and loses on the small maps (layer 4: 56 vs
+// 40 us); inside the step 1010 / 1000 vs 1033 clip-pairs/s (levels 1 / 2 vs 0) -- see the header of conv_wgrad_pp.hip for why.
+static bool wgrad_pp_enabled(const mscl_conv_desc* d) {
+  const char* e = getenv("MSCL_WGRAD_PP");
+  const int level = e ? atoi(e) : 0;
+  if (level <= 0) return false;
+  return level >= 2 || (long)d->N * d->To * d->Ho * d->Wo >= 16384;
+}
 
 // 128 x 128 tile, 2 x 2 waves of 64 x 64: per 64-position step a wave makes 16 transposing reads for 16 MFMAs (the 64 x 64
 // tile with the columns split four ways makes 10 for 4 and asks the LDS for 320 B/clk), and a block stages 32 KB for 128
@@ -411,7 +422,14 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
     if (dfl < 0) return MSCL_E_ARG;
   }
   // (NCOL = 192, three taps sharing one dy tile, measured slower than 64 -- fewer blocks per CU -- and was dropped)
-  if (hres == 1) e = 0;
+  int pres = 0;
+  if (hres == 0 && ws != nullptr && wgrad_pp_enabled(d)) {
+    // its slabs are added in split order, so the result is deterministic as it stands: same path in deterministic mode
+    const long tail = (mscl_det() && dbias) ? (long)MSCL_STAT_SLOTS * d->K : 0;
+    pres = mscl_wgrad_pp(d, x, dy, dw, ws, ws_floats - tail, st);
+    if (pres < 0 || pres > 1) return pres;
+  }
+  if (hres == 1 || pres == 1) e = 0;
   else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st, dws, dfl);
   else if (d->K >= 64) e = launch_w<64, 64>(g, x, dy, dw, st, dws, dfl);
   else if (d->K == 32) e = launch_w<32, 64>(g, x, dy, dw, st, dws, dfl);
@@ -440,9 +458,12 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
 
 // floats of `ws` mscl_conv3d_wgrad wants for this layer in deterministic mode (at most 64 slabs of the weight gradient plus
 // the bias partials); 0 outside deterministic mode for layers that do not use the window-resident kernel
+extern "C" int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) {
   if (!d) return 0;
-  if (!mscl_det()) return 0;
+  const int64_t pp = wgrad_pp_enabled(d) ? mscl_wgrad_pp_ws(d) : 0;
+  if (!mscl_det()) return pp;
+  if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_STAT_SLOTS * d->K : 0);
   const int64_t dwn = (int64_t)d->K * d->kT * d->kH * d->kW * d->C;
   int64_t slabs = ((int64_t)1 << 28) / (dwn > 0 ? dwn : 1);          // cap the slab workspace at 1 GiB
   if (slabs > 64) slabs = 64;

@@ -29,13 +29,29 @@ def out_shape(d):
     return (d.N, d.To, d.Ho, d.Wo, d.K)
 
 
-def _splitk_ws(rows, chans, device):
-    """fp32 scratch for split-K when the layer has too few position tiles to fill 256 CUs (else None)."""
+def _splitk_floats(rows, chans):
+    """floats of fp32 scratch for split-K when the layer has too few position tiles to fill 256 CUs (else 0)."""
     tiles = ((rows + 127) // 128) * ((chans + 127) // 128 if chans >= 128 else 1)
     if tiles > 256 or chans < 64:
-        return None
-    nslab = min(16, (512 + tiles - 1) // tiles)
-    return torch.empty((nslab * rows * chans,), dtype=torch.float32, device=device)
+        return 0
+    return min(16, (512 + tiles - 1) // tiles) * rows * chans
+
+
+def _splitk_ws(rows, chans, device):
+    n = _splitk_floats(rows, chans)
+    return torch.empty((n,), dtype=torch.float32, device=device) if n else None
+
+
+def fwd_ws_floats(d, stat_groups=0):
+    """floats of fp32 scratch a forward conv wants: split-K slabs, and in deterministic mode the partials of the statistics pass
+    (stat_groups > 0; the two uses follow one another on the stream, the larger size serves both)"""
+    rows = d.N * d.To * d.Ho * d.Wo
+    return max(_splitk_floats(rows, d.K), lib.det_parts_floats(rows, d.K, stat_groups, 2) if stat_groups else 0)
+
+
+def fwd_ws(d, device, stat_groups=0):
+    n = fwd_ws_floats(d, stat_groups)
+    return torch.empty((n,), dtype=torch.float32, device=device) if n else None
 
 
 import os as _os
@@ -75,7 +91,7 @@ def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats = (sum, sumsq) fp32 K-vectors, pre-zeroed."""
     y = torch.empty(out_shape(d), dtype=torch.bfloat16, device=x.device)
     s0, s1 = stats if stats is not None else (None, None)
-    ws = _splitk_ws(d.N * d.To * d.Ho * d.Wo, d.K, x.device)
+    ws = fwd_ws(d, x.device, 1 if stats is not None else 0)
     e0 = prof_begin()
     call('mscl_conv3d_fwd', ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(addend), int(relu),
          ptr(s0), ptr(s1), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
@@ -113,8 +129,10 @@ def conv3d_wgrad(x, dy, d, dw, dbias=None):
     ws = None
     if (d.C, d.K, d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW) == (64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1):
         ws = torch.empty((WGRAD_HALO_WS,), dtype=torch.float32, device=x.device)
-    elif lib.deterministic():          # per-split slabs (+ bias partials), added in a fixed order
-        ws = torch.empty((lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(dbias is not None)),), dtype=torch.float32, device=x.device)
+    else:                              # slabs of the shared-tap kernel, or deterministic mode's per-split slabs (+ bias partials)
+        n = lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(dbias is not None))
+        if n > 0:
+            ws = torch.empty((n,), dtype=torch.float32, device=x.device)
     e0 = prof_begin()
     call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
          ws.numel() if ws is not None else 0, stream_ptr())
@@ -199,10 +217,12 @@ def bn_act_bwd(dout, out, y, gamma, smean, sinv, dgamma, dbeta, relu, scratch, r
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if (res is not None or want_identity_dres) else None
     r = res or {}
+    pn = lib.det_parts_floats(rows, C, groups, 4) if relu != 2 else 0       # deterministic mode: scratch for the per-block partials
+    parts = torch.empty((pn,), dtype=torch.float32, device=y.device) if pn else None
     call('mscl_bn_act_bwd_groups', ptr(dout), ptr(out), ptr(y), ptr(gamma), ptr(beta), ptr(smean), ptr(sinv), ptr(dgamma), ptr(dbeta),
          ptr(r.get('y')), ptr(r.get('gamma')), ptr(r.get('mean')), ptr(r.get('invstd')), ptr(r.get('dgamma')),
          ptr(r.get('dbeta')), ptr(dy), ptr(dres), int(want_identity_dres and res is None), ptr(scratch), rows, C,
-         int(relu), groups, stream_ptr())
+         int(relu), groups, ptr(parts), pn, stream_ptr())
     return dy, dres
 
 

@@ -35,8 +35,11 @@ _SIGS = {
     'mscl_debug_pp_launches': [],
     'mscl_debug_win64_launches': [],
     'mscl_get_deterministic': [],
-    'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P],
+    'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P, c_int64, P],
+    'mscl_det_parts_floats': [c_int64, c_int, c_int, c_int],
     'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],
+    'mscl_wgrad_pp_ws': [POINTER(ConvDesc)],
+    'mscl_debug_wgrad_pp_launches': [],
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
     'mscl_conv3d_fwd_groups': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, c_int, P, c_int64, P],
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
@@ -48,7 +51,7 @@ _SIGS = {
     'mscl_bn_act_fwd': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, P],
     'mscl_bn_act_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P],
     'mscl_bn_act_fwd_groups': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, c_int, P],
-    'mscl_bn_act_bwd_groups': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, c_int, P],
+    'mscl_bn_act_bwd_groups': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, c_int, P, c_int64, P],
     'mscl_pack_input': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P],
     'mscl_pack_input_ind': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P],
     'mscl_pair_w': [P, P, c_int64, c_int, P],
@@ -89,7 +92,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches')
+_INT64_RESULT = ('mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_wgrad_pp_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches', 'mscl_debug_wgrad_pp_launches')
 EXPORTS = tuple(_SIGS)
 
 _lib = None
@@ -161,8 +164,18 @@ def call(name, *args):
 def set_deterministic(on=True):
     """the reference's `--deterministic` (tools/train.py:55-57,149): fixed-order sums in place of float atomics (include/mscl_hip.h,
     mscl_set_deterministic); two runs on the same inputs are then bit-identical.  Process-wide, set before the first step."""
+    global DET
     call('mscl_set_deterministic', int(bool(on)))
+    DET = bool(on)
+
+
+DET = False              # mirror of the library's flag for the per-launch Python paths (scratch sizing)
 
 
 def deterministic():
     return bool(call_raw('mscl_get_deterministic'))
+
+
+def det_parts_floats(rows, C, groups, vecs):
+    """floats of scratch the deterministic BatchNorm sums want for their per-block partials (0 outside deterministic mode)"""
+    return call_raw('mscl_det_parts_floats', rows, C, groups, vecs) if DET else 0

@@ -121,8 +121,7 @@ def cba_fwd(conv, bn, x, residual, relu):
     plan = conv._plans.get(shape)
     if plan is None:
         d = conv.desc(shape)
-        ws = K._splitk_ws(d.N * d.To * d.Ho * d.Wo, d.K, x.device)
-        plan = conv._plans[shape] = (d, ctypes.byref(d), K.out_shape(d), ws.numel() if ws is not None else 0,
+        plan = conv._plans[shape] = (d, ctypes.byref(d), K.out_shape(d), K.fwd_ws_floats(d, 2 if d.N % 2 == 0 else 1),
                                      (d.N, d.T, d.H, d.W, d.C, d.K, d.kT))
     d, dref, oshape, ws_n, sig = plan
     C = conv.out_channels

@@ -189,6 +189,39 @@ def test_conv_pp_forced(case, dev, monkeypatch):
         assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
 
 
+# conv_wgrad_pp.hip (shared-tap ping-pong weight gradient) forced onto small shapes: position tails inside a 62-position K tile,
+# several position splits and a single one, 2 x 2 / 4 x 4 channel tiles, kT = 1, strides along T / H, accumulation into a
+# non-zero dw, and the layer shapes of the step that take it by default (>= 16384 positions) via REAL_CASES above.
+WGRAD_PP_CASES = [c for c in PP_CASES if c[5] % 128 == 0 and c[6] % 128 == 0]
+
+
+@pytest.mark.parametrize('case', WGRAD_PP_CASES, ids=['wg' + c[0] for c in WGRAD_PP_CASES])
+def test_conv_wgrad_pp_forced(case, dev, monkeypatch):
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, C, K, kern, stride, pad, _ = case
+    monkeypatch.setenv('MSCL_WGRAD_PP', '2')
+    x = bf(rnd((N, T, H, W, C), 31)); w = rnd((K, *kern, C), 32)
+    d = K_.conv_desc(x.shape, K, kern, stride, pad)
+    xr = x.float(); wr = w.clone().requires_grad_(True)
+    yr = _conv_ref(xr, wr, stride, pad)
+    dy = bf(rnd(tuple(yr.shape), 33))
+    yr.backward(dy.float())
+    dw = torch.zeros((K, *kern, C), dtype=torch.float32, device=dev)
+    db = torch.zeros((K,), dtype=torch.float32, device=dev)
+    n0 = lib.call_raw('mscl_debug_wgrad_pp_launches')
+    K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, db)
+    assert lib.call_raw('mscl_debug_wgrad_pp_launches') == n0 + 1, 'the weight gradient did not take the shared-tap kernel'
+    close(dw, wr.grad, F32_TOL, 'wgrad_pp')
+    close(db, dy.float().sum(dim=(0, 1, 2, 3)), F32_TOL, 'wgrad_pp dbias')
+    first = dw.clone()
+    K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, None)           # accumulates; fixed-order slab sums: the same bits every run
+    assert torch.equal(dw, 2 * first)
+    for _ in range(5):
+        dw2 = torch.zeros_like(dw)
+        K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw2, None)
+        assert torch.equal(dw2, first)
+
+
 # conv_win64.hip (persistent window-resident ping-pong kernel, 64 -> 64, 3x3 in plane): tiles that straddle planes and samples,
 # a map smaller than one tile, more tiles than blocks would need on a small grid (the persistent walk), kT = 1, the widest plane
 # (W = 61), the real layer-1 map (1654 tiles over 256 blocks: 6-7 tiles per block, windows prefetched across tile boundaries).
@@ -785,11 +818,60 @@ def test_bn_wide_maps_and_fixed_order_statistics(dev):
         dy, _ = K_.bn_act_bwd(dout.to(dev), bf(o.detach()).to(dev), y.to(dev), gamma.to(dev), mean.to(dev), inv.to(dev), dg, db, 1, scratch)
         close(dy, yr.grad, 2.0 ** -6, f'bn bwd C={C}')
         close(dg, gr.grad, 2e-3, 'dgamma'); close(db, br.grad, 2e-3, 'dbeta')
-        st = [torch.zeros((K_.STAT_SLOTS, 2, C), device=dev) for _ in range(2)]
-        for t in st:
-            lib.call('mscl_bn_stats', y.to(dev).data_ptr(), t.data_ptr(), t.data_ptr() + 4 * C, rows, C, 1, lib.stream_ptr())
-        assert torch.equal(st[0], st[1])
-        close(st[0][:, 0].sum(0), y.float().sum(0), 1e-5, 'stats sum'); close(st[0][:, 1].sum(0), (y.float() ** 2).sum(0), 1e-5, 'stats sumsq')
+        yd = y.to(dev)
+        for parts_n in (0, lib.call_raw('mscl_det_parts_floats', rows, C, 1, 2)):     # partials in the slots / in caller scratch
+            st = [torch.zeros((K_.STAT_SLOTS, 2, C), device=dev) for _ in range(2)]
+            parts = torch.empty((parts_n,), device=dev) if parts_n else None
+            for t in st:
+                lib.call('mscl_bn_stats', yd.data_ptr(), t.data_ptr(), t.data_ptr() + 4 * C, rows, C, 1, lib.ptr(parts), parts_n, lib.stream_ptr())
+            assert torch.equal(st[0], st[1])
+            assert not st[0][1:].any(), 'the sums belong in slot 0, the other slots stay zero'
+            close(st[0][0, 0], y.float().sum(0), 1e-5, 'stats sum'); close(st[0][0, 1], (y.float() ** 2).sum(0), 1e-5, 'stats sumsq')
+
+
+def test_deterministic_bn_sums_two_levels(dev):
+    """deterministic mode's BatchNorm sums on a map large enough for many partial blocks (layer-2 size) and with two statistics
+    groups: statistics pass and backward with caller scratch for the partials (mscl_det_parts_floats) and without it (the slots hold
+    them) agree with fp32 sums / the atomic path, and repeat bit for bit."""
+    from mscl_amd import kernels as K_, lib
+    C, rows = 128, 2 * 6272
+    y = bf(rnd((rows, C), 51)); dout = bf(rnd((rows, C), 52)); gamma = rnd((C,), 53) * 0.2 + 1; beta = rnd((C,), 54) * 0.1
+    yd, dd = y.to(dev), dout.to(dev)
+    for G in (1, 2):
+        yg = y.float().view(G, rows // G, C)
+        need = lib.call_raw('mscl_det_parts_floats', rows, C, G, 2)
+        assert need == G * min(128, -(-(rows // G) // (256 // (C // 8) * 8))) * 2 * C
+        got = []
+        for parts_n in (0, need, need):
+            st = torch.zeros((G, K_.STAT_SLOTS, 2, C), device=dev)
+            parts = torch.full((parts_n,), float('nan'), device=dev) if parts_n else None
+            lib.call('mscl_bn_stats', yd.data_ptr(), st.data_ptr(), st.data_ptr() + 4 * C, rows, C, G, lib.ptr(parts), parts_n, lib.stream_ptr())
+            assert not st[:, 1:].any()
+            close(st[:, 0, 0], yg.sum(1), 1e-5, f'sum G={G}'); close(st[:, 0, 1], (yg ** 2).sum(1), 1e-5, f'sumsq G={G}')
+            got.append(st)
+        assert torch.equal(got[1], got[2])
+        # backward: atomic path as the yardstick, then deterministic mode with and without scratch
+        mean = yg.mean(1); inv = 1.0 / torch.sqrt(yg.var(1, unbiased=False) + 1e-5)
+        out = bf(F.relu((yg - mean[:, None]) * inv[:, None] * gamma + beta)).view(rows, C).to(dev)
+        sm = (mean if G > 1 else mean[0]).contiguous().to(dev); si = (inv if G > 1 else inv[0]).contiguous().to(dev)
+
+        def run():
+            dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            scr = torch.zeros((G * K_.STAT_SLOTS * 4 * C,), device=dev)
+            dy, _ = K_.bn_act_bwd(dd, out, yd, gamma.to(dev), sm, si, dg, db, 1, scr, groups=G)
+            return dy, dg, db
+        ref = run()
+        lib.set_deterministic(True)
+        try:
+            a, b = run(), run()
+            lib.DET = False                  # no scratch for the partials: the slots hold them
+            c = run()
+        finally:
+            lib.set_deterministic(False)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        for r in (a, c):
+            close(r[0], ref[0], 2.0 ** -6, f'dy G={G}'); close(r[1], ref[1], 1e-4, 'dgamma'); close(r[2], ref[2], 1e-4, 'dbeta')
 
 
 def test_linear_more_than_32_rows(dev):
