@@ -184,28 +184,43 @@ __global__ __launch_bounds__(256) void bn_stats_det_kernel(const bf16_t* __restr
   }
 }
 
-// level 2 of every deterministic BatchNorm sum: dst[group][v][c] = sum over p (in index order) of part[group][p][v][c], v < nvec;
+// level 2 of every deterministic BatchNorm sum: dst[group][v][c] = sum over p of part[group][p][v][c], v < nvec, in a FIXED order:
+// eight lanes per channel each add a contiguous eighth of the partials in index order (their loads in flight together: one
+// thread adding 128 partials one after the other took 5 us, 140 times a step), then lane 0 adds the eight sums in lane order.
 // part rows are [pvec][ldc] wide, dst rows [ldc]; dst_gstride = floats between the groups' slot 0.  zero_tail > 0: the partials
 // ARE slots 0 .. P-1 of dst (in place): slots 1 .. P-1 are zeroed again so that consumers may add any number of slots.
 __global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__ part, float* __restrict__ dst, int P, int nvec, int pvec,
                                                        int ldc, long part_gstride, long dst_gstride, int zero_tail) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nvec * ldc) return;
+  __shared__ float red[8][32];
+  const int ix = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + ix;
+  const bool live = i < nvec * ldc;
+  const long pitch = (long)pvec * ldc;
   const float* src = part + blockIdx.y * part_gstride + i;
+  const int per = (P + 7) >> 3;
+  const int pe = min(P, (py + 1) * per);
   float t = 0.f;
-  int p = 0;
-  for (; p + 8 <= P; p += 8) {
-    float v[8];
+  if (live) {
+    int p = py * per;
+    for (; p + 8 <= pe; p += 8) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(long)(p + u) * pvec * ldc];
+      for (int u = 0; u < 8; ++u) v[u] = src[(p + u) * pitch];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t += v[u];
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; p < pe; ++p) t += src[p * pitch];
   }
-  for (; p < P; ++p) t += src[(long)p * pvec * ldc];
+  red[py][ix] = t;
+  __syncthreads();
+  if (py != 0 || !live) return;
+  t = red[0][ix];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) t += red[k][ix];
   float* d = dst + blockIdx.y * dst_gstride;
   d[i] = t;
   if (zero_tail)
-    for (int q = 1; q < P; ++q) d[(long)q * pvec * ldc + i] = 0.f;
+    for (int q = 1; q < P; ++q) d[q * pitch + i] = 0.f;
 }
 
 // partial blocks of a deterministic pass over `rows_g` rows of a C-channel map: enough rows per block that its loads overlap
@@ -236,7 +251,7 @@ extern "C" int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t
   hipLaunchKernelGGL(bn_stats_det_kernel, dim3(P, C / Cc, groups), dim3(256), (size_t)8 * Cc * sizeof(float), st, y, part,
                      (long)(rows / groups), Cc, C, pgs);
   MSCL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(det_fold_kernel, dim3((2 * C + 255) / 256, groups), dim3(256), 0, st, (const float*)part, ssum, P, 2, 2, C, pgs,
+  hipLaunchKernelGGL(det_fold_kernel, dim3((2 * C + 31) / 32, groups), dim3(256), 0, st, (const float*)part, ssum, P, 2, 2, C, pgs,
                      (long)MSCL_STAT_SLOTS * 2 * C, own ? 0 : 1);
   MSCL_LAUNCH_CHECK();
   return 0;
@@ -476,7 +491,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
                        out, y, save_mean, save_invstd, res_y, res_mean, res_invstd, scratch, (long)rows_g, Cc, relu, gamma, beta, C, part, pgs);
     MSCL_LAUNCH_CHECK();
     if (det) {
-      hipLaunchKernelGGL(det_fold_kernel, dim3((3 * C + 255) / 256, groups), dim3(256), 0, st, (const float*)part, scratch, (int)blocks,
+      hipLaunchKernelGGL(det_fold_kernel, dim3((3 * C + 31) / 32, groups), dim3(256), 0, st, (const float*)part, scratch, (int)blocks,
                          res_y ? 3 : 2, 4, C, pgs, (long)MSCL_STAT_SLOTS * 4 * C, own ? 0 : 1);
       MSCL_LAUNCH_CHECK();
     }

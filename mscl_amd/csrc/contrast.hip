@@ -204,9 +204,22 @@ __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __rest
                                                              int RT, int R, int dim) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= R * dim) return;
-  float s4[4] = {0.f, 0.f, 0.f, 0.f};
   const int step = gridDim.y;
   int b = blockIdx.y;
+  if (step == 1) {            // deterministic mode: ONE add per element of a sum taken in slab order, 16 loads in flight per trip
+    float s = 0.f;
+    for (; b + 16 <= nslab; b += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = slab[(long)(b + u) * RT * dim + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; b < nslab; ++b) s += slab[(long)b * RT * dim + e];
+    atomicAdd(&dq[e], s);
+    return;
+  }
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
   for (; b + 3 * step < nslab; b += 4 * step) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) s4[u] += slab[(long)(b + u * step) * RT * dim + e];
@@ -384,10 +397,16 @@ extern "C" int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, co
 
 // ---------------------------------------------------------------- LMCL: one block per clip
 #define LMCL_MAX_T 32
+// deterministic mode: the clips' losses meet in this table and the block that arrives last adds them in clip order (one launch
+// for all clips; round 2 launched the clips one after the other, 8 x 22 us on the step's critical path).  Library-owned words: two
+// mscl_lmcl launches must not run side by side in deterministic mode (the step has one).
+#define LMCL_MAX_B 4096
+__device__ float g_lmcl_part[LMCL_MAX_B];
+__device__ unsigned g_lmcl_ticket;
 __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb, const float* __restrict__ flow,
                                                    float* __restrict__ loss_sum, int32_t* __restrict__ hits,
                                                    float* __restrict__ drgb, float* __restrict__ dflow, int B, int t, int C,
-                                                   float inv_T, int b0) {
+                                                   float inv_T, int det) {
   extern __shared__ float sm[];
   const int t2 = 2 * t;
   float* xr = sm;                    // [t][C] normalised
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
   float* sim = nf + t2;              // [t][2t] -> dlogits
   float* gr = sim + t * t2;          // [t][C]  grad wrt normalised rgb
   float* gf = gr + t * C;            // [2t][C]
-  const int b = blockIdx.x + b0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* lrow = gf + t2 * C;          // [t] per-frame loss terms of this clip, added up in frame order by one thread
   const float* rb = rgb + (long)b * t * C; const float* fb = flow + (long)b * t2 * C;
   for (int row = wave; row < t + t2; row += 4) {
@@ -435,10 +454,21 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
     for (int j = 0; j < t2; ++j) sim[i * t2 + j] = (expf(sim[i * t2 + j] - lse) - (j == i ? 1.f : 0.f)) * scale * inv_T;
   }
   __syncthreads();
-  if (tid == 0) {                     // one float add per clip: the clips' order is the launch order in deterministic mode
+  if (tid == 0) {                     // one float add per clip; deterministic mode: one add of the sum taken in clip order
     float s = 0.f;
     for (int i = 0; i < t; ++i) s += lrow[i];
-    atomicAdd(loss_sum, s);
+    if (!det) atomicAdd(loss_sum, s);
+    else {
+      __hip_atomic_store(&g_lmcl_part[b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      if (atomicAdd(&g_lmcl_ticket, 1u) == (unsigned)(B - 1)) {
+        __threadfence();
+        float tot = 0.f;
+        for (int k = 0; k < B; ++k) tot += __hip_atomic_load(&g_lmcl_part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(loss_sum, tot);
+        g_lmcl_ticket = 0;            // ready for the next launch (stream order)
+      }
+    }
   }
   for (int e = tid; e < t * C; e += 256) {
     const int i = e / C, c = e % C;
@@ -473,14 +503,9 @@ extern "C" int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, i
   if (lds > 150 * 1024) return MSCL_E_SHAPE;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lmcl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  if (mscl_det()) {                   // clip by clip: the one float add per clip lands in clip order
-    for (int b = 0; b < B; ++b) {
-      hipLaunchKernelGGL(lmcl_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, b);
-      MSCL_LAUNCH_CHECK();
-    }
-    return 0;
-  }
-  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, 0);
+  const int det = (mscl_det() && B <= LMCL_MAX_B) ? 1 : 0;
+  if (mscl_det() && !det) return MSCL_E_SHAPE;
+  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, det);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -275,10 +275,21 @@ __global__ __launch_bounds__(256) void colsum_det_kernel(const bf16_t* __restric
   const long per = (rows + gridDim.x - 1) / gridDim.x;
   const long rbeg = (long)blockIdx.x * per, rend = rbeg + per < rows ? rbeg + per : rows;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long r = rbeg + tr; r < rend; r += RP) {
-    float f[8]; unpack8(*reinterpret_cast<const uint4*>(xx + r * ldc + tg * 8), f);
+  constexpr int UNR = 4;            // loads of a trip issued together: the loop is latency-bound
+  for (long r0 = rbeg + tr; r0 < rend; r0 += (long)RP * UNR) {
+    uint4 v[UNR];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] += f[i];
+    for (int u = 0; u < UNR; ++u) {
+      const long r = r0 + (long)u * RP;
+      v[u] = *reinterpret_cast<const uint4*>(xx + (r < rend ? r : r0) * ldc + tg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (r0 + (long)u * RP >= rend) break;
+      float f[8]; unpack8(v[u], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
   }
   __shared__ float red[4 * 512];
   block_channel_sum(s, red, G, C, 1, 0);
@@ -289,7 +300,15 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= C) return;
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += part[(long)k * C + i];
+  int k = 0;
+  for (; k + 8 <= nblk; k += 8) {       // eight loads in flight, added in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u) * C + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < nblk; ++k) s += part[(long)k * C + i];
   out[i] += s;
 }
 
@@ -414,10 +433,10 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   const int hres = ws != nullptr ? mscl_wgrad_halo64(d, x, dy, dw, ws, ws_floats, st) : 0;   // layer-1 shape, window-resident
   if (hres < 0 || hres > 1) return hres;
   // deterministic mode: `ws` doubles as the slab workspace of the general kernel ([splits][K][ncols] floats) and, behind it,
-  // the partial column sums of the bias gradient ([MSCL_STAT_SLOTS][K]); mscl_conv3d_wgrad_ws() gives the size to pass
+  // the partial column sums of the bias gradient ([MSCL_DET_PARTS][K]); mscl_conv3d_wgrad_ws() gives the size to pass
   float* dws = nullptr; long dfl = 0;
   if (mscl_det() && hres == 0 && ws != nullptr) {
-    const long tail = dbias ? (long)MSCL_STAT_SLOTS * d->K : 0;
+    const long tail = dbias ? (long)MSCL_DET_PARTS * d->K : 0;
     dws = ws; dfl = ws_floats - tail;
     if (dfl < 0) return MSCL_E_ARG;
   }
@@ -425,7 +444,7 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   int pres = 0;
   if (hres == 0 && ws != nullptr && wgrad_pp_enabled(d)) {
     // its slabs are added in split order, so the result is deterministic as it stands: same path in deterministic mode
-    const long tail = (mscl_det() && dbias) ? (long)MSCL_STAT_SLOTS * d->K : 0;
+    const long tail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
     pres = mscl_wgrad_pp(d, x, dy, dw, ws, ws_floats - tail, st);
     if (pres < 0 || pres > 1) return pres;
   }
@@ -440,11 +459,13 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   if (dbias) {
     const int Kc = d->K > 512 ? 512 : d->K, kchunks = d->K / Kc;        // K/8 is a power of two (checked above)
     if (mscl_det()) {
-      if (ws == nullptr || ws_floats < (long)MSCL_STAT_SLOTS * d->K) return MSCL_E_ARG;
-      float* part = ws + (ws_floats - (long)MSCL_STAT_SLOTS * d->K);
-      hipLaunchKernelGGL(colsum_det_kernel, dim3(MSCL_STAT_SLOTS, kchunks), dim3(256), 0, st, dy, part, M, Kc, d->K);
+      if (ws == nullptr || ws_floats < (long)MSCL_DET_PARTS * d->K) return MSCL_E_ARG;
+      float* part = ws + (ws_floats - (long)MSCL_DET_PARTS * d->K);
+      const int RPd = 256 / (Kc / 8);
+      long P = (M + RPd * 8 - 1) / (RPd * 8); if (P > MSCL_DET_PARTS) P = MSCL_DET_PARTS; if (P < 1) P = 1;      // a function of the shape alone
+      hipLaunchKernelGGL(colsum_det_kernel, dim3((unsigned)P, kchunks), dim3(256), 0, st, dy, part, M, Kc, d->K);
       MSCL_LAUNCH_CHECK();
-      hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->K + 255) / 256), dim3(256), 0, st, (const float*)part, dbias, MSCL_STAT_SLOTS, d->K);
+      hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->K + 255) / 256), dim3(256), 0, st, (const float*)part, dbias, (int)P, d->K);
       MSCL_LAUNCH_CHECK();
       return 0;
     }
@@ -463,10 +484,10 @@ extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) 
   if (!d) return 0;
   const int64_t pp = wgrad_pp_enabled(d) ? mscl_wgrad_pp_ws(d) : 0;
   if (!mscl_det()) return pp;
-  if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_STAT_SLOTS * d->K : 0);
+  if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_DET_PARTS * d->K : 0);
   const int64_t dwn = (int64_t)d->K * d->kT * d->kH * d->kW * d->C;
   int64_t slabs = ((int64_t)1 << 28) / (dwn > 0 ? dwn : 1);          // cap the slab workspace at 1 GiB
   if (slabs > 64) slabs = 64;
   if (slabs < 2) slabs = 2;
-  return slabs * dwn + (with_bias ? (int64_t)MSCL_STAT_SLOTS * d->K : 0);
+  return slabs * dwn + (with_bias ? (int64_t)MSCL_DET_PARTS * d->K : 0);
 }
