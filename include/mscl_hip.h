@@ -55,6 +55,8 @@ int mscl_abi_version(void);
 int64_t mscl_debug_pp_launches(void);
 /* the same for the persistent window-resident 64 -> 64 kernel (conv_win64.hip) */
 int64_t mscl_debug_win64_launches(void);
+/* the same for the window-resident 1x3x3 kernel of the 16- / 32-channel maps (conv_thin.hip) */
+int64_t mscl_debug_thin_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);
 /* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order and stored

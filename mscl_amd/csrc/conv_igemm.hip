@@ -625,6 +625,13 @@ static bool halo_enabled(const mscl_conv_desc* d) {
   return (long)d->H * (d->W + 2) >= 1024;                   // 256-position tiles: planes of a few hundred positions waste them
 }
 
+int mscl_conv_thin(int planes, int H, int W, int C, int K, int flip, const bf16_t* x, const bf16_t* w, bf16_t* y, const float* bias,
+                   const bf16_t* addend, int relu, float* ssum, float* ssq, int stat_groups, hipStream_t st);      // conv_thin.hip
+static bool thin_shape(const mscl_conv_desc* d) {
+  return d->kT == 1 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 1 && d->pW == 1 &&
+         (d->C == 16 || d->C == 32) && (d->K == 16 || d->K == 32);
+}
+
 extern "C" int mscl_conv3d_fwd(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* w, uint16_t* y,
                                const float* bias, const uint16_t* addend, int relu, float* ssum, float* ssq,
                                float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
@@ -646,6 +653,11 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
     e = mscl_conv3d_fwd_groups(d, x, w, y, bias, addend, relu, nullptr, nullptr, 1, splitk_ws, splitk_ws_floats, stream);
     if (e) return e;
     return mscl_bn_stats(y, ssum, ssq, (int64_t)d->N * d->To * d->Ho * d->Wo, d->K, stat_groups, splitk_ws, splitk_ws_floats, stream);
+  }
+  if (thin_shape(d)) {             // 1x3x3 s1 between 16- / 32-channel maps: window-resident direct kernel (conv_thin.hip)
+    const int h = mscl_conv_thin(d->N * d->T, d->H, d->W, d->C, d->K, 0, x, w, y, bias, addend, relu, ssum, ssq, stat_groups,
+                                 (hipStream_t)stream);
+    if (h != 0) return h == 1 ? 0 : h;
   }
   if (stat_groups == 1 && bias == nullptr && !relu && win64_enabled(d)) {
     const int h = mscl_conv_win64(d, 0, x, w, y, addend, ssum, ssq, stream);
@@ -671,6 +683,11 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
                                  const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   int e = check_desc(d); if (e) return e;
   if (!dy || !wT || !dx) return MSCL_E_ARG;
+  if (thin_shape(d)) {
+    const int h = mscl_conv_thin(d->N * d->T, d->H, d->W, d->K, d->C, 1, dy, wT, dx, nullptr, addend, 0, nullptr, nullptr, 1,
+                                 (hipStream_t)stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
   if (win64_enabled(d)) {
     const int h = mscl_conv_win64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
     if (h != 0) return h == 1 ? 0 : h;

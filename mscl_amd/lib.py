@@ -92,7 +92,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_wgrad_pp_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches', 'mscl_debug_wgrad_pp_launches')
+_INT64_RESULT = ('mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_wgrad_pp_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches', 'mscl_debug_wgrad_pp_launches', 'mscl_debug_thin_launches')
 EXPORTS = tuple(_SIGS)
 
 _lib = None

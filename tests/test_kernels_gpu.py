@@ -222,6 +222,62 @@ def test_conv_wgrad_pp_forced(case, dev, monkeypatch):
         assert torch.equal(dw2, first)
 
 
+# conv_thin.hip (window-resident 1x3x3 kernel of the 16- / 32-channel maps): every channel pairing, bands that divide the plane
+# by 8, by 7 and not at all (a short last band), planes narrower than a 16-position tile row, the flow trunk's real layer1 / layer2
+# maps with two statistics groups.
+THIN_CASES = [
+    ('thin_16_16', 2, 3, 16, 20, 16, 16, 1),
+    ('thin_16_32', 2, 2, 14, 14, 16, 32, 1),
+    ('thin_32_16', 1, 3, 9, 10, 32, 16, 1),
+    ('thin_32_32', 2, 2, 21, 12, 32, 32, 2),
+    ('thin_short_band', 2, 1, 11, 5, 16, 16, 2),
+    ('thin_flow_l1', 4, 8, 56, 56, 16, 16, 2),
+    ('thin_flow_l2', 4, 8, 28, 28, 32, 32, 2),
+]
+
+
+@pytest.mark.parametrize('case', THIN_CASES, ids=[c[0] for c in THIN_CASES])
+def test_conv_thin(case, dev):
+    import ctypes
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, C, K, groups = case
+    kern, stride, pad = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    x = bf(rnd((N, T, H, W, C), 61)); w = bf(rnd((K, *kern, C), 62, scale=(2.0 / (C * 9)) ** 0.5))
+    d = K_.conv_desc(x.shape, K, kern, stride, pad)
+    xg, wg = x.to(dev), w.to(dev)
+    n0 = lib.call_raw('mscl_debug_thin_launches')
+    st = torch.zeros((groups, K_.STAT_SLOTS, 2, K), device=dev)
+    y = torch.empty(K_.out_shape(d), dtype=torch.bfloat16, device=dev)
+    lib.call('mscl_conv3d_fwd_groups', ctypes.byref(d), xg.data_ptr(), wg.data_ptr(), y.data_ptr(), None, None, 0,
+             st.data_ptr(), st.data_ptr() + 4 * K, groups, None, 0, lib.stream_ptr())
+    assert lib.call_raw('mscl_debug_thin_launches') == n0 + 1, 'the forward did not take the window-resident kernel'
+    xr = x.float().requires_grad_(True); wr = w.float()
+    yr = _conv_ref(xr, wr, stride, pad)
+    close(y, yr, BF16_TOL, 'thin fwd')
+    yg = yr.detach().view(groups, N // groups, T, H, W, K)
+    close(st[:, :, 0].sum(1), yg.sum(dim=(1, 2, 3, 4)), 2e-3, 'thin bn sum')
+    close(st[:, :, 1].sum(1), (yg * yg).sum(dim=(1, 2, 3, 4)), 2e-3, 'thin bn sumsq')
+    b = rnd((K,), 63); a = bf(rnd(tuple(yr.shape), 64))
+    y2 = K_.conv3d_fwd(xg, wg, d, bias=b.to(dev), addend=a.to(dev), relu=True)
+    close(y2, F.relu(yr.detach() + b + a.float()), BF16_TOL, 'thin fwd epilogue')
+    dy = bf(rnd(tuple(yr.shape), 65))
+    yr.backward(dy.float())
+    wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(wg, wT, K, 9, C)
+    add = bf(rnd(tuple(x.shape), 66))
+    n1 = lib.call_raw('mscl_debug_thin_launches')
+    dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
+    assert lib.call_raw('mscl_debug_thin_launches') == n1 + 1, 'the input gradient did not take the window-resident kernel'
+    close(dx, xr.grad + add.float(), BF16_TOL, 'thin dgrad+addend')
+    # against the implicit-GEMM kernel on the same inputs: same products, fp32 sums in another order
+    import os
+    os.environ['MSCL_THIN'] = '0'
+    try:
+        close(K_.conv3d_fwd(xg, wg, d), y, 2.0 ** -7, 'thin vs implicit GEMM')
+    finally:
+        del os.environ['MSCL_THIN']
+
+
 # conv_win64.hip (persistent window-resident ping-pong kernel, 64 -> 64, 3x3 in plane): tiles that straddle planes and samples,
 # a map smaller than one tile, more tiles than blocks would need on a small grid (the persistent walk), kT = 1, the widest plane
 # (W = 61), the real layer-1 map (1654 tiles over 256 blocks: 6-7 tiles per block, windows prefetched across tile boundaries).
