@@ -57,6 +57,7 @@ int64_t mscl_debug_pp_launches(void);
 int64_t mscl_debug_win64_launches(void);
 /* the same for the window-resident 1x3x3 kernel of the 16- / 32-channel maps (conv_thin.hip) */
 int64_t mscl_debug_thin_launches(void);
+int64_t mscl_debug_thin_wgrad_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);
 /* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order and stored
@@ -72,6 +73,9 @@ int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int 
  * applies, the per-split slabs of deterministic mode otherwise (0: none needed) */
 int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias);
 int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
+/* floats of workspace the window-resident weight-gradient kernel of the 1x3x3 16- / 32-channel layers wants (conv_thin.hip: one
+ * 9 x K x C partial per block, added in block order); 0 = the layer is not one of them.  Included in mscl_conv3d_wgrad_ws. */
+int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);
 /* test aid: launches taken by the shared-tap weight-gradient kernel (conv_wgrad_pp.hip) in this process */
 int64_t mscl_debug_wgrad_pp_launches(void);
 

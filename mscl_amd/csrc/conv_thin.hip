@@ -189,3 +189,203 @@ int mscl_conv_thin(int planes, int H, int W, int C, int K, int flip, const bf16_
   g_thin_launches.fetch_add(1);
   return 1;
 }
+
+// ---------------------------------------------------------------- weight gradient of the same layers
+//   dW[k][tap][c] += sum over positions of dy[pos][k] * x[pos + off(tap)][c]
+// Reference op: the weight gradient autograd computes for those nn.Conv3d (r3d.py:36-60).  Byte-bound again (the two maps in, 9 x C
+// x K floats out), and the output is so small that float atomics are the wrong tool: every block adding into the same 9-KB of dW
+// runs 14x below the atomic rate (MI355X_MICROARCH.md, Global float atomics, row 'contention') -- the 16-row tile of
+// conv_wgrad.hip took 31 us on the layer1 map for that reason.  Here:
+//  * a block walks band units (RB rows of one plane) and keeps BOTH maps' windows in LDS in the padded-linear layout of
+//    conv_wgrad_pp.hip: position q = row * (W + 2) + column with a zero column each side, dy rows [q], x rows [q + tap offset] -- the
+//    reduction index is affine, no per-tap masks;
+//  * nine waves, one tap each (no sum across waves): per 32 positions KT x CT MFMAs from 2 (KT + CT) transposing reads
+//    (ds_read_b64_tr_b16: both operands are position-major); the reduction slot of lane group g, read h, row j is position
+//    16 h + 4 g + j, so a 32-lane half reads 8 consecutive rows;
+//  * every block plain-stores its 9 x K x C partial to a slab; wgrad_thin_reduce_kernel adds the slabs in block order into dW
+//    (fixed order: the same bits every run, so deterministic mode takes this path as it is).
+struct ThinWGeom {
+  int planes, H, W, RB, bands, units, upb;     // upb: band units per block
+  int QD, XR;                                   // dy rows (multiple of 32), x rows in LDS
+  FastDiv dWp, dBands;
+};
+
+#define THIN_TR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+
+template <int C, int K>
+__global__ __launch_bounds__(576) void wgrad_thin_kernel(const ThinWGeom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                         float* __restrict__ slab) {
+  constexpr int KT = K / 16, CT = C / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tap = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fg = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int Wp = g.W + 2;
+  const unsigned dyL = lds0, xL = lds0 + (unsigned)g.QD * K * 2;       // x rows start one guard position in (index -1 is row 0)
+  const int th = tap / 3, tw = tap - 3 * th;
+  const int xoff = Wp + (th - 1) * Wp + (tw - 1) + 1;                  // + 1: the guard row
+
+  f32x4_t acc[KT][CT];
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int u = blockIdx.x * g.upb; u < min(g.units, (int)(blockIdx.x + 1) * g.upb); ++u) {
+    const int plane = fdiv(u, g.dBands), band = u - plane * g.bands;
+    const int r0 = band * g.RB;
+    const int rows = min(g.RB, g.H - r0);
+    __syncthreads();                            // the previous unit's reads are done
+    {   // dy: QD padded positions x K channels
+      constexpr int GP = K / 8;
+      const int total = g.QD * GP;
+      const bf16_t* dp = dy + ((long)plane * g.H + r0) * g.W * K;
+      for (int i = tid; i < total; i += 576) {
+        const int q = i / GP, gq = i - q * GP;
+        const int pr = fdiv(q, g.dWp), pc = q - pr * Wp - 1;
+        const bool ok = pr < rows && (unsigned)pc < (unsigned)g.W;
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(dp + ((long)pr * g.W + pc) * K + gq * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(smem + (long)i * 16) = v;
+      }
+    }
+    {   // x: guard row, then the (rows + 2) x (W + 2) window, then zeros up to XR rows
+      constexpr int GP = C / 8;
+      const int total = g.XR * GP;
+      const bf16_t* xp = x + (long)plane * g.H * g.W * C;
+      unsigned char* xs = smem + (long)g.QD * K * 2;
+      for (int i = tid; i < total; i += 576) {
+        const int q = i / GP - 1, gq = i % GP;
+        const int wr = q >= 0 ? fdiv(q, g.dWp) : 0, wc = q - wr * Wp;
+        const int hr = r0 + wr - 1, cc = wc - 1;
+        const bool ok = q >= 0 && wr < rows + 2 && (unsigned)hr < (unsigned)g.H && (unsigned)cc < (unsigned)g.W;
+        const uint4 v = ok ? *reinterpret_cast<const uint4*>(xp + ((long)hr * g.W + cc) * C + gq * 8) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(xs + (long)i * 16) = v;
+      }
+    }
+    __syncthreads();
+    const int nstep = (rows * Wp + 31) >> 5;
+    for (int s = 0; s < nstep; ++s) {
+      s16x4_t va[2][KT], vb[2][CT];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = s * 32 + 16 * h + 4 * fg + qq;
+#pragma unroll
+        for (int a = 0; a < KT; ++a) THIN_TR(va[h][a], dyL + (unsigned)(r * K * 2 + a * 32 + pp * 8));
+#pragma unroll
+        for (int b = 0; b < CT; ++b) THIN_TR(vb[h][b], xL + (unsigned)((r + xoff) * C * 2 + b * 32 + pp * 8));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      bf16x8_t fa[KT], fb[CT];
+#pragma unroll
+      for (int a = 0; a < KT; ++a) {
+        const s16x8_t w8 = {va[0][a][0], va[0][a][1], va[0][a][2], va[0][a][3], va[1][a][0], va[1][a][1], va[1][a][2], va[1][a][3]};
+        fa[a] = __builtin_bit_cast(bf16x8_t, w8);
+      }
+#pragma unroll
+      for (int b = 0; b < CT; ++b) {
+        const s16x8_t w8 = {vb[0][b][0], vb[0][b][1], vb[0][b][2], vb[0][b][3], vb[1][b][0], vb[1][b][1], vb[1][b][2], vb[1][b][3]};
+        fb[b] = __builtin_bit_cast(bf16x8_t, w8);
+      }
+#pragma unroll
+      for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  // the block's partial in dW layout [k][tap][c]: lane holds c = lane & 15, k = 4 * (lane >> 4) + r
+  float* out = slab + (long)blockIdx.x * 9 * K * C;
+  const int fj = lane & 15;
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[((a * 16 + fg * 4 + r) * 9 + tap) * C + b * 16 + fj] = acc[a][b][r];
+}
+
+// dw[i] += sum over blocks (in block order) of slab[b][i]: eight lanes per element take an eighth of the blocks each
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nb, int n) {
+  __shared__ float red[8][32];
+  const int ix = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + ix;
+  const int per = (nb + 7) >> 3;
+  const int pe = min(nb, (py + 1) * per);
+  float t = 0.f;
+  if (i < n) {
+    int p = py * per;
+    for (; p + 8 <= pe; p += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slab[(long)(p + u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; p < pe; ++p) t += slab[(long)p * n + i];
+  }
+  red[py][ix] = t;
+  __syncthreads();
+  if (py != 0 || i >= n) return;
+  t = red[0][ix];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) t += red[k][ix];
+  dw[i] += t;
+}
+
+static std::atomic<long> g_thin_wgrad_launches{0};
+extern "C" int64_t mscl_debug_thin_wgrad_launches(void) { return g_thin_wgrad_launches.load(); }
+
+static bool thin_wgrad_geom(const mscl_conv_desc* d, ThinWGeom& g) {
+  if (!(d->kT == 1 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 1 && d->pW == 1)) return false;
+  if (!((d->C == 16 || d->C == 32) && (d->K == 16 || d->K == 32))) return false;
+  if (d->H < 4 || d->W < 4 || d->W > 254) return false;
+  if (const char* e = getenv("MSCL_THIN")) if (atoi(e) == 0) return false;
+  g.planes = d->N * d->T; g.H = d->H; g.W = d->W;
+  g.RB = (d->H % 8 == 0) ? 8 : (d->H % 7 == 0) ? 7 : 8;
+  g.bands = (d->H + g.RB - 1) / g.RB;
+  const long units = (long)g.planes * g.bands;
+  if (units >= (1L << 30)) return false;
+  g.units = (int)units;
+  const long pbytes = (long)9 * d->K * d->C * 4;
+  long upb = (units + 511) / 512;                                  // at most 512 blocks ...
+  const long byb = (units * pbytes + (12L << 20) - 1) / (12L << 20);      // ... and at most 12 MB of slabs
+  if (byb > upb) upb = byb;
+  g.upb = (int)upb;
+  const int Wp = d->W + 2;
+  g.QD = (g.RB * Wp + 31) / 32 * 32;
+  g.XR = g.QD + 2 * Wp + 3;
+  g.dWp = make_fastdiv(Wp); g.dBands = make_fastdiv(g.bands);
+  return ((size_t)g.QD * d->K + (size_t)g.XR * d->C) * 2 <= 64 * 1024;
+}
+
+extern "C" int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d) {
+  ThinWGeom g;
+  if (!d || !thin_wgrad_geom(d, g)) return 0;
+  return (int64_t)((g.units + g.upb - 1) / g.upb) * 9 * d->K * d->C;
+}
+
+// 1 = launched (dw += the gradient), 0 = shape not covered or no workspace
+int mscl_wgrad_thin(const mscl_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* ws, int64_t ws_floats, hipStream_t st) {
+  ThinWGeom g;
+  if (!thin_wgrad_geom(d, g)) return 0;
+  const int nb = (g.units + g.upb - 1) / g.upb;
+  const int n = 9 * d->K * d->C;
+  if (ws == nullptr || ws_floats < (int64_t)nb * n) return 0;
+  const size_t lds = ((size_t)g.QD * d->K + (size_t)g.XR * d->C) * 2;
+#define THIN_WGO(CC, KK) hipLaunchKernelGGL((wgrad_thin_kernel<CC, KK>), dim3(nb), dim3(576), lds, st, g, x, dy, ws)
+  if (d->C == 16 && d->K == 16) THIN_WGO(16, 16);
+  else if (d->C == 16 && d->K == 32) THIN_WGO(16, 32);
+  else if (d->C == 32 && d->K == 16) THIN_WGO(32, 16);
+  else THIN_WGO(32, 32);
+#undef THIN_WGO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)ws, dw, nb, n);
+  e = hipGetLastError();
+  if (e != hipSuccess) return -(int)e;
+  g_thin_wgrad_launches.fetch_add(1);
+  return 1;
+}

@@ -391,6 +391,8 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
                       hipStream_t st);           // conv_wgrad_halo.hip
 int mscl_wgrad_pp(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                   hipStream_t st);               // conv_wgrad_pp.hip
+int mscl_wgrad_thin(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
+                    hipStream_t st);             // conv_thin.hip
 // shared-tap ping-pong kernel (conv_wgrad_pp.hip): MSCL_WGRAD_PP 0 (default) = off, 1 = maps of >= 16384 positions, 2 = wherever it
 // applies.  Opt-in: alone it ties the 128 x 128 kernel below on layer 2 (82.5 vs 81.0 us) and loses on the small maps (layer 4: 56 vs
 // 40 us); inside the step 1010 / 1000 vs 1033 clip-pairs/s (levels 1 / 2 vs 0) -- see the header of conv_wgrad_pp.hip for why.
@@ -448,7 +450,13 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
     pres = mscl_wgrad_pp(d, x, dy, dw, ws, ws_floats - tail, st);
     if (pres < 0 || pres > 1) return pres;
   }
-  if (hres == 1 || pres == 1) e = 0;
+  int tres = 0;
+  if (hres == 0 && pres == 0 && ws != nullptr) {          // 1x3x3 between 16- / 32-channel maps: window-resident kernel (conv_thin.hip)
+    const long tail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
+    tres = mscl_wgrad_thin(d, x, dy, dw, ws, ws_floats - tail, st);
+    if (tres < 0 || tres > 1) return tres;
+  }
+  if (hres == 1 || pres == 1 || tres == 1) e = 0;
   else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st, dws, dfl);
   else if (d->K >= 64) e = launch_w<64, 64>(g, x, dy, dw, st, dws, dfl);
   else if (d->K == 32) e = launch_w<32, 64>(g, x, dy, dw, st, dws, dfl);
@@ -480,9 +488,11 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
 // floats of `ws` mscl_conv3d_wgrad wants for this layer in deterministic mode (at most 64 slabs of the weight gradient plus
 // the bias partials); 0 outside deterministic mode for layers that do not use the window-resident kernel
 extern "C" int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
+extern "C" int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) {
   if (!d) return 0;
-  const int64_t pp = wgrad_pp_enabled(d) ? mscl_wgrad_pp_ws(d) : 0;
+  int64_t pp = wgrad_pp_enabled(d) ? mscl_wgrad_pp_ws(d) : 0;
+  if (pp == 0) pp = mscl_wgrad_thin_ws(d);
   if (!mscl_det()) return pp;
   if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_DET_PARTS * d->K : 0);
   const int64_t dwn = (int64_t)d->K * d->kT * d->kH * d->kW * d->C;

@@ -269,6 +269,17 @@ def test_conv_thin(case, dev):
     dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
     assert lib.call_raw('mscl_debug_thin_launches') == n1 + 1, 'the input gradient did not take the window-resident kernel'
     close(dx, xr.grad + add.float(), BF16_TOL, 'thin dgrad+addend')
+    # weight gradient: accumulates into a non-zero dw, fixed-order slab sums (the same bits every run), bias gradient beside it
+    dw = torch.zeros((K, *kern, C), dtype=torch.float32, device=dev); db = torch.zeros((K,), dtype=torch.float32, device=dev)
+    n2 = lib.call_raw('mscl_debug_thin_wgrad_launches')
+    K_.conv3d_wgrad(xg, dy.to(dev), d, dw, db)
+    assert lib.call_raw('mscl_debug_thin_wgrad_launches') == n2 + 1, 'the weight gradient did not take the window-resident kernel'
+    wr2 = w.float().requires_grad_(True)
+    _conv_ref(x.float(), wr2, stride, pad).backward(dy.float())
+    close(dw, wr2.grad, F32_TOL, 'thin wgrad'); close(db, dy.float().sum(dim=(0, 1, 2, 3)), F32_TOL, 'thin dbias')
+    first = dw.clone()
+    K_.conv3d_wgrad(xg, dy.to(dev), d, dw, None)
+    assert torch.equal(dw, 2 * first)
     # against the implicit-GEMM kernel on the same inputs: same products, fp32 sums in another order
     import os
     os.environ['MSCL_THIN'] = '0'
