@@ -411,6 +411,66 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* __restr
     *reinterpret_cast<uint4*>(ds + (long)e * 8) = pack8(f);
   }
 }
+// The same gather for scales <= 2 per axis (every upsample of the FPN / SEPC necks): the fine cells that touch a coarse cell are
+// at most FOUR consecutive ones per axis (nearest: 2; trilinear, align_corners = False: 2i-1 .. 2i+2), so each axis is decoded once
+// into (first index, four weights) -- the general kernel above re-derives the weights inside the triple loop, 126 coordinate
+// computations and up to 216 trips per element for 64 loads, and took 26-31 us on a 12.8-MB map.  Same candidates in the same
+// (t, h, w) order with the same weight products: the same bits.
+__device__ __forceinline__ void up_axis4(int is, int n_src, int n_dst, FastDiv dD, int trilinear, int& d0, float (&wt)[4]) {
+  const float sc = (float)n_dst / (float)n_src;
+  int lo, hi;
+  if (!trilinear) { lo = (int)floorf(is * sc); hi = (int)ceilf((is + 1) * sc); }
+  else { lo = (int)floorf((is - 0.5f) * sc - 0.5f); hi = (int)ceilf((is + 1.5f) * sc - 0.5f); }
+  lo = max(0, lo); hi = min(n_dst - 1, hi);
+  auto weight = [&](int d) -> float {
+    if (d > hi) return 0.f;
+    if (!trilinear) return (fdiv(d * n_src, dD) == is) ? 1.f : 0.f;
+    int i0, i1; float a; lin_coord(d, n_src, n_dst, i0, i1, a);
+    return (i0 == is ? 1.f - a : 0.f) + (i1 == is ? a : 0.f);
+  };
+  d0 = lo;
+  for (int k = 0; k < 3 && weight(d0) == 0.f && d0 < hi; ++k) ++d0;      // at most two zero-weight candidates lead (open bounds)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wt[k] = weight(d0 + k);
+}
+__global__ __launch_bounds__(256) void upsample_bwd4_kernel(const bf16_t* __restrict__ dd, bf16_t* __restrict__ ds, int N,
+                                                            int Ts, int Hs, int Ws, int Td, int Hd, int Wd, int C,
+                                                            int trilinear, UpDiv dv) {
+  const int G = C >> 3;
+  const int total = N * Ts * Hs * Ws * G;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int r = fdiv(e, dv.G); const int gq = e - r * G;
+    int q = fdiv(r, dv.Ws); const int ws = r - q * Ws; r = q;
+    q = fdiv(r, dv.Hs); const int hs = r - q * Hs; r = q;
+    const int n = fdiv(r, dv.Ts), ts = r - n * Ts;
+    int t0, h0, w0; float wt_t[4], wt_h[4], wt_w[4];
+    up_axis4(ts, Ts, Td, dv.Td, trilinear, t0, wt_t);
+    up_axis4(hs, Hs, Hd, dv.Hd, trilinear, h0, wt_h);
+    up_axis4(ws, Ws, Wd, dv.Wd, trilinear, w0, wt_w);
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (wt_t[a] == 0.f) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (wt_h[b] == 0.f) continue;
+        const bf16_t* row = dd + ((((long)n * Td + t0 + a) * Hd + h0 + b) * Wd + w0) * C + gq * 8;
+        uint4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = wt_w[c] != 0.f ? *reinterpret_cast<const uint4*>(row + (long)c * C) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (wt_w[c] == 0.f) continue;
+          float g8[8]; unpack8(v[c], g8);
+          const float wt = wt_t[a] * wt_h[b] * wt_w[c];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] += wt * g8[i];
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(ds + (long)e * 8) = pack8(f);
+  }
+}
 extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, int Ts, int Hs, int Ws, int Td, int Hd, int Wd,
                                  int C, int trilinear, void* stream) {
   if (!ddst || !dsrc || N <= 0 || Ts <= 0 || Hs <= 0 || Ws <= 0 || Td <= 0 || Hd <= 0 || Wd <= 0) return MSCL_E_ARG;
@@ -418,8 +478,12 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
   const long total = (long)N * Ts * Hs * Ws * (C / 8);
   if ((long)N * Td * Hd * Wd * (C / 8) >= (1L << 31) || (long)Td * Ts >= (1L << 31)) return MSCL_E_SHAPE;
   long blocks = (total + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, N, Ts, Hs, Ws,
-                     Td, Hd, Wd, C, trilinear, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
+  if (Td <= 2 * Ts && Hd <= 2 * Hs && Wd <= 2 * Ws && Td >= Ts && Hd >= Hs && Wd >= Ws)
+    hipLaunchKernelGGL(upsample_bwd4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, N, Ts, Hs, Ws,
+                       Td, Hd, Wd, C, trilinear, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
+  else
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, N, Ts, Hs, Ws,
+                       Td, Hd, Wd, C, trilinear, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));
   MSCL_LAUNCH_CHECK();
   return 0;
 }

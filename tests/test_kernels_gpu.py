@@ -547,7 +547,9 @@ def test_pack_add_relu_pool(dev):
 def test_upsample(tri, dev):
     from mscl_amd import kernels as K_
     mode = 'trilinear' if tri else 'nearest'
-    for (ss, ds) in (((2, 7, 7), (4, 14, 14)), ((4, 14, 14), (8, 28, 28)), ((2, 3, 5), (3, 7, 9))):
+    # scales of exactly 2 (the necks), 1 along some axes, between 1 and 2, and above 2 (the general backward kernel)
+    for (ss, ds) in (((2, 7, 7), (4, 14, 14)), ((4, 14, 14), (8, 28, 28)), ((2, 3, 5), (3, 7, 9)), ((2, 7, 7), (4, 7, 7)),
+                     ((3, 5, 6), (5, 9, 11)), ((1, 1, 3), (2, 2, 6))):
         src = bf(rnd((2, *ss, 16), 1)); dst = bf(rnd((2, *ds, 16), 2))
         sr = src.float().requires_grad_(True)
         up = F.interpolate(sr.permute(0, 4, 1, 2, 3), size=ds, mode=mode).permute(0, 2, 3, 4, 1)
