@@ -478,10 +478,6 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
     if (want * out_elems > ws_floats) want = ws_floats / out_elems;
     if (want > 1) g.ksplit = (int)want;
   }
-  if (const char* f = getenv("MSCL_IGEMM_KSPLIT")) {        // tuning aid
-    long want = atoi(f);
-    if (ws != nullptr && want >= 1 && want <= nk && want * out_elems <= ws_floats) g.ksplit = (int)want;
-  }
   float* partial = g.ksplit > 1 ? ws : nullptr;
   bool launched = false;
   if constexpr (fast_tile<BM, BN, BK, WAVES_M, WAVES_N, STAGES>()) {
@@ -533,16 +529,6 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   auto blocks = [&](int bm, int bn) { return (long)((rowsM + bm - 1) / bm) * ((Cr + bn - 1) / bn); };
 #define GO3(BM, BN, BK, WMv, WNv, ST) return launch_cfg<BM, BN, BK, WMv, WNv, ST>(g, src, wgt, out, bias, addend, ssum, ssq, relu, ws, ws_floats, st)
 #define GO(BM, BN, BK, WMv, WNv) GO3(BM, BN, BK, WMv, WNv, 2)
-  if (const char* force = getenv("MSCL_IGEMM_CFG")) {       // tuning aid: "BM,BN,BK"
-    int bm = 0, bn = 0, bk = 0;
-    if (sscanf(force, "%d,%d,%d", &bm, &bn, &bk) == 3 && (bk == 32 || bk64) && bn <= (Cr < 16 ? 16 : Cr)) {
-#define TRY(BM, BN, BK, WMv, WNv) if (bm == BM && bn == BN && bk == BK) { GO(BM, BN, BK, WMv, WNv); }
-      TRY(128, 128, 64, 2, 2); TRY(64, 128, 64, 2, 2); TRY(256, 64, 64, 4, 1); TRY(128, 64, 64, 2, 2); TRY(64, 64, 64, 2, 2);
-      TRY(128, 128, 32, 2, 2); TRY(256, 64, 32, 4, 1); TRY(128, 64, 32, 2, 2); TRY(64, 64, 32, 2, 2);
-      TRY(256, 128, 32, 4, 1); TRY(64, 128, 32, 2, 2);
-#undef TRY
-    }
-  }
   // ping-pong kernel with shared W taps (conv_pp.hip): kW = 3, stride 1 along W, source channels a multiple of 64, output
   // channels a multiple of 128.  MSCL_PP: 0 = off, 1 (default) = layers of >= 400 k outputs (784 positions x 512 channels and up:
   // measured faster on every such shape of the step; the 784 x 128 pyramid level is not), 2 = wherever it applies.

@@ -405,10 +405,9 @@ static bool wgrad_pp_enabled(const mscl_conv_desc* d) {
 
 // 128 x 128 tile, 2 x 2 waves of 64 x 64: per 64-position step a wave makes 16 transposing reads for 16 MFMAs (the 64 x 64
 // tile with the columns split four ways makes 10 for 4 and asks the LDS for 320 B/clk), and a block stages 32 KB for 128
-// MFMAs instead of 16 KB for 32.  MSCL_WGRAD_TILE=64 / 128 forces the choice.
+// MFMAs instead of 16 KB for 32.
 static bool big_tile(const mscl_conv_desc* d) {
   if (d->K < 128 || d->C < 64) return false;
-  if (const char* f = getenv("MSCL_WGRAD_TILE")) return atoi(f) == 128;
   // measured (us, 64 -> 128 tile): 50176 positions x 27 taps 110 -> 86 (128 ch), 65 -> 57 (64 -> 128 ch, stride 2); 6272 positions
   // 58 -> 56; but 9-tap / 1-tap layers and maps of a few thousand positions lose (too few tiles to split over): 44 -> 47, 24 -> 32
   const long M = (long)d->N * d->To * d->Ho * d->Wo;

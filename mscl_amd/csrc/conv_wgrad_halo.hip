@@ -244,12 +244,10 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
                       hipStream_t st) {
   if (d->C != 64 || d->K != 64 || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
       d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
-  const char* e = getenv("MSCL_WGRAD_HALO");
-  if (e && e[0] == '0') return 0;
   WHGeom g{};
   g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
   if (256 + 2 * g.Wp + 2 > WH_XROWS || (long)d->N * d->T * g.HW * 64 * 2 >= (1L << 31)) return 0;
-  if (!(e && e[0] == '1') && (long)d->H * g.Wp < 1024) return 0;          // small planes: the general kernel
+  if ((long)d->H * g.Wp < 1024) return 0;          // small planes: the general kernel
   g.tiles = (d->H * g.Wp + 255) / 256;
   g.total = d->N * d->T * g.tiles;
   static int cus = 0;

@@ -54,9 +54,7 @@ def fwd_ws(d, device, stat_groups=0):
     return torch.empty((n,), dtype=torch.float32, device=device) if n else None
 
 
-import os as _os
-STAT_SLOTS = int(_os.environ.get('MSCL_STAT_SLOTS', 16))   # = MSCL_STAT_SLOTS (include/mscl_hip.h): BN statistics buffers are [slots][2][C]
-# (the environment variable only serves A/B runs against a library built with another -DMSCL_STAT_SLOTS, selected by MSCL_LIB)
+STAT_SLOTS = 16         # = MSCL_STAT_SLOTS (include/mscl_hip.h): BN statistics buffers are [slots][2][C]
 STAT_ACTIVE = 4         # = MSCL_STAT_ACTIVE (csrc/common.h): the slots the atomic producers use and the consumers add outside deterministic mode
 
 

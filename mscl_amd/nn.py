@@ -7,7 +7,7 @@ never travel through autograd: kernels accumulate them straight into the flat gr
 (mscl_amd/arena.py), so a fused block is one graph node.
 """
 import ctypes
-import os
+
 
 import torch
 import torch.nn as nn
@@ -169,11 +169,11 @@ def cba_eval(conv, bn, x, residual, relu):
     return out
 
 
-# Opt-in (MSCL_FUSE_BN_REDUCE=1): measured on the layer-1 map (tools/bench_fused_bn.py) the fused epilogue adds 38 us to the
+# Off (nn.FUSE_BN_REDUCE = True turns it on, tests do): measured on the layer-1 map (tools/bench_fused_bn.py) the fused epilogue adds 38 us to the
 # input-gradient kernel (two more maps read at the 2.7 TB/s a one-block-per-CU epilogue reaches) and takes 36-42 us off the
 # BatchNorm backward: no gain on the step (900 vs 907-918 clip-pairs/s).  Staging the epilogue's operands into the window slot
 # that is free during the last nine taps is what would make it pay.
-FUSE_BN_REDUCE = os.environ.get('MSCL_FUSE_BN_REDUCE', '0') == '1'
+FUSE_BN_REDUCE = False
 # gradient tensors that are dz already, with their BatchNorm's sums reduced by the producing kernel: data_ptr -> scratch.
 # Filled by cba_bwd(next_bn=...), consumed by the cba_bwd of that BatchNorm -- in the same autograd node (conv2 -> bn1) or
 # in the previous block's / the stem's node (conv1 + shortcut -> bn2 / stem bn).  Cleared at every step start.

@@ -612,21 +612,22 @@ class MSCLWithAug(nn.Module):
         self._step = 0
         self._scal = self._idx = self._inv = None         # staging.StagingRing: per-step words, host -> device
         self._bg = 0
-        self.shuffle_mode = os.environ.get('MSCL_SHUFFLE', 'a2a')      # 'a2a' | 'gather' (shuffle-BN exchange, world size > 1)
+        self.shuffle_mode = 'a2a'      # 'a2a' | 'gather' (shuffle-BN exchange, world size > 1; graph.py sets 'gather')
         self._a2a = False
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
-        self.loss_fork = os.environ.get('MSCL_LOSS_FORK', '1') != '0'          # RGB-queue InfoNCE pass beside the flow-queue passes
-        # ... and (opt-in, MSCL_LOSS_FORK_C=1) the post-enqueue flow-queue pass on a "virtual" snapshot beside the pre-enqueue one:
+        self.stream_probing = True     # side streams chosen by the overlap probe (streams.py); False: the first ones created
+        self.loss_fork = True          # RGB-queue InfoNCE pass beside the flow-queue passes
+        # ... and (attribute, off) the post-enqueue flow-queue pass on a "virtual" snapshot beside the pre-enqueue one:
         # exact (test_nce_virtual_enqueue_equals_real_enqueue) but no faster -- 957.8 vs 957.6 clip-pairs/s over five alternating pairs
-        self.loss_fork_c = os.environ.get('MSCL_LOSS_FORK_C', '0') == '1' 
-        self.key_graphs = os.environ.get('MSCL_KEY_GRAPHS', '1') == '1'          # key branches as sub-graphs in eager steps
+        self.loss_fork_c = False
+        self.key_graphs = True          # key branches as sub-graphs in eager steps
         self._key_graph = [KeyGraph(), KeyGraph(), KeyGraph()]                  # RGB, flow base, flow rotated
-        self.query_graphs = os.environ.get('MSCL_QUERY_GRAPHS', '1') == '1'      # flow query passes (fwd + bwd) likewise
+        self.query_graphs = True      # flow query passes (fwd + bwd) likewise
         self._query_graph = [QueryGraph(), QueryGraph()]                         # flow base, flow rotated
         self._graph_anchor = None
         # base || rotated flow query clips in ONE trunk pass with two BatchNorm statistics groups (halves the ~250 launches of the
         # two query passes, forward and backward); needs a flow neck without parameters of its own (BaseMoCo)
-        self.flow_batch = os.environ.get('MSCL_FLOW_BATCH', '1') == '1'
+        self.flow_batch = True
         # RGB weight gradients (leaves of the backward chain) off the main stream -- an experiment that stays OFF: '1' = a stream of
         # their own, 'flow' / 'key' = the flow / RGB-key stream (idle during most of the backward).  Measured in round 2 against
         # 954-957 clip-pairs/s: 889 / 851-856 / 892.  Two MFMA-heavy kernels side by side lose more than the shorter chain gains.
@@ -877,7 +878,7 @@ class MSCLWithAug(nn.Module):
         import time
         from .streams import pick_side_streams
         dev = self.arena.device
-        cand = [torch.cuda.Stream(device=dev) for _ in range(n if os.environ.get('MSCL_STREAM_PROBE') == '0' else 12)]
+        cand = [torch.cuda.Stream(device=dev) for _ in range(12 if self.stream_probing else n)]
         if len(cand) == n or torch.cuda.is_current_stream_capturing():
             return cand[:n]
         main = torch.cuda.current_stream()
@@ -910,7 +911,7 @@ class MSCLWithAug(nn.Module):
                 dist.all_reduce(self.buf)                               # issued from the idle main stream
                 torch.cuda.synchronize()
                 return time.perf_counter() - t0
-        use_comm = (not parallel.single() and dist.get_backend() == 'nccl' and os.environ.get('MSCL_STREAM_PROBE') != 'nocomm')
+        use_comm = not parallel.single() and dist.get_backend() == 'nccl'
         chosen, self.stream_probe = pick_side_streams(cand, n, spin, _Comm() if use_comm else None)
         return chosen
 

@@ -46,8 +46,10 @@ def build(num_frames, K, dev, arch='r18'):
     return m, cfg
 
 
-def loss_close(got, ref, what):
-    assert abs(got - ref) <= 0.02 * max(1.0, abs(ref)) + 0.03, f'{what}: hip {got} vs ref {ref}'
+def loss_close(got, ref, what, tol=2e-3):
+    """loss-like scalars: relative to max(1, |ref|).  2e-3 is the bar for one step from the same weights on the same inputs (bf16
+    convolution operands, fp32 sums); a caller that compares across a noisier boundary passes its own tolerance and says why."""
+    assert abs(got - ref) <= tol * max(1.0, abs(ref)), f'{what}: hip {got} vs ref {ref}'
 
 
 def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None):

@@ -3,7 +3,8 @@ bf16 storage ahead of BatchNorm-backward (per-tensor gradient cosine ~0.92 on tr
 optimizer does?  60 optimizer steps (clip 40, SGD 0.9 / 1e-4, lr 0.02) on four rotating synthetic batches, B = 4, T = 8, 64^2,
 K = 256 -- the setting of tests/test_model_gpu.py::test_training_learns, where the frame-level LMCL term has a learnable answer.
 Prints a markdown table of the total loss, loss_pos and loss_cls of both runs every 5 steps.
-usage: python tools/train_curve.py [--steps 60] > profiles/r02_training_curve.md"""
+usage: python tools/train_curve.py [--steps 60] [--batch 4] [--every 5] [--deterministic] > profiles/r03_training_curve.md
+(--steps 500 --batch 2 --every 25 --deterministic: the long curve of round 3, the HIP side with fixed-order sums)"""
 import argparse
 import os
 import sys
@@ -18,13 +19,19 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--every', type=int, default=5)
+    ap.add_argument('--deterministic', action='store_true')
     a = ap.parse_args()
     import test_model_gpu as tm
     from mscl_amd import ClipSGD
     from mscl_amd.synthetic import synthetic_batch
     from oracle import fill as ofill, mscl as om
     dev = torch.device('cuda:0')
-    B, T, H, Kq = 4, 8, 64, 256
+    B, T, H, Kq = a.batch, 8, 64, 256
+    if a.deterministic:
+        from mscl_amd import lib
+        lib.set_deterministic(True)
     model, cfg = tm.build(T, Kq, dev)
     opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
     orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
@@ -34,8 +41,9 @@ def main():
     dbatches = [{k: [t.to(dev) for t in v] for k, v in b.items()} for b in batches]
     keys = ('loss', 'loss_pos', 'loss_cls', 'loss_cls_flow', 'loss_cls_mx')
     print('# HIP path (bf16 convolutions) vs fp32 oracle: %d optimizer steps from the same weights on the same batches\n' % a.steps)
-    print('`python tools/train_curve.py` (B = 4, T = 8, 64^2, K = 256, four rotating synthetic batches, lr 0.02, clip 40).  After step 0 the two')
-    print('runs are different trajectories of a chaotic system (batch-4 BatchNorm), so values are compared as curves, not digit by digit.\n')
+    print('`python tools/train_curve.py --steps %d --batch %d%s` (B = %d, T = 8, 64^2, K = 256, four rotating synthetic batches, lr 0.02, clip 40).  After step 0 the two'
+          % (a.steps, B, ' --deterministic' if a.deterministic else '', B))
+    print('runs are different trajectories of a chaotic system (small-batch BatchNorm), so values are compared as curves, not digit by digit.\n')
     print('| step | ' + ' | '.join(f'{k} hip / oracle' for k in keys) + ' | grad norm hip / oracle |')
     print('|---|' + '---|' * (len(keys) + 1))
     for it in range(a.steps):
@@ -45,7 +53,7 @@ def main():
         torch.manual_seed(100 + it)
         oo = orc.train_step(batches[it % 4]); oopt.zero_grad(); oo['loss'].backward()
         go = oopt.step()
-        if it % 5 == 0 or it == a.steps - 1:
+        if it % a.every == 0 or it == a.steps - 1:
             lv, ov = out['log_vars'], oo['log_vars']
             print(f'| {it} | ' + ' | '.join(f'{lv[k]:.4f} / {ov[k]:.4f}' for k in keys) + f' | {gh:.1f} / {go:.1f} |', flush=True)
 
