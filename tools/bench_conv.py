@@ -123,7 +123,7 @@ def main():
     ap.add_argument('--modes', default='fwd,dgrad,wgrad')
     ap.add_argument('--sweep', default=None, help='NAME=v1,v2,..: A/B an environment tuning hook that the library reads per '
                     'launch (e.g. MSCL_PP=0,1,2), variants interleaved per shape in ONE process')
-    ap.add_argument('--rounds', type=int, default=3, help='rounds per variant with --sweep (min is reported)')
+    ap.add_argument('--rounds', type=int, default=3, help='rounds per measurement (min is reported)')
     ap.add_argument('--r50', action='store_true', help='the ResNet3dSlowOnly-50 shapes at 8 x 32 x 224^2 instead (adds a GB/s column: x + y bytes)')
     ap.add_argument('--no-stats', action='store_true', help='forward without the BatchNorm statistics epilogue')
     a = ap.parse_args()
@@ -148,15 +148,17 @@ def main():
         out = [f'{name:16s} {flops/1e9:7.2f} GF']
         nbytes = 2.0 * (x.numel() + dy.numel())
         gbs = (lambda ms: f' {nbytes/ms/1e6:6.0f} GB/s') if a.r50 else (lambda ms: '')
+        # min over --rounds rounds of the mean of --iters launches: the first rounds of a process run at ramping clocks
+        best = lambda fn: min(timeit(fn, a.iters) for _ in range(a.rounds))
         if 'fwd' in modes:
             st = None if a.no_stats else (stats[0], stats[1])
-            ms = timeit(lambda: K.conv3d_fwd(x, w, d, stats=st), a.iters)
+            ms = best(lambda: K.conv3d_fwd(x, w, d, stats=st))
             out.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF' + gbs(ms))
         if 'dgrad' in modes and C >= 16:
-            ms = timeit(lambda: K.conv3d_dgrad(dy, wT, d), a.iters)
+            ms = best(lambda: K.conv3d_dgrad(dy, wT, d))
             out.append(f'dgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF' + gbs(ms))
         if 'wgrad' in modes:
-            ms = timeit(lambda: K.conv3d_wgrad(x, dy, d, dw), a.iters)
+            ms = best(lambda: K.conv3d_wgrad(x, dy, d, dw))
             out.append(f'wgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF' + gbs(ms))
         print('  '.join(out), flush=True)
 
