@@ -245,7 +245,7 @@ def main():
         achieved = flops / (avg_ms * 1e-3) / 1e12 if ms else 0.0
         traffic = None
         tname = None
-        for tname in ('r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
+        for tname in ('r03_traffic_layer1.json', 'r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
             tp = os.path.join(ROOT, 'profiles', tname)
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get('traffic_bytes_per_launch')

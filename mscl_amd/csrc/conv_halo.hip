@@ -299,10 +299,16 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
     }
   }
   // ---- epilogue: BatchNorm statistics ----
+  // Every wave plain-stores its 64-channel sums as one LDS row ([wave][2][64], eight 16-byte writes per wave); 128 threads add the
+  // rows (no LDS atomics).  This section costs the forward 12-13 us on the layer-1 map (108 vs 95 us for the same kernel as input
+  // gradient; ~1.7 us per block, and a CU takes its 6-7 blocks one after the other).  Measured NOT to be the cause: the global float
+  // atomics (per-block rows + a fold launch: the same), the LDS atomics this form replaced (the same), slot count 1 .. 1024, slot
+  // stride, placement, statistics after the output stores.  What is left is its own arithmetic at the end of every block: 64 FMAs
+  // and 32 sixteen-lane reductions (128 dependent DPP adds) per wave between two barriers.
   if (stat_sum != nullptr) {
-    float* red = reinterpret_cast<float*>(smem);      // [2][64]
-    for (int i = tid; i < 2 * HC; i += 64 * NW) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [NW][2][64]
+    const int wv = tid >> 6;
+    __syncthreads();                                  // the tiles are dead
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -320,18 +326,17 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
         s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
       }
       if (fr == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nl = j * 16 + fq * 4 + r;
-          atomicAdd(&red[nl], s[r]);
-          atomicAdd(&red[HC + nl], q[r]);
-        }
+        *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * HC + j * 16 + fq * 4]) = make_float4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * HC + j * 16 + fq * 4]) = make_float4(q[0], q[1], q[2], q[3]);
       }
     }
     __syncthreads();
-    for (int i = tid; i < HC; i += 64 * NW) {
+    if (tid < 2 * HC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) t += red[w8 * 2 * HC + tid];
       const int so = (int)(blockIdx.x % MSCL_STAT_ACTIVE) * g.stat_stride;
-      atomicAdd(&stat_sum[so + i], red[i]); atomicAdd(&stat_sq[so + i], red[HC + i]);
+      atomicAdd(tid < HC ? &stat_sum[so + tid] : &stat_sq[so + tid - HC], t);
     }
   }
   const bool plain_add = addend != nullptr && !fused_bn;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IGemmGeom& g, f32x4_t 
 
   // ---- epilogue: BatchNorm statistics of the raw fp32 result ----
   if (stat_sum != nullptr) {
-    float* red = reinterpret_cast<float*>(smem);      // [2][BN], tiles are dead after the last barrier
+    float* red = reinterpret_cast<float*>(smem);      // [waves][2][JN * 16]
     // statistics groups (a batch that holds two BatchNorm calls of the reference, e.g. base || rotated flow clips): rows below
     // `bound` feed group g_lo, the rest (a tile that straddles the boundary; there are at most two groups) group g_lo + 1
     int g_lo = 0, bound = 0x7fffffff, npass = 1;
@@ -73,9 +73,12 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IGemmGeom& g, f32x4_t 
       bound = (g_lo + 1) * g.grp_rows;
       npass = (min(m0 + BM, Mc) > bound) ? 2 : 1;
     }
+    // Every wave plain-stores the sums of its JN * 16 channels as one LDS row ([wave row][wave column][2][JN * 16]); the block's
+    // first BN threads add the rows of their column (no LDS atomics, no zero-fill pass; cost of this section: conv_halo.hip).
+    constexpr int WCH = JN * 16, NWM = BM / (IM * 16), NWN = BN / WCH;
+    const int wrow = (wm0 / (IM * 16)) * NWN + wn0 / WCH;
     for (int pass = 0; pass < npass; ++pass) {
-      for (int i = tid; i < 2 * BN; i += (int)blockDim.x) red[i] = 0.f;
-      __syncthreads();
+      __syncthreads();                                // the tiles (or the previous pass's rows) are dead
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -90,22 +93,21 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IGemmGeom& g, f32x4_t 
           s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
         }
         if (fr == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int nl = wn0 + j * 16 + fq * 4 + r;
-            atomicAdd(&red[nl], s[r]);
-            atomicAdd(&red[BN + nl], q[r]);
-          }
+          *reinterpret_cast<float4*>(&red[(wrow * 2 + 0) * WCH + j * 16 + fq * 4]) = make_float4(s[0], s[1], s[2], s[3]);
+          *reinterpret_cast<float4*>(&red[(wrow * 2 + 1) * WCH + j * 16 + fq * 4]) = make_float4(q[0], q[1], q[2], q[3]);
         }
       }
       __syncthreads();
       for (int i = tid; i < BN; i += (int)blockDim.x) {
         if (n0 + i < g.Cr) {
+          const int wn = i / WCH, c = i - wn * WCH;
+          float ts = 0.f, tq = 0.f;
+#pragma unroll
+          for (int m = 0; m < NWM; ++m) { ts += red[((m * NWN + wn) * 2 + 0) * WCH + c]; tq += red[((m * NWN + wn) * 2 + 1) * WCH + c]; }
           const int so = ((g_lo + pass) * MSCL_STAT_SLOTS + (int)(blockIdx.x % MSCL_STAT_ACTIVE)) * 2 * g.Cr;
-          atomicAdd(&stat_sum[so + n0 + i], red[i]); atomicAdd(&stat_sq[so + n0 + i], red[BN + i]);
+          atomicAdd(&stat_sum[so + n0 + i], ts); atomicAdd(&stat_sq[so + n0 + i], tq);
         }
       }
-      if (npass > 1) __syncthreads();
     }
   }
 

@@ -59,10 +59,8 @@ _STATS_POOL = None
 
 
 def stats_slice(Kc, dev):
-    """[2][K] statistics rows cut from a 16-MB buffer, as the step cuts them from kernels.ZEROS.  (Measured while looking for the 12-13
-    us the statistics epilogue costs the layer-1 forward, 108 vs 95 us for the same kernel without it: neither the slot count (1 ..
-    1024), nor the slot stride, nor the placement of the rows changes it; plain stores instead of the 128 float atomics per block
-    remove it -- a block's last wave waits for its atomics before the CU takes the next block.)"""
+    """[2][K] statistics rows cut from a 16-MB buffer, as the step cuts them from kernels.ZEROS (what the statistics epilogue costs the
+    layer-1 forward, and what does not cause it: conv_halo.hip)"""
     global _STATS_POOL
     if _STATS_POOL is None:
         _STATS_POOL = torch.zeros((4 << 20,), device=dev)

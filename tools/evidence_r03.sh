@@ -21,6 +21,10 @@ cd $R
 python3 tools/bench_trunk.py > $O/trunk_r18.json 2>/dev/null
 python3 tools/bench_trunk.py --r50 > $O/trunk_r50.json 2>/dev/null
 python3 bench.py --deterministic --no-cpu-baseline > $O/bench_line_deterministic.json 2>/dev/null
+python3 tools/bench_step_r50.py > $O/step_config5_r50_32x224.json 2>/dev/null
+python3 tools/bench_step_r50.py --frames 8 > $O/step_config5_r50_8x224.json 2>/dev/null
+python3 tools/traffic_json.py $O/l1_FETCH_SIZE $O/l1_WRITE_SIZE $H > $O/traffic_layer1.json
+{ echo "# commit $H: BatchNorm passes alone (tools/bench_bn.py)"; python3 tools/bench_bn.py 2>/dev/null | grep -v amdgpu; } > $O/bn_passes.txt
 f=$(ls $O/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
 rm -rf $O/stats $O/pmc_*/*/*.db 2>/dev/null
 ls -la $O | head -40; echo finished
