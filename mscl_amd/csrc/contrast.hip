@@ -96,22 +96,45 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// one wave per row: merge the per-block partials
-__global__ __launch_bounds__(64) void nce_finish_kernel(const float* __restrict__ part, const float* __restrict__ pos,
-                                                        float* __restrict__ lse, float* __restrict__ loss_rows,
-                                                        int32_t* __restrict__ rank, int R, int nblk, float inv_T) {
-  const int r = blockIdx.x, lane = threadIdx.x;
+// one block per row: merge the per-block partials.  256 threads take nblk / 256 partials each with every load in flight, then
+// meet through LDS (one wave looping over 1024 partials twice was 32 dependent round trips: 8 us, three times in the loss phase)
+__global__ __launch_bounds__(256) void nce_finish_kernel(const float* __restrict__ part, const float* __restrict__ pos,
+                                                         float* __restrict__ lse, float* __restrict__ loss_rows,
+                                                         int32_t* __restrict__ rank, int R, int nblk, float inv_T) {
+  __shared__ float red[3][4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float p = pos[r] * inv_T;
-  float m = p;
-  for (int b = lane; b < nblk; b += 64) m = fmaxf(m, part[((long)b * R + r) * 3]);
-  m = wave_max(m);
-  float s = 0.f, c = 0.f;
-  for (int b = lane; b < nblk; b += 64) {
-    const float* o = part + ((long)b * R + r) * 3;
-    s += o[1] * expf(o[0] - m); c += o[2];
+  constexpr int U = 8;
+  float m = -INFINITY, s = 0.f, c = 0.f;
+  for (int b0 = tid; b0 < nblk; b0 += 256 * U) {
+    float pm[U], ps[U], pc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u * 256;
+      const float* o = part + ((long)(b < nblk ? b : b0) * R + r) * 3;
+      pm[u] = b < nblk ? o[0] : -INFINITY; ps[u] = b < nblk ? o[1] : 0.f; pc[u] = b < nblk ? o[2] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float mn = fmaxf(m, pm[u]);
+      s = (mn == -INFINITY) ? 0.f : s * expf(m - mn) + ps[u] * expf(pm[u] - mn);
+      m = mn; c += pc[u];
+    }
   }
-  s = wave_sum(s) + expf(p - m); c = wave_sum(c);
-  if (lane == 0) { const float l = m + logf(s); lse[r] = l; loss_rows[r] = l - p; rank[r] = (int32_t)(c + 0.5f); }
+  // block merge: the maximum first, then the sums rescaled to it
+  const float wm = wave_max(m);
+  if (lane == 0) red[0][wave] = wm;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])), p);
+  const float sw = wave_sum(m == -INFINITY ? 0.f : s * expf(m - M)), cw = wave_sum(c);
+  if (lane == 0) { red[1][wave] = sw; red[2][wave] = cw; }
+  __syncthreads();
+  if (tid == 0) {
+    const float S = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + expf(p - M);
+    const float C = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float l = M + logf(S);
+    lse[r] = l; loss_rows[r] = l - p; rank[r] = (int32_t)(C + 0.5f);
+  }
 }
 
 // dq[r][c] += inv_T * row_scale[r] * sum_k softmax_k * decay_k * queue[c][k]
@@ -266,7 +289,7 @@ extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float*
   if (!part || !pos_logit || !lse || !loss_rows || !rank || R <= 0 || nblk <= 0) return MSCL_E_ARG;
   for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {
     const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
-    hipLaunchKernelGGL(nce_finish_kernel, dim3(Rt), dim3(64), 0, (hipStream_t)stream, part + (size_t)nblk * r0 * 3, pos_logit + r0,
+    hipLaunchKernelGGL(nce_finish_kernel, dim3(Rt), dim3(256), 0, (hipStream_t)stream, part + (size_t)nblk * r0 * 3, pos_logit + r0,
                        lse + r0, loss_rows + r0, rank + r0, Rt, nblk, inv_T);
     MSCL_LAUNCH_CHECK();
   }

@@ -473,7 +473,7 @@ def nce_forward(queue, count, q, pos, inv_T, virt=None):
 def nce_backward(queue, count, q, lse, row_scale, inv_T, virt=None):
     """dq (R, dim) = inv_T * row_scale[r] * sum_k softmax_k * W[:, k] (negatives only)."""
     R, dim = q.shape
-    dq = torch.zeros((R, dim), dtype=torch.float32, device=q.device)
+    dq = ZEROS.take(R * dim, q.device).view(R, dim)          # (a slice of the step's pre-zeroed pool: no fill launch in the loss phase)
     Kq = queue.shape[1]
     ws = torch.empty(((Kq + 127) // 128) * ((min(R, 32) + 7) // 8 * 8) * dim, dtype=torch.float32, device=q.device)
     vk, vp = virt if virt is not None else (None, None)
@@ -525,8 +525,8 @@ def lmcl(rgb, flow, inv_T):
     """rgb (B,t,C), flow (B,2t,C) fp32 pooled features -> loss_sum[1], hits[2], drgb, dflow."""
     B, t, C = rgb.shape
     dev = rgb.device
-    loss_sum = torch.zeros((1,), dtype=torch.float32, device=dev)
-    hits = torch.zeros((2,), dtype=torch.int32, device=dev)
+    loss_sum = ZEROS.take(1, dev)
+    hits = ZEROS.take(2, dev).view(torch.int32)
     drgb, dflow = torch.empty_like(rgb), torch.empty_like(flow)
     call('mscl_lmcl', ptr(rgb), ptr(flow), ptr(loss_sum), ptr(hits), ptr(drgb), ptr(dflow), B, t, C, inv_T, stream_ptr())
     return loss_sum, hits, drgb, dflow
