@@ -228,7 +228,10 @@ MASK_FROM_Y_MIN = 1 << 24   # BN backward recomputes the ReLU mask from y on map
 
 def _wgrad(conv, x, dy):
     """(weight gradients on a side stream, off the dgrad / BatchNorm-backward chain, were measured in rounds 1 and 2: -6 ... -13 %
-    on the step -- two MFMA-heavy kernels side by side do not pay -- and removed in round 3)"""
+    on the step -- two MFMA-heavy kernels side by side do not pay -- and removed in round 3.  Round 3 re-measured the narrowest
+    form: only the layer-1 / stem weight gradients of the RGB query trunk, issued AFTER their layer's input gradient on the idle
+    key stream so that they would run beside the next BatchNorm-backward passes: 984-988 vs 1043-1048 clip-pairs/s; with layer 2 and
+    the flow trunk's as well 922-937.)"""
     conv.wgrad(x, dy)
 
 
