@@ -468,7 +468,7 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   g.ksplit = 1;
   const long out_elems = (long)g.N * g.Tr * g.Hr * g.Wr * g.Cr;
   if (ws != nullptr && blocks <= 256 && nk >= 32) {           // too few tiles for 256 CUs and a long K loop
-    // measured on the 6272- and 784-position layers (tools/sweep_ksplit.sh): one round of <= 2 blocks per CU beats more
+    // measured on the 6272- and 784-position layers (a sweep of round 2, its tuning hooks removed in round 3): one round of <= 2 blocks per CU beats more
     // splits (98 tiles x 6 = 588 blocks ran 52 us, x 4 = 392 blocks 44 us), and a block wants >= 12 K steps
     constexpr long ks_target = 448, ks_steps = 12;        // swept in round 2 (320 / 448 / 640 blocks, 8 / 12 / 18 steps): kept
     long want = (WAVES_M * WAVES_N == 8 ? ks_target * 256 / 448 : ks_target) / blocks;      // wide tiles: one 96-KB block per CU
