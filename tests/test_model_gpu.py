@@ -450,7 +450,7 @@ def test_uv_flow_and_flip_inputs(dev):
         losses[name] = out['log_vars']
     for k, v in losses['host'].items():
         if 'loss' in k:
-            loss_close(losses['uv+mask'][k], v, k)      # (+-1 colour level on <= 0.5 % of the pixels + fp32-atomic order noise)
+            loss_close(losses['uv+mask'][k], v, k, tol=6e-3)      # (+-1 colour level on <= 0.5 % of the pixels + fp32-atomic order noise, through batch-2 BatchNorm; spread seen: 0.1 .. 0.24 %)
 
 
 def test_color_aug_inputs_and_stochastic_mode(dev):
