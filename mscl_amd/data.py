@@ -261,7 +261,8 @@ class ClipPairLoader:
     def _to_device(self, slot):
         """PCIe + the GPU part; returns the data_batch.  Runs on the consumer's (current) stream."""
         dev, T = self.device, self.T
-        nb = len(slot.labels)                                        # a short last batch (drop_last=False) travels as its rows only
+        labels = list(slot.labels)                                   # read BEFORE the slot is released below: the filler may refill it at once
+        nb = len(labels)                                             # a short last batch (drop_last=False) travels as its rows only
         frames = slot.frames[:nb].to(dev, non_blocking=True)
         flow = slot.flow[:nb].to(dev, non_blocking=True)
         ints = slot.ints[:nb].to(dev, non_blocking=True)
@@ -281,7 +282,7 @@ class ClipPairLoader:
         else:                         # validation (one clip): both views see the same frames / base||rotated, two boxes
             imgs = [K.crop_resize(frames, box(0), hw), K.crop_resize(frames, box(1), hw)]
             flows = [K.crop_resize(normed, box(2), hw), K.crop_resize(normed, box(3), hw)]
-        return dict(imgs=imgs, flow_imgs=flows, label=torch.tensor(slot.labels, device=dev))
+        return dict(imgs=imgs, flow_imgs=flows, label=torch.tensor(labels, device=dev))
 
     def _retire_worker(self):
         """stop and join the filler of an epoch the consumer walked away from (break / exception mid-epoch): it may be blocked

@@ -490,7 +490,7 @@ def test_color_aug_inputs_and_stochastic_mode(dev):
         m.aug_gpu.stochastic = True
         m.aug_gpu.seed(seed)
         outs.append(m.train_step({k: [t.to(dev) for t in v] for k, v in batch.items()})['log_vars']['loss'])
-    loss_close(outs[0], outs[1], 'same seed, same draws')          # (equal up to the fp32 atomics order, amplified by batch-2 BatchNorm)
+    loss_close(outs[0], outs[1], 'same seed, same draws', tol=6e-3)          # (equal up to the fp32 atomics order, amplified by batch-2 BatchNorm; spread seen: up to 0.21 %)
     assert abs(outs[0] - outs[2]) > 1e-4
     # graph replay with a stochastic augmenter: masks and rows are static buffers refreshed per step
     opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
@@ -592,7 +592,7 @@ def test_flow_query_subgraphs_equal_eager(dev):
         assert abs(g[1].norm().item() / e1[1].norm().item() - 1) < 5e-2
         for k, v in e1[0].items():
             if 'loss' in k:
-                loss_close(g[0][k], v, k)
+                loss_close(g[0][k], v, k, tol=6e-3)      # (second step of two runs that differ in the fp32-atomic order of the first; spread seen: 0.26 %)
     assert e1[1].abs().max().item() > 0
 
 
