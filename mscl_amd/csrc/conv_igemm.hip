@@ -271,34 +271,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int split = bid % g.ksplit; bid /= g.ksplit;
-  int ci = 0;                                  // parity class of the strided input gradient (mode 2), fastest index after the split
-  if (g.nclass > 0) { ci = bid % g.nclass; bid /= g.nclass; }
   const int nt = bid % g.ntiles; bid /= g.ntiles;
   const int mt = bid;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int mode = __builtin_amdgcn_readfirstlane(g.mode);      // 0 forward, 1 stride-1 input gradient, 2 strided input gradient
-  // Mode 2 (conv_igemm_kernel has the derivation): the rows of a parity class are the cells (n, tq, hq, wq) whose outputs sit at
-  // (s tq + ro, ...); a tap of the class reads dy at cell + (dt, dh, dw) with d = (ro + p - k) >> log2(s) -- the same offset for
-  // every row, so the tap is wave-uniform here too and its offset travels in the SGPR operand.
-  int roT = 0, roH = 0, roW = 0, rsT = 1, rsH = 1, rsW = 1, TrS = g.Tr, HrS = g.Hr, WrS = g.Wr, Mc = g.M, ntl = g.ntaps;
-  FastDiv dW = g.dW, dH = g.dH, dT = g.dT;
-  unsigned csel_lo = 0, csel_hi = 0;
-  if (g.nclass > 0) {
-    ClassInfo csel = g.cls[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) if (ci == c) csel = g.cls[c];
-    roT = csel.ro[0]; roH = csel.ro[1]; roW = csel.ro[2]; rsT = g.sT; rsH = g.sH; rsW = g.sW;
-    TrS = csel.TrS; HrS = csel.HrS; WrS = csel.WrS; Mc = csel.M; ntl = csel.ntl;
-    dW = csel.dW; dH = csel.dH; dT = csel.dT;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { csel_lo |= (unsigned)csel.taps[t] << (8 * t); csel_hi |= (unsigned)csel.taps[4 + t] << (8 * t); }
-  }
-  if (m0 >= Mc) return;                       // class smaller than the grid's (max) tile count
+  const int mode = __builtin_amdgcn_readfirstlane(g.mode);      // 0 forward, 1 stride-1 input gradient
+  const int Mc = g.M;
   const int cs2 = g.Cs * 2;
   // tap offsets are kept non-negative for the SGPR operand: the descriptor base is moved back by `bias_bytes`
   const int maxlin = ((g.kT - 1) * g.Hs + (g.kH - 1)) * g.Ws + (g.kW - 1);
   const int padlin = (g.pT * g.Hs + g.pH) * g.Ws + g.pW;
-  const int bias_bytes = mode == 2 ? 0 : (mode == 0 ? padlin : maxlin) * cs2;
+  const int bias_bytes = (mode == 0 ? padlin : maxlin) * cs2;
 
   const int rg = tid & 7, rr = tid >> 3;
   const int rgl = swz<BK>(rr, rg);
@@ -308,29 +290,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
     const int m = m0 + p * RPP + rr;
     int mask = 0, base = 0;
     if (m < Mc) {
-      const int q1 = fdiv(m, dW), ws_ = m - q1 * WrS;
-      const int q2 = fdiv(q1, dH), hs_ = q1 - q2 * HrS;
-      const int n = fdiv(q2, dT), ts_ = q2 - n * TrS;
-      const int tr = ts_ * rsT + roT, hr = hs_ * rsH + roH, wr = ws_ * rsW + roW;
+      const int q1 = fdiv(m, g.dW), wr = m - q1 * g.Wr;
+      const int q2 = fdiv(q1, g.dH), hr = q1 - q2 * g.Hr;
+      const int n = fdiv(q2, g.dT), tr = q2 - n * g.Tr;
       int t0, h0, w0;
       if (mode == 0) { t0 = tr * g.sT - g.pT; h0 = hr * g.sH - g.pH; w0 = wr * g.sW - g.pW; }
       else { t0 = tr + g.pT; h0 = hr + g.pH; w0 = wr + g.pW; }
-      for (int k = 0; k < g.kT; ++k) {
-        const int d = (mode == 0) ? t0 + k : t0 - k;
-        const bool ok = (mode == 2) ? (d >= 0 && (d & (g.sT - 1)) == 0 && (d >> g.lsT) < g.Ts) : ((unsigned)d < (unsigned)g.Ts);
-        mask |= ok ? (1 << k) : 0;
-      }
-      for (int k = 0; k < g.kH; ++k) {
-        const int d = (mode == 0) ? h0 + k : h0 - k;
-        const bool ok = (mode == 2) ? (d >= 0 && (d & (g.sH - 1)) == 0 && (d >> g.lsH) < g.Hs) : ((unsigned)d < (unsigned)g.Hs);
-        mask |= ok ? (1 << (8 + k)) : 0;
-      }
-      for (int k = 0; k < g.kW; ++k) {
-        const int d = (mode == 0) ? w0 + k : w0 - k;
-        const bool ok = (mode == 2) ? (d >= 0 && (d & (g.sW - 1)) == 0 && (d >> g.lsW) < g.Ws) : ((unsigned)d < (unsigned)g.Ws);
-        mask |= ok ? (1 << (16 + k)) : 0;
-      }
-      base = (mode == 2) ? ((n * g.Ts + ts_) * g.Hs + hs_) * g.Ws + ws_ : ((n * g.Ts + t0) * g.Hs + h0) * g.Ws + w0;
+      for (int k = 0; k < g.kT; ++k) { const int d = (mode == 0) ? t0 + k : t0 - k; mask |= ((unsigned)d < (unsigned)g.Ts) ? (1 << k) : 0; }
+      for (int k = 0; k < g.kH; ++k) { const int d = (mode == 0) ? h0 + k : h0 - k; mask |= ((unsigned)d < (unsigned)g.Hs) ? (1 << (8 + k)) : 0; }
+      for (int k = 0; k < g.kW; ++k) { const int d = (mode == 0) ? w0 + k : w0 - k; mask |= ((unsigned)d < (unsigned)g.Ws) ? (1 << (16 + k)) : 0; }
+      base = ((n * g.Ts + t0) * g.Hs + h0) * g.Ws + w0;
     }
     row_voff[p] = base * cs2 + (mode == 0 ? bias_bytes : 0) + rgl * 16;      // >= 0 for every row with a valid tap
     row_mask[p] = mask;
@@ -354,21 +323,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
     for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int sub = g.cgs - 3, submask = (1 << sub) - 1;          // K steps per tap = Cs / 64
-  const int nk_all = ntl << sub;
+  const int nk_all = g.ntaps << sub;
   const int k_beg = (int)((long)nk_all * split / g.ksplit), k_end = (int)((long)nk_all * (split + 1) / g.ksplit);
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   auto issue = [&](int kt, int buf) {
-    const int tslot = kt >> sub, cpart = kt & submask;
-    // the tap behind slot `tslot` of this class's list (dense launches: the identity)
-    const int slot = g.nclass > 0 ? (int)((tslot < 4 ? (csel_lo >> (8 * tslot)) : (csel_hi >> (8 * (tslot - 4)))) & 255u) : tslot;
+    const int slot = kt >> sub, cpart = kt & submask;
     const int q = fdiv(slot, g.dKW), kw = slot - q * g.kW;
     const int kd = fdiv(q, g.dKH), kh = q - kd * g.kH;
     const int lin = (kd * g.Hs + kh) * g.Ws + kw;
-    const int lin2 = ((((roT + g.pT - kd) >> g.lsT) * g.Hs) + ((roH + g.pH - kh) >> g.lsH)) * g.Ws + ((roW + g.pW - kw) >> g.lsW);
-    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((mode == 2 ? lin2 : (mode == 0 ? lin : maxlin - lin)) * cs2 + cpart * 128));
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((mode == 0 ? lin : maxlin - lin) * cs2 + cpart * 128));
     const int tb = __builtin_amdgcn_readfirstlane((1 << kd) | (1 << (8 + kh)) | (1 << (16 + kw)));
-    const unsigned woff = __builtin_amdgcn_readfirstlane((unsigned)((slot << sub) + cpart) * 128u);
+    const unsigned woff = __builtin_amdgcn_readfirstlane((unsigned)kt * 128u);
     unsigned char* a = As + buf * A_STAGE + wave * 1024;
     unsigned char* b = Bs + buf * B_STAGE + wave * 1024;
 #pragma unroll
@@ -421,8 +387,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, dW, dH, dT, TrS, HrS, WrS, rsT, rsH, rsW,
-                                 roT, roH, roW, out, bias, addend, stat_sum, stat_sq, relu, partial);
+  igemm_epilogue<BM, BN, IM, JN>(g, acc, smem, tid, fr, fq, m0, n0, wm0, wn0, split, Mc, g.dW, g.dH, g.dT, g.Tr, g.Hr, g.Wr, 1, 1, 1,
+                                 0, 0, 0, out, bias, addend, stat_sum, stat_sq, relu, partial);
 }
 
 // split-K epilogue: out = bf16( relu?( sum of slabs + bias + addend ) ), BN statistics of the sum
@@ -515,9 +481,9 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
   float* partial = g.ksplit > 1 ? ws : nullptr;
   bool launched = false;
   if constexpr (fast_tile<BM, BN, BK, WAVES_M, WAVES_N, STAGES>()) {
-    // uniform-tap kernel: whole 64-channel K steps of one tap (parity classes included: their taps are uniform too), offsets below 2^31
+    // uniform-tap kernel: whole 64-channel K steps of one tap, no parity classes, offsets below 2^31
     const long span = ((long)g.N * g.Ts * g.Hs * g.Ws + 2L * (((long)g.kT * g.Hs + g.kH) * g.Ws + g.kW)) * g.Cs * 2;
-    if (g.cgs >= 3 && span < (1L << 31)) {
+    if (g.mode != 2 && g.cgs >= 3 && span < (1L << 31)) {
       g.dKW = make_fastdiv(g.kW); g.dKH = make_fastdiv(g.kH);
       const long nblk = blocks * g.ksplit;
       auto kern = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 2>;
@@ -597,9 +563,6 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     if (Cr > 32) {
       // strided input gradient into 64 channels: a class has 1-8 taps, i.e. 2-16 K steps of 64; half-depth steps pipeline
       // these short loops better (97 -> 84 us on the layer-2 entry conv)
-      // Round 3: every tile of either kernel runs this launch in 77-92 us (128 x 64 x 32 general 79, 128 x 64 x 64 uniform-tap 79,
-      // 256 x 64 77-84, 64 x 64 83-92): with 64 output channels a K step stages 24 KB for 0.5 M MACs = 22 MAC/B, and 11.1 GMAC at the
-      // ~6.3 TB/s of LDS-DMA fill is 81 us.  Only keeping dy resident across a cell's 27 (tap, class) uses would lift it.
       if (g.nclass > 0 && Cr <= 64) GO(128, 64, 32, 2, 2);
       if (blocks(128, 64) >= 384 || can_split) GO(128, 64, 64, 2, 2);   // 48 KB LDS: 3 blocks/CU
       GO(64, 64, 64, 2, 2);
