@@ -563,6 +563,11 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     if (Cr > 32) {
       // strided input gradient into 64 channels: a class has 1-8 taps, i.e. 2-16 K steps of 64; half-depth steps pipeline
       // these short loops better (97 -> 84 us on the layer-2 entry conv)
+      // Round 3: every tile of either kernel runs this launch in 77-92 us (128 x 64 x 32 general 79, 128 x 64 x 64 uniform-tap 79,
+      // 256 x 64 77-84, 64 x 64 83-92): with 64 output channels a K step stages 24 KB for 0.5 M MACs = 22 MAC/B, and 11.1 GMAC at the
+      // ~6.3 TB/s of LDS-DMA fill is 81 us.  Only keeping dy resident across a cell's 27 (tap, class) uses would lift it.  (The
+      // uniform-tap kernel with parity classes was built: 42 -> 38 us and 37 -> 36 us on the 128- / 256-channel strided layers, but
+      // the class logic cost its dense uses more inside the step: 1013-1017 vs 1021-1023 clip-pairs/s.  Not kept.)
       if (g.nclass > 0 && Cr <= 64) GO(128, 64, 32, 2, 2);
       if (blocks(128, 64) >= 384 || can_split) GO(128, 64, 64, 2, 2);   // 48 KB LDS: 3 blocks/CU
       GO(64, 64, 64, 2, 2);
