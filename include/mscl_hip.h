@@ -56,10 +56,16 @@ int64_t mscl_debug_pp_launches(void);
 /* the same for the persistent window-resident 64 -> 64 kernel (conv_win64.hip) */
 int64_t mscl_debug_win64_launches(void);
 /* the same for the window-resident 1x3x3 kernel of the 16- / 32-channel maps (conv_thin.hip) */
+/* the same for the window-resident layer-1 kernels: forward / input gradient (conv_halo.hip), weight gradient (conv_wgrad_halo.hip) */
+int64_t mscl_debug_halo_launches(void);
+int64_t mscl_debug_wgrad_halo_launches(void);
 int64_t mscl_debug_thin_launches(void);
 int64_t mscl_debug_thin_wgrad_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);
+/* The library's tuning switches (MSCL_* environment variables) are read once and cached; after this call every
+ * switch re-reads its variable at its next use (tests and A/B sweeps that flip a switch inside one process). */
+int mscl_tuning_reload(void);
 /* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order and stored
  * into slot 0 of ssum / ssq ([group][slot][2][C], ssq = ssum + C; the other slots must hold zeros and do so afterwards).
  * Two levels: per-block partials over contiguous row shares, then one add per channel in partial order; the number of partials

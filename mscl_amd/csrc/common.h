@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mscl_hip.h"
 
 typedef uint16_t bf16_t;
@@ -122,6 +123,23 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((uint64_t)
 // Deterministic mode (mscl_set_deterministic, include/mscl_hip.h): every fp32 sum whose order the hardware would otherwise pick
 // (float atomics between blocks) is taken in a fixed order instead, so two runs on the same inputs are bit-identical.
 static inline bool mscl_det() { return g_mscl_deterministic != 0; }
+
+// Tuning switches (MSCL_* environment variables, listed in INTEGRATION.md) are read ONCE and cached: getenv per launch costs the
+// host-bound eager step, and a captured graph bakes in whatever was read at capture time anyway.  mscl_tuning_reload() (C ABI)
+// makes every switch re-read its variable at its next use: tests and A/B sweeps that flip a switch inside one process call it.
+extern int g_mscl_tune_gen;
+struct MsclTune {
+  const char* name; int gen; bool set; int val; char c0;
+  explicit MsclTune(const char* n) : name(n), gen(-1), set(false), val(0), c0(0) {}
+  bool read() {
+    if (gen != g_mscl_tune_gen) {
+      const char* e = getenv(name);
+      set = e != nullptr; val = e ? atoi(e) : 0; c0 = e ? e[0] : 0; gen = g_mscl_tune_gen;
+    }
+    return set;
+  }
+  int get(int dflt) { return read() ? val : dflt; }
+};
 
 #define MSCL_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 static inline int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }

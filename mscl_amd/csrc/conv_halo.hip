@@ -371,6 +371,9 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
 // the time, slower inside the three-stream step, 785-793 vs 804-808 clip-pairs/s, and was removed in round 3.  Its successor is
 // conv_win64.hip, which shows the same pattern: 101 vs 107 us alone, 970 vs 1007 clip-pairs/s in the step.)
 
+static long g_halo_launches = 0;
+extern "C" int64_t mscl_debug_halo_launches(void) { return g_halo_launches; }      // tests: which kernel family took a launch
+
 // returns 1 if launched, 0 if the shape is not covered (caller falls back to the implicit-GEMM kernel), <0 / >0 on error
 static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                        const uint16_t* addend, float* ssum, float* ssq, HaloBn bn, int stat_stride, void* stream);
@@ -389,9 +392,9 @@ extern "C" int mscl_conv_halo64_dgrad_bn(const mscl_conv_desc* d, const uint16_t
                                          const uint16_t* addend, const uint16_t* bn_y, const uint16_t* bn_mask,
                                          const float* bn_mean, const float* bn_invstd, float* scratch, void* stream) {
   if (!bn_y || !bn_mask || !bn_mean || !bn_invstd || !scratch) return MSCL_E_ARG;
-  const char* e = getenv("MSCL_HALO");
-  if (e && e[0] == '0') return 0;
-  if (!(e && e[0] == '1') && d && (long)d->H * (d->W + 2) < 1024) return 0;          // as halo_enabled() in conv_igemm.hip
+  static MsclTune t("MSCL_HALO");
+  if (t.read() && t.c0 == '0') return 0;
+  if (!(t.read() && t.c0 == '1') && d && (long)d->H * (d->W + 2) < 1024) return 0;          // as halo_enabled() in conv_igemm.hip
   return halo_launch(d, 1, dy, wT, dz, addend, scratch, scratch + HC, HaloBn{bn_y, bn_mask, bn_mean, bn_invstd}, 4 * HC, stream);
 }
 
@@ -419,5 +422,6 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
   hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, (hipStream_t)stream, g, src, w,
                      out, addend, ssum, ssq, bn);
   MSCL_LAUNCH_CHECK();
+  ++g_halo_launches;
   return 1;
 }

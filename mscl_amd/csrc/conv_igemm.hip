@@ -533,8 +533,8 @@ static int launch_igemm(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   // channels a multiple of 128.  MSCL_PP: 0 = off, 1 (default) = layers of >= 400 k outputs (784 positions x 512 channels and up:
   // measured faster on every such shape of the step; the 784 x 128 pyramid level is not), 2 = wherever it applies.
   {
-    const char* e_pp = getenv("MSCL_PP");                    // read per launch: tests and A/B sweeps flip it inside one process
-    const int pp_level = e_pp ? atoi(e_pp) : 1;
+    static MsclTune t_pp("MSCL_PP");
+    const int pp_level = t_pp.get(1);
     if (pp_level > 0 && (pp_level >= 2 || (long)rowsM * Cr >= 400000L)) {
       const int r = mscl_launch_conv_pp(g, src, wgt, out, bias, addend, ssum, ssq, relu, ws, ws_floats, st);
       if (r != MSCL_PP_SKIP) return r;
@@ -602,17 +602,17 @@ extern "C" int mscl_conv_win64(const mscl_conv_desc* d, int mode, const uint16_t
                                const uint16_t* addend, float* ssum, float* ssq, void* stream);
 // persistent window-resident ping-pong kernel for 64 -> 64 (conv_win64.hip); MSCL_WIN64=0 falls back to conv_halo.hip
 static bool win64_enabled(const mscl_conv_desc* d) {
-  const char* e = getenv("MSCL_WIN64");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '2') return true;                        // forced (tests: small planes too)
-  return (e && e[0] == '1') && (long)d->H * (d->W + 2) >= 1024;
+  static MsclTune t("MSCL_WIN64");
+  if (!t.read() || t.c0 == '0') return false;
+  if (t.c0 == '2') return true;                             // forced (tests: small planes too)
+  return t.c0 == '1' && (long)d->H * (d->W + 2) >= 1024;
 }
 // layer-1 shape (3x3x3 s1 p1, 64 -> 64): halo-resident kernel, 131 / 109 us vs 156 / 135 us (fwd / dgrad) for the
 // implicit-GEMM kernel; MSCL_HALO=0 switches it off
 static bool halo_enabled(const mscl_conv_desc* d) {
-  const char* e = getenv("MSCL_HALO");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '1') return true;                        // forced (tests: small planes too)
+  static MsclTune t("MSCL_HALO");
+  if (t.read() && t.c0 == '0') return false;
+  if (t.read() && t.c0 == '1') return true;                 // forced (tests: small planes too)
   return (long)d->H * (d->W + 2) >= 1024;                   // 256-position tiles: planes of a few hundred positions waste them
 }
 
@@ -793,5 +793,7 @@ extern "C" int mscl_weight_transpose_batched(const void* table, int n, int total
 extern "C" int mscl_abi_version(void) { return 1; }
 
 int g_mscl_deterministic = 0;
+int g_mscl_tune_gen = 0;
+extern "C" int mscl_tuning_reload(void) { ++g_mscl_tune_gen; return 0; }
 extern "C" int mscl_set_deterministic(int on) { g_mscl_deterministic = on ? 1 : 0; return 0; }
 extern "C" int mscl_get_deterministic(void) { return g_mscl_deterministic; }

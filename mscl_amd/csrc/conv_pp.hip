@@ -301,18 +301,19 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     if (want * out_elems > ws_floats) want = ws_floats / out_elems;
     if (want > 1) g.ksplit = (int)want;
   }
-  if (const char* f = getenv("MSCL_PP_KSPLIT")) {        // tuning aid
-    const long want = atol(f);
+  static MsclTune t_ks("MSCL_PP_KSPLIT");               // tuning aid
+  if (t_ks.read()) {
+    const long want = t_ks.val;
     if (want >= 1 && want <= ng && (want == 1 || (ws != nullptr && want * out_elems <= ws_floats && g.Cr <= 512))) g.ksplit = (int)want;
   }
   float* partial = g.ksplit > 1 ? ws : nullptr;
   const size_t lds = 4 * (size_t)BN * 128 + 2 * 256 * 128;
   const bool n64 = BN == 64;
+  static bool attr_done[2] = {false, false};    // per kernel (both instantiations have the same function type: ONE lambda body)
   auto go = [&](auto kern) {
-    static bool attr_done = false;              // (one static per instantiation of this lambda = per kernel)
-    if (!attr_done) {
+    if (!attr_done[n64]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done = true;
+      attr_done[n64] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(512), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu,
                        partial);

@@ -165,7 +165,7 @@ int mscl_conv_thin(int planes, int H, int W, int C, int K, int flip, const bf16_
                    const bf16_t* addend, int relu, float* ssum, float* ssq, int stat_groups, hipStream_t st) {
   if (!((C == 16 || C == 32) && (K == 16 || K == 32))) return 0;
   if (H < 4 || W < 4 || W > 254 || planes < 1 || stat_groups < 1 || planes % stat_groups) return 0;
-  if (const char* e = getenv("MSCL_THIN")) if (atoi(e) == 0) return 0;
+  { static MsclTune t("MSCL_THIN"); if (t.read() && t.val == 0) return 0; }
   ThinGeom g;
   g.planes = planes; g.H = H; g.W = W;
   g.RB = (H % 8 == 0) ? 8 : (H % 7 == 0) ? 7 : 8;
@@ -342,7 +342,7 @@ static bool thin_wgrad_geom(const mscl_conv_desc* d, ThinWGeom& g) {
   if (!(d->kT == 1 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 1 && d->pW == 1)) return false;
   if (!((d->C == 16 || d->C == 32) && (d->K == 16 || d->K == 32))) return false;
   if (d->H < 4 || d->W < 4 || d->W > 254) return false;
-  if (const char* e = getenv("MSCL_THIN")) if (atoi(e) == 0) return false;
+  { static MsclTune t("MSCL_THIN"); if (t.read() && t.val == 0) return false; }
   g.planes = d->N * d->T; g.H = d->H; g.W = d->W;
   g.RB = (d->H % 8 == 0) ? 8 : (d->H % 7 == 0) ? 7 : 8;
   g.bands = (d->H + g.RB - 1) / g.RB;

@@ -397,8 +397,8 @@ int mscl_wgrad_thin(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* 
 // applies.  Opt-in: alone it ties the 128 x 128 kernel below on layer 2 (82.5 vs 81.0 us) and loses on the small maps (layer 4: 56 vs
 // 40 us); inside the step 1010 / 1000 vs 1033 clip-pairs/s (levels 1 / 2 vs 0) -- see the header of conv_wgrad_pp.hip for why.
 static bool wgrad_pp_enabled(const mscl_conv_desc* d) {
-  const char* e = getenv("MSCL_WGRAD_PP");
-  const int level = e ? atoi(e) : 0;
+  static MsclTune t("MSCL_WGRAD_PP");
+  const int level = t.get(0);
   if (level <= 0) return false;
   return level >= 2 || (long)d->N * d->To * d->Ho * d->Wo >= 16384;
 }

@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float* _
   atomicAdd(&dw[(co * 27 + kt * 9 + t9) * 64 + ci], s);
 }
 
+static long g_wgrad_halo_launches = 0;
+extern "C" int64_t mscl_debug_wgrad_halo_launches(void) { return g_wgrad_halo_launches; }
+
 // returns 1 if launched, 0 if the shape / workspace is not covered, <0 / >0 on error
 int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                       hipStream_t st) {
@@ -269,5 +272,6 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   MSCL_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((27 * 4096 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, gk);
   MSCL_LAUNCH_CHECK();
+  ++g_wgrad_halo_launches;
   return 1;
 }

@@ -37,6 +37,8 @@ import torch
 from . import kernels as K
 from .lib import MsclError
 
+_RETIRED = object()          # what a stopped filler leaves in its queue (ClipLoader.__iter__)
+
 
 # ----------------------------------------------------------------------------------------------- plain-file store
 class ClipStore:
@@ -284,27 +286,33 @@ class ClipPairLoader:
             flows = [K.crop_resize(normed, box(2), hw), K.crop_resize(normed, box(3), hw)]
         return dict(imgs=imgs, flow_imgs=flows, label=torch.tensor(labels, device=dev))
 
-    def _retire_worker(self):
+    def _retire_worker(self, st=None):
         """stop and join the filler of an epoch the consumer walked away from (break / exception mid-epoch): it may be blocked
-        in q.put or on a slot, and it shares the slots and the random streams with the next epoch's filler"""
-        st = getattr(self, '_active', None)
+        in q.put or on a slot, and it shares the slots and the random streams with the next epoch's filler.
+        st = the (stop, thread, queue) of ONE epoch: a generator retires its own filler only -- an old epoch's generator that is
+        finalised late (kept alive by a traceback or a dropped `iter(loader)` handle) finds its filler already joined by the next
+        `__iter__` and must touch neither the slots nor the filler of the epoch that is running now."""
+        mine = st is not None
+        st = st if mine else getattr(self, '_active', None)
         if st is None:
             return
         stop, th, q = st
         stop.set()
-        for slot in self._slots:
-            slot.free.set()                                          # wake a filler waiting for a slot
-        while th.is_alive():
-            try:
-                q.get_nowait()                                       # make room for a filler blocked in q.put
-            except queue.Empty:
-                pass
-            th.join(timeout=0.01)
-        for slot in self._slots:                                     # uploads already queued must finish before a slot is refilled
-            if slot.event is not None:
-                slot.event.synchronize()
-            slot.free.set()
-        self._active = None
+        if th.is_alive():
+            for slot in self._slots:
+                slot.free.set()                                      # wake a filler waiting for a slot
+            while th.is_alive():
+                try:
+                    q.get_nowait()                                   # make room for a filler blocked in q.put
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.01)
+            for slot in self._slots:                                 # uploads already queued must finish before a slot is refilled
+                if slot.event is not None:
+                    slot.event.synchronize()
+                slot.free.set()
+        if getattr(self, '_active', None) is st:
+            self._active = None
 
     def __iter__(self):
         self._retire_worker()
@@ -316,32 +324,41 @@ class ClipPairLoader:
         q = queue.Queue(maxsize=max(1, len(self._slots) - 1))
         stop = threading.Event()
 
+        def retired():
+            # a stopped filler still leaves a word for whoever may be waiting on ITS queue: a consumer never blocks for ever
+            try:
+                q.put_nowait(_RETIRED)
+            except queue.Full:
+                pass
+
         def worker():
             try:
                 for i, ids in enumerate(batches):
                     slot = self._slots[i % len(self._slots)]
                     slot.free.wait()                                 # the consumer has queued this slot's previous upload ...
                     if stop.is_set():
-                        return
+                        return retired()
                     slot.free.clear()
                     if slot.event is not None:
                         slot.event.synchronize()                     # ... and the copy engine has finished reading it
                     q.put(self._fill(slot, ids))
                     if stop.is_set():
-                        return
+                        return retired()
                 q.put(None)
             except BaseException as e:      # noqa: BLE001 -- surfaced in the consumer
                 q.put(e)
         th = threading.Thread(target=worker, daemon=True)
-        self._active = (stop, th, q)
+        mine = self._active = (stop, th, q)
         th.start()
         try:
             while True:
                 item = q.get()
                 if item is None:
                     break
+                if item is _RETIRED:
+                    raise MsclError('this epoch of the loader was retired (a newer iter(loader) took over its slots)')
                 if isinstance(item, BaseException):
                     raise item
                 yield self._to_device(item)
         finally:
-            self._retire_worker()           # normal end: the filler has returned; abandoned epoch (GeneratorExit): stop it
+            self._retire_worker(mine)       # normal end: the filler has returned; abandoned epoch (GeneratorExit): stop THIS epoch's filler

@@ -12,7 +12,8 @@ from . import parallel
 
 
 class GraphedStep:
-    def __init__(self, model, optimizer, example_batch, warmup=2):
+    def __init__(self, model, optimizer, example_batch, warmup=2, indirect=None):
+        """indirect: None = inputs by address wherever the step allows it (below), False = always through the static buffers"""
         self.model, self.opt = model, optimizer
         model.shuffle_mode = 'gather'            # all-to-all split sizes change per step and cannot be baked into a graph
         dev = model.arena.device
@@ -41,7 +42,7 @@ class GraphedStep:
         # a 116-MB copy into static buffers (~55 us of the step at B = 8, T = 16).  Everything else keeps the static copies.
         self.indirect = None
         ins = [self.static[model.im_key][0], self.static[model.im_key][1], self.static[fk][0], self.static[fk][1]]
-        plain = (parallel.single() and not getattr(model.aug_gpu, 'stochastic', False) and 'flip_mask' not in self.static
+        plain = (indirect is not False and parallel.single() and not getattr(model.aug_gpu, 'stochastic', False) and 'flip_mask' not in self.static
                  and all(t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == 3 for t in ins))
         if plain:
             from .kernels import IndirectInput
@@ -92,6 +93,11 @@ class GraphedStep:
                 self._ptr_cpu[i] = t.data_ptr()
             self._ptr_ring.push(self._ptr_cpu)
             self._live = (self._live[-2:] if hasattr(self, '_live') else []) + [srcs]      # the clips of the last replays stay referenced
+            for k, v in self.static.items():        # whatever else the batch carries still travels through its static buffer
+                if k != m.im_key and k not in m.flow_key and k in batch:
+                    for dst, src in zip(v, batch[k]):
+                        if torch.is_tensor(dst) and dst.data_ptr() != src.data_ptr():
+                            dst.copy_(src, non_blocking=True)
         else:
             if self.indirect:                       # a batch in another form: through the static buffers, addressed by the same words
                 for i, (k, j) in enumerate(((m.im_key, 0), (m.im_key, 1), (m.flow_key[0], 0), (m.flow_key[0], 1))):

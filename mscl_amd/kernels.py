@@ -122,15 +122,19 @@ def conv_halo64_dgrad_bn(dy, wT, d, bn_y, bn_mask, bn_mean, bn_invstd, scratch, 
     raise lib.MsclError(f'mscl_conv_halo64_dgrad_bn -> {h}')
 
 
-def conv3d_wgrad(x, dy, d, dw, dbias=None):
-    """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated)."""
-    ws = None
+def wgrad_ws_floats(d, with_bias):
+    """floats of fp32 scratch the weight gradient of this layer wants (a function of the descriptor and of the library's mode:
+    callers on the hot path cache it per (module, shape, lib.DET_GEN))"""
     if (d.C, d.K, d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW) == (64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1):
-        ws = torch.empty((WGRAD_HALO_WS,), dtype=torch.float32, device=x.device)
-    else:                              # slabs of the shared-tap kernel, or deterministic mode's per-split slabs (+ bias partials)
-        n = lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(dbias is not None))
-        if n > 0:
-            ws = torch.empty((n,), dtype=torch.float32, device=x.device)
+        return max(WGRAD_HALO_WS, lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(with_bias)))
+    # slabs of the shared-tap / window-resident kernels, or deterministic mode's per-split slabs (+ bias partials)
+    return lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(with_bias))
+
+
+def conv3d_wgrad(x, dy, d, dw, dbias=None, ws_floats=None):
+    """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated)."""
+    n = wgrad_ws_floats(d, dbias is not None) if ws_floats is None else ws_floats
+    ws = torch.empty((n,), dtype=torch.float32, device=x.device) if n > 0 else None
     e0 = prof_begin()
     call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
          ws.numel() if ws is not None else 0, stream_ptr())

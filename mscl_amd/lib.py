@@ -35,8 +35,11 @@ _SIGS = {
     'mscl_debug_pp_launches': [],
     'mscl_debug_win64_launches': [],
     'mscl_debug_thin_launches': [],
+    'mscl_debug_halo_launches': [],
+    'mscl_debug_wgrad_halo_launches': [],
     'mscl_debug_thin_wgrad_launches': [],
     'mscl_get_deterministic': [],
+    'mscl_tuning_reload': [],
     'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P, c_int64, P],
     'mscl_det_parts_floats': [c_int64, c_int, c_int, c_int],
     'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],
@@ -95,7 +98,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_wgrad_pp_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches', 'mscl_debug_wgrad_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
+_INT64_RESULT = ('mscl_debug_halo_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_wgrad_pp_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches', 'mscl_debug_wgrad_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
 EXPORTS = tuple(_SIGS)
 
 _lib = None
@@ -167,11 +170,24 @@ def call(name, *args):
 def set_deterministic(on=True):
     """the reference's `--deterministic` (tools/train.py:55-57,149): fixed-order sums in place of float atomics (include/mscl_hip.h,
     mscl_set_deterministic); two runs on the same inputs are then bit-identical.  Process-wide, set before the first step."""
-    global DET
+    global DET, DET_GEN
     call('mscl_set_deterministic', int(bool(on)))
     DET = bool(on)
+    DET_GEN += 1              # cached per-(module, shape) plans hold mode-dependent scratch sizes: they key on this
 
 
+def tune(**switches):
+    """set (value) or clear (None) MSCL_* tuning switches of the library for this process and make it re-read them: the
+    library caches its environment switches (csrc/common.h, MsclTune), so os.environ alone is not seen after the first launch"""
+    for k, v in switches.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    call('mscl_tuning_reload')
+
+
+DET_GEN = 0
 DET = False              # mirror of the library's flag for the per-launch Python paths (scratch sizing)
 
 

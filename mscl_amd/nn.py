@@ -70,15 +70,43 @@ class Conv3dHip(nn.Module):
             raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
         return K.conv3d_fwd(x, rt['w'], self.desc(x.shape), bias=rt['bias'], addend=addend, relu=relu, stats=stats)
 
+    def wT(self):
+        """the transposed bf16 kernel the input-gradient kernels read, refreshed first if an optimizer step has left it behind the
+        masters (TransposeState: the refresh is deferred off the step's serial tail, so EVERY reader comes through here)"""
+        st = self._rt.get('wt_state')
+        if st is not None and st.stale:
+            st.refresh()
+        return self._rt['wT']
+
     def dgrad(self, dy, x_shape, addend=None):
-        return K.conv3d_dgrad(dy, self._rt['wT'], self.desc(x_shape), addend=addend)
+        return K.conv3d_dgrad(dy, self.wT(), self.desc(x_shape), addend=addend)
 
     def wgrad(self, x, dy):
         rt = self._rt
-        K.conv3d_wgrad(x, dy, self.desc(x.shape), rt['dw'], rt['dbias'])
+        d = self.desc(x.shape)
+        key = ('w', tuple(x.shape), lib.DET_GEN)
+        n = self._plans.get(key)
+        if n is None:             # (one ctypes query per (shape, mode) instead of per launch: the eager step is host-bound)
+            n = self._plans[key] = K.wgrad_ws_floats(d, rt['dbias'] is not None)
+        K.conv3d_wgrad(x, dy, d, rt['dw'], rt['dbias'], ws_floats=n)
         rt['slot_w'].touched = True
         if rt['slot_b'] is not None:
             rt['slot_b'].touched = True
+
+
+class TransposeState:
+    """The transposed kernels [Cin][taps][Cout] of a model's convs (one batched launch refreshes all of them) and whether they lag
+    the masters.  An optimizer step marks them stale instead of refreshing in its serial tail; the step refreshes them at its
+    head on a side stream (recognizers.MSCLWithAug._device_step), and any OTHER backward entry -- encode_q + backward, a
+    trunk-only loop, a custom step function -- refreshes them lazily at its first input gradient (Conv3dHip.wT), on the stream
+    that gradient runs on."""
+
+    def __init__(self, table):
+        self.table, self.stale = table, False
+
+    def refresh(self):
+        K.weight_transpose_batched(*self.table)
+        self.stale = False
 
 
 class BatchNorm3dHip(nn.Module):
@@ -118,10 +146,11 @@ def cba_fwd(conv, bn, x, residual, relu):
     if rt is None:
         raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
     shape = tuple(x.shape)
-    plan = conv._plans.get(shape)
+    pkey = (shape, lib.DET_GEN)        # (the scratch size below depends on the library's deterministic mode)
+    plan = conv._plans.get(pkey)
     if plan is None:
         d = conv.desc(shape)
-        plan = conv._plans[shape] = (d, ctypes.byref(d), K.out_shape(d), K.fwd_ws_floats(d, 2 if d.N % 2 == 0 else 1),
+        plan = conv._plans[pkey] = (d, ctypes.byref(d), K.out_shape(d), K.fwd_ws_floats(d, 2 if d.N % 2 == 0 else 1),
                                      (d.N, d.T, d.H, d.W, d.C, d.K, d.kT))
     d, dref, oshape, ws_n, sig = plan
     C = conv.out_channels
@@ -213,7 +242,7 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
         if next_bn is not None and FUSE_BN_REDUCE and G == 1 and conv.halo_shape and conv._rt.get('wT') is not None:
             ny, nout, nsave = next_bn
             nscr = K.ZEROS.take(K.STAT_SLOTS * 4 * conv.in_channels, dout.device)
-            dx = K.conv_halo64_dgrad_bn(dy, conv._rt['wT'], conv.desc(x.shape), ny, nout, nsave[0], nsave[1], nscr, addend=dx_addend)
+            dx = K.conv_halo64_dgrad_bn(dy, conv.wT(), conv.desc(x.shape), ny, nout, nsave[0], nsave[1], nscr, addend=dx_addend)
             if dx is not None:
                 PRE_REDUCED[dx.data_ptr()] = (nscr, dx)      # the reference keeps the address from being reused while registered
         if dx is None:

@@ -617,7 +617,7 @@ class MSCLWithAug(nn.Module):
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
         self.stream_probing = True     # side streams chosen by the overlap probe (streams.py); False: the first ones created
         self.defer_transpose = True
-        self._wt_stale = False
+        self._wt = None
         self.loss_fork = True          # RGB-queue InfoNCE pass beside the flow-queue passes
         # ... and (attribute, off) the post-enqueue flow-queue pass on a "virtual" snapshot beside the pre-enqueue one:
         # exact (test_nce_virtual_enqueue_equals_real_enqueue) but no faster -- 957.8 vs 957.6 clip-pairs/s over five alternating pairs
@@ -700,6 +700,12 @@ class MSCLWithAug(nn.Module):
                     if isinstance(m, Conv3dHip) and m._rt.get('wT') is not None:
                         entries.append((m._rt['w'], m._rt['wT'], m.out_channels, m.taps, m.in_channels))
         self._tr_table = K.build_transpose_table(entries, device)
+        self._wt = nn_hip.TransposeState(self._tr_table)
+        for rec in (self.recognizer, self.recognizer_flow):
+            for top in rec.q_modules():
+                for m in top.modules():
+                    if isinstance(m, Conv3dHip) and m._rt.get('wT') is not None:
+                        m._rt['wt_state'] = self._wt      # every reader of a transposed kernel checks it (Conv3dHip.wT)
         # gradient all-reduce buckets (contiguous arena ranges, in backward-completion order) and their triggers
         def span(mods):
             slots = [p._mscl_slot for m in mods for p in m.parameters()]
@@ -739,8 +745,7 @@ class MSCLWithAug(nn.Module):
         for rec in (self.recognizer, self.recognizer_flow):
             for fn in rec._q_refresh + rec._k_refresh:
                 fn()
-        K.weight_transpose_batched(*self._tr_table)
-        self._wt_stale = False
+        self._wt.refresh()
 
     @torch.no_grad()
     def refresh_after_optimizer(self):
@@ -751,10 +756,12 @@ class MSCLWithAug(nn.Module):
         # refresh (one 45-us launch over every conv weight) leaves the serial tail of the step and runs at the head of the next
         # one on the flow stream, beside the forward (_device_step): 1033 vs 1026 clip-pairs/s.  (The same for the gradient clear --
         # on the key stream from the start of the loss phase on -- lost: 1016-1023 vs 1032-1035; it competes with the queue passes.)
+        # Any backward that does not come through _device_step (encode_q + backward, a custom step function) refreshes them
+        # lazily at its first input gradient (nn.TransposeState / Conv3dHip.wT).
         if self.defer_transpose:
-            self._wt_stale = True
+            self._wt.stale = True
         else:
-            K.weight_transpose_batched(*self._tr_table)
+            self._wt.refresh()
 
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:
@@ -1010,10 +1017,9 @@ class MSCLWithAug(nn.Module):
         side_k = self._side_stream(1) if side is not main else main   # RGB key chain on its own stream (on the flow stream: -7 %)
         if side_k is not main:
             side_k.wait_stream(main)
-        if self._wt_stale or torch.cuda.is_current_stream_capturing():      # (a captured step always carries the refresh)
+        if self._wt.stale or torch.cuda.is_current_stream_capturing():      # (a captured step always carries the refresh)
             with torch.cuda.stream(s_fq):
-                K.weight_transpose_batched(*self._tr_table)                 # deferred by refresh_after_optimizer; joined before the loss
-            self._wt_stale = False
+                self._wt.refresh()                                          # deferred by refresh_after_optimizer; joined before the loss
         if dp:
             # Issued from a stream of their own, never from one that later captures a sub-graph: a collective whose
             # completion the process group's watchdog has not yet polled, issued from stream S, made the watchdog's

@@ -24,3 +24,15 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment(request):
+    """The library caches its MSCL_* tuning switches (csrc/common.h, MsclTune).  A GPU test that flips one with
+    monkeypatch.setenv calls lib.tune() itself; this autouse fixture is torn down AFTER monkeypatch has restored the
+    environment and makes the library read it again, so a forced kernel path never leaks into the next test."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from mscl_amd import lib
+        if lib._lib is not None:
+            lib.tune()

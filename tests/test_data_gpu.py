@@ -165,3 +165,45 @@ def test_loader_abandoned_epoch_and_short_last_batch(dev, tmp_path):
     assert tuple(last['imgs'][0].shape) == (1, 3, T, 32, 32) and tuple(last['flow_imgs'][1].shape) == (1, 2, 2 * T, 32, 32)
     assert last['label'].tolist() == [vids[6]['label']]
     assert loader._active is None
+
+
+def test_loader_old_epoch_finalised_after_a_new_one_started(dev, tmp_path):
+    """(round-3 advisor) an old epoch's generator that is kept alive (an `it = iter(loader)` handle, a traceback) and finalised only
+    AFTER a newer epoch has started must retire its own -- already joined -- filler and nothing else: the running epoch still
+    yields every batch, and a consumer of the retired epoch gets an error instead of waiting for ever."""
+    import pytest as _pt
+    from mscl_amd import Config
+    from mscl_amd.data import ClipPairLoader, MSCLPipeline
+    from mscl_amd.lib import MsclError
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    T, B, hw, fhw = 4, 2, (40, 52), (20, 26)
+    store, vids = _make_store(str(tmp_path / 'store'), 8, 120, hw, fhw, seed=4)
+    steps = [dict(s) for s in cfg.train_pipeline]
+    for s in steps:
+        if s['type'] == 'TemporalShiftChosenSampleFrames':
+            s.update(clip_len=T, frame_interval=2)
+        if s['type'] == 'MoCoResize':
+            s.update(scale=(32, 32))
+    pipe = MSCLPipeline.from_cfg(steps)
+    loader = ClipPairLoader(store, pipe, B, dev, seed=3, shuffle=False, slots=2)
+    old = iter(loader)
+    next(old)                                   # epoch 1 is mid-flight and its handle stays alive
+    new = iter(loader)
+    first = next(new)                           # epoch 2 starts: it joins epoch 1's filler
+    running = loader._active
+    assert running is not None
+    old.close()                                 # late finalisation of epoch 1: must not stop epoch 2's filler
+    assert loader._active is running and not running[0].is_set()
+    rest = list(new)
+    assert len(rest) == len(loader) - 1 and len(first['label']) == B
+    assert loader._active is None
+    # a consumer still holding a retired epoch gets an error, not a hang
+    old2 = iter(loader)
+    next(old2)
+    it3 = iter(loader)
+    next(it3)
+    with _pt.raises((MsclError, StopIteration)):
+        for _ in range(len(loader) + 1):
+            next(old2)
+    it3.close()

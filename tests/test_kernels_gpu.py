@@ -118,6 +118,9 @@ def test_conv_fwd_dgrad_wgrad(case, dev):
 # tile, the ping-pong shared-tap kernel, conv_wgrad_kernel<128,128,2>, the parity-class input gradient at full depth): the small
 # CONV_CASES never reach them.  CPU fp32 F.conv3d is the reference (a few seconds each on the box's host cores).
 REAL_CASES = [
+    # the layer that carries 46 % of the step's FLOPs, at its real map: the DEFAULT window-resident kernels (conv_halo64_kernel
+    # forward / input gradient, wgrad_halo64_kernel), asserted by their launch counters below
+    ('real_l1_64_64', 8, 16, 56, 56, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # r3d.py:16-34 layer1 convs
     ('real_l2_128_128', 8, 8, 28, 28, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # r3d.py:16-34 layer2 convs, sepc.py Pconv level 0
     ('real_l2_entry_64_128_s2', 8, 16, 56, 56, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     ('real_l3_256_256', 8, 4, 14, 14, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
@@ -128,7 +131,14 @@ REAL_CASES = [
 
 @pytest.mark.parametrize('case', REAL_CASES, ids=[c[0] for c in REAL_CASES])
 def test_conv_real_layer_shapes(case, dev):
+    from mscl_amd import lib
+    n_halo, n_wh = lib.call_raw('mscl_debug_halo_launches'), lib.call_raw('mscl_debug_wgrad_halo_launches')
     test_conv_fwd_dgrad_wgrad(case, dev)
+    if case[0] == 'real_l1_64_64':
+        # the forward with statistics, 2 input gradients (plain / + addend), 2 weight gradients (the forward with bias + ReLU is the
+        # implicit-GEMM family's: the window-resident kernel has no such epilogue)
+        assert lib.call_raw('mscl_debug_halo_launches') == n_halo + 3, 'layer 1 did not take the window-resident conv kernel'
+        assert lib.call_raw('mscl_debug_wgrad_halo_launches') == n_wh + 2, 'layer 1 did not take the window-resident weight gradient'
 
 
 # conv_pp.hip (ping-pong, shared W taps) forced onto small shapes: row tails, a map smaller than one tile, split-K over the
@@ -158,6 +168,7 @@ def test_conv_pp_forced(case, dev, monkeypatch):
     monkeypatch.setenv('MSCL_HALO', '0')          # (the window-resident layer-1 kernel would take the 64 -> 64 cases first)
     if ksplit:
         monkeypatch.setenv('MSCL_PP_KSPLIT', str(ksplit))
+    lib.tune()                                    # the library caches its switches: re-read (conftest re-reads after the test)
     x = bf(rnd((N, T, H, W, C), 11)); w = bf(rnd((K, *kern, C), 12, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
     xg, wg = x.to(dev), w.to(dev)
@@ -200,6 +211,7 @@ def test_conv_wgrad_pp_forced(case, dev, monkeypatch):
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K, kern, stride, pad, _ = case
     monkeypatch.setenv('MSCL_WGRAD_PP', '2')
+    lib.tune()
     x = bf(rnd((N, T, H, W, C), 31)); w = rnd((K, *kern, C), 32)
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
     xr = x.float(); wr = w.clone().requires_grad_(True)
@@ -282,11 +294,11 @@ def test_conv_thin(case, dev):
     assert torch.equal(dw, 2 * first)
     # against the implicit-GEMM kernel on the same inputs: same products, fp32 sums in another order
     import os
-    os.environ['MSCL_THIN'] = '0'
+    lib.tune(MSCL_THIN=0)
     try:
         close(K_.conv3d_fwd(xg, wg, d), y, 2.0 ** -7, 'thin vs implicit GEMM')
     finally:
-        del os.environ['MSCL_THIN']
+        lib.tune(MSCL_THIN=None)
 
 
 # conv_win64.hip (persistent window-resident ping-pong kernel, 64 -> 64, 3x3 in plane): tiles that straddle planes and samples,
@@ -311,6 +323,7 @@ def test_conv_win64_forced(case, dev, monkeypatch):
     C = K = 64
     stride = (1, 1, 1)
     monkeypatch.setenv('MSCL_WIN64', '2')
+    lib.tune()
     x = bf(rnd((N, T, H, W, C), 21)); w = bf(rnd((K, *kern, C), 22, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
     xg, wg = x.to(dev), w.to(dev)

@@ -289,7 +289,9 @@ def test_graphed_step_matches_eager(dev):
 
 def test_graphed_step_equals_eager_bitwise_in_deterministic_mode(dev):
     """With lib.set_deterministic the captured-graph step and the eager step are the same arithmetic in the same order: three
-    optimizer steps give bit-identical losses, parameters and queue state (no noise yardstick needed)."""
+    optimizer steps on three DIFFERENT batches give bit-identical losses, parameters and queue state (no noise yardstick needed)
+    -- for the graph that reads its inputs by address (the single-GPU default: asserted, so a replay provably read each new
+    batch's address and not the capture batch's) and for the graph that copies them into static buffers."""
     from mscl_amd import ClipSGD, lib
     from mscl_amd.graph import GraphedStep
     from mscl_amd.synthetic import synthetic_batch
@@ -297,13 +299,14 @@ def test_graphed_step_equals_eager_bitwise_in_deterministic_mode(dev):
     lib.set_deterministic(True)
     try:
         runs = []
-        for mode in ('eager', 'graph'):
+        for mode in ('eager', 'graph', 'graph_static'):
             model, cfg = build(T, Kq, dev)
             opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
             batches = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(3)]
             losses = []
-            if mode == 'graph':
-                gs = GraphedStep(model, opt, batches[0], warmup=2)
+            if mode != 'eager':
+                gs = GraphedStep(model, opt, batches[0], warmup=2, indirect=None if mode == 'graph' else False)
+                assert (gs.indirect is not None) == (mode == 'graph'), 'which input path the captured step took'
                 for s in range(3):
                     losses.append(float(gs.step(batches[s])[0]))
             else:
@@ -316,10 +319,12 @@ def test_graphed_step_equals_eager_bitwise_in_deterministic_mode(dev):
             runs.append((losses, model.arena.Q.clone(), model.recognizer.queue.clone(), model.recognizer_flow.queue.clone()))
     finally:
         lib.set_deterministic(False)
-    (l0, q0, a0, b0), (l1, q1, a1, b1) = runs
-    assert l0 == l1, (l0, l1)
-    assert torch.equal(q0, q1), float((q0 - q1).abs().max())
-    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    (l0, q0, a0, b0) = runs[0]
+    assert len(set(l0)) == 3, 'the three batches must give three different losses'
+    for (l1, q1, a1, b1) in runs[1:]:
+        assert l0 == l1, (l0, l1)
+        assert torch.equal(q0, q1), float((q0 - q1).abs().max())
+        assert torch.equal(a0, a1) and torch.equal(b0, b1)
 
 
 # ----------------------------------------------------------------------------- 2 ranks on one GPU
@@ -1193,6 +1198,47 @@ def test_deterministic_mode_is_bit_identical(dev):
             assert abs(a[0][k] - v) <= 2e-3 * max(1.0, abs(v)) + 0.02, (k, a[0][k], v)
     cos = torch.nn.functional.cosine_similarity
     assert float(cos(a[3].double(), ref[3].double(), dim=0)) >= 0.90
+
+
+def test_deferred_transpose_reaches_every_backward_entry(dev):
+    """(round-3 advisor) `refresh_after_optimizer` only MARKS the transposed kernels stale (defer_transpose, the default); the
+    step refreshes them at its head.  A backward that does not come through the step -- encode_q + backward after an optimizer
+    step, as tools/chain_times.py and trunk-only loops do -- must refresh them itself before its first input gradient
+    (nn.TransposeState, Conv3dHip.wT).  Deterministic mode, so the comparison is bit for bit: (a) two optimizer steps with
+    defer_transpose on and off leave identical parameters and logs; (b) after them, the trunk-only backward gives identical
+    gradients either way (a stale wT would give the previous step's input gradients)."""
+    from mscl_amd import ClipSGD, lib
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H = 2, 8, 64
+    lib.set_deterministic(True)
+    try:
+        res = []
+        for defer in (True, False):
+            model, cfg = build(T, 64, dev)
+            model.defer_transpose = defer
+            opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+            logs = []
+            for s in range(2):
+                batch = synthetic_batch(B, T, H, H, 0, s, device=dev)
+                out = model.train_step(batch)
+                opt.zero_grad(); out['loss'].backward(); opt.step()
+                logs.append(dict(out['log_vars']))
+            assert model._wt.stale == defer
+            # a backward entry of its own: the RGB query trunk alone
+            x = synthetic_batch(B, T, H, H, 0, 7, device=dev)['imgs'][0]
+            model.zero_grad()
+            maps = model.recognizer.encoder_q(model.aug_gpu.pack_rgb(x))
+            (maps[-1].float().mean() + maps[0].float().mean()).backward()
+            torch.cuda.synchronize()
+            assert not model._wt.stale, 'the first input gradient must have refreshed the transposed kernels'
+            res.append((logs, model.arena.Q.clone(), model.arena.G.clone()))
+        (la, qa, ga), (lb, qb, gb) = res
+        assert la == lb
+        assert torch.equal(qa, qb)
+        assert torch.equal(ga, gb), float((ga - gb).abs().max())
+        assert float(ga.abs().max()) > 0
+    finally:
+        lib.set_deterministic(False)
 
 
 def test_flow_batch_equals_two_passes(dev):

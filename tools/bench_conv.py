@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mscl_amd import kernels as K  # noqa: E402
+from mscl_amd import kernels as K, lib  # noqa: E402
 
 SHAPES = [
     # name, (N,T,H,W,C), K, kernel, stride, pad
@@ -105,12 +105,9 @@ def sweep(a):
             best = {v: 1e9 for v in vals}
             for _ in range(a.rounds):
                 for v in vals:
-                    if v == '-':
-                        os.environ.pop(var, None)
-                    else:
-                        os.environ[var] = v
+                    lib.tune(**{var: None if v == '-' else v})     # (the library caches its switches: set + re-read)
                     best[v] = min(best[v], timeit(fns[m], a.iters) * 1e3)
-            os.environ.pop(var, None)
+            lib.tune(**{var: None})
             print(f'{name:16s} {m:6s} ' + '  '.join(f'{v}: {best[v]:7.1f}' for v in vals), flush=True)
 
 
