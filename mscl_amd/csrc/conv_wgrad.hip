@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
           // deterministic mode: this split's tile goes to its own slab with plain stores; wgrad_slab_reduce_kernel adds the
           // slabs to dw in split order
           if (slab != nullptr) slab[((long)split * g.K + co) * g.ncols + col] = acc[i][j][r];
+          else if (g.splits == 1) dw[(long)co * g.ncols + col] += acc[i][j][r];       // one owner per element: no atomic needed
           else atomicAdd(&dw[(long)co * g.ncols + col], acc[i][j][r]);
         }
       }
@@ -352,6 +353,8 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   long target = (CO + NCOL) > 128 ? 512 : 768;            // blocks overall: 2 per CU with the 68-KB 128 x 128 tile, ~3 otherwise
   if (g.C <= 8) target = 2048;                            // stems: 16-byte gathers per position, the DMA latency wants more waves (95 -> 81 us)
   long want = (CO + NCOL) > 128 ? (target / tiles > 0 ? target / tiles : 1) : (target + tiles - 1) / tiles;
+  static MsclTune t_one("MSCL_WGRAD_ONE_SPLIT");          // layers with at least this many tiles run ONE split (plain adds, no atomics)
+  if (tiles >= t_one.get(1 << 30)) want = 1;
   long maxs = (g.M + 255) / 256;                          // at least 4 steps per block
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -443,10 +446,10 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   }
   // (NCOL = 192, three taps sharing one dy tile, measured slower than 64 -- fewer blocks per CU -- and was dropped)
   int pres = 0;
-  if (hres == 0 && ws != nullptr && wgrad_pp_enabled(d)) {
+  if (hres == 0 && wgrad_pp_enabled(d)) {
     // its slabs are added in split order, so the result is deterministic as it stands: same path in deterministic mode
     const long tail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
-    pres = mscl_wgrad_pp(d, x, dy, dw, ws, ws_floats - tail, st);
+    pres = mscl_wgrad_pp(d, x, dy, dw, ws, ws != nullptr ? ws_floats - tail : 0, st);
     if (pres < 0 || pres > 1) return pres;
   }
   int tres = 0;

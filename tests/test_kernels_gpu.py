@@ -160,10 +160,14 @@ PP_CASES = [
 ]
 
 
+@pytest.mark.parametrize('late', [0, 1, 2], ids=['inL', 'afterM', 'beforeM'])
 @pytest.mark.parametrize('case', PP_CASES, ids=[c[0] for c in PP_CASES])
-def test_conv_pp_forced(case, dev, monkeypatch):
+def test_conv_pp_forced(case, late, dev, monkeypatch):
+    """late: where a wave issues its share of the next group's LDS-DMA (conv_pp.hip, LATE): every placement is a schedule of its own
+    and gets the full parity + repeat-launch race screen"""
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K, kern, stride, pad, ksplit = case
+    monkeypatch.setenv('MSCL_PP_LATE', str(late))
     monkeypatch.setenv('MSCL_PP', '2')
     monkeypatch.setenv('MSCL_HALO', '0')          # (the window-resident layer-1 kernel would take the 64 -> 64 cases first)
     if ksplit:
@@ -206,11 +210,18 @@ def test_conv_pp_forced(case, dev, monkeypatch):
 WGRAD_PP_CASES = [c for c in PP_CASES if c[5] % 128 == 0 and c[6] % 128 == 0]
 
 
+# a long single map so that every block walks many K tiles through all three ring slots (the small cases stop after 1-6 tiles)
+WGRAD_PP_CASES.append(('pp_ring', 2, 4, 28, 28, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 0))
+
+
+@pytest.mark.parametrize('late', [1, 0], ids=['late', 'inL'])
 @pytest.mark.parametrize('case', WGRAD_PP_CASES, ids=['wg' + c[0] for c in WGRAD_PP_CASES])
-def test_conv_wgrad_pp_forced(case, dev, monkeypatch):
+def test_conv_wgrad_pp_forced(case, late, dev, monkeypatch):
+    """late: the DMA pieces issued from the M sections (the default) / from L of phase 0 (the A/B arm), both on the three-slot ring"""
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K, kern, stride, pad, _ = case
     monkeypatch.setenv('MSCL_WGRAD_PP', '2')
+    monkeypatch.setenv('MSCL_WGRAD_PP_LATE', str(late))
     lib.tune()
     x = bf(rnd((N, T, H, W, C), 31)); w = rnd((K, *kern, C), 32)
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
