@@ -72,6 +72,7 @@ def parse():
     p.add_argument('--no-graph', action='store_true', help='eager launches instead of one captured HIP graph per step')
     p.add_argument('--deterministic', action='store_true',
                    help='variant: the library\'s deterministic mode (fixed-order sums instead of float atomics; the reference\'s --deterministic)')
+    p.add_argument('--no-variants', action='store_true', help='skip the deterministic-mode leg that follows the headline region')
     p.add_argument('--stochastic-aug', action='store_true',
                    help='variant (not the BASELINE.json workload): random flip / colour jitter / grayscale / blur per step')
     return p.parse_args()
@@ -118,6 +119,40 @@ def cpu_baseline(cpu_batch):
                 sample=f'oracle MSCLWithAug step (fwd+bwd+clip+SGD), fp32, B={cpu_batch}, T={T_FRAMES}, {SIDE}x{SIDE}, '
                        f'1 warm-up, thread count picked from {cands} by one step each, then 3 timed steps '
                        f'(mean {mean:.2f} s on {threads} threads)')
+
+
+def rccl_probe(dev, world, model):
+    """What RCCL saw, so that a driver can verify an N-rank line from the line itself (world size > 1, or a one-rank group with
+    MSCL_FORCE_DIST=1): backend, world size, the ranks an all-gather returned, the bus bandwidth of one 100-MB fp32 all-reduce
+    timed before the warm-up (busbw = 2 (W-1)/W x bytes / time, the ring figure RCCL's own tests quote; 0 at W = 1), and the
+    ring-model estimate of the wire time the step leaves exposed (parallel.exposed_wire_ms on the bucket sizes of THIS model and
+    the fire times of profiles/r03_chain_times.txt)."""
+    from mscl_amd import parallel
+    sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)      # (CPU + gloo: the 2-rank test of this function)
+    out = {'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
+    seen = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([dist.get_rank()], dtype=torch.int64, device=dev))
+    out['ranks_seen'] = [int(t) for t in seen]
+    buf = torch.ones(25 << 20, dtype=torch.float32, device=dev)          # 100 MiB
+    dist.all_reduce(buf)                                                   # warm-up: connections, proxy threads
+    sync(); dist.barrier()
+    t0 = time.perf_counter()
+    dist.all_reduce(buf)
+    sync()
+    dt = time.perf_counter() - t0
+    out['allreduce_100MB_ms'] = round(dt * 1e3, 3)
+    out['allreduce_busbw_GBps'] = round(2.0 * (world - 1) / world * buf.numel() * 4 / dt / 1e9, 1) if world > 1 else 0.0
+    red = getattr(model, 'reducer', None)
+    if red is not None:
+        nbytes = [(b - a) * 4 for a, b in red.ranges]
+        out['grad_buckets_MB'] = [round(n / 1e6, 1) for n in nbytes]
+        out['grad_collective'], out['grad_transport'] = red.collective, red.transport
+        # fire times into backward (ms) of [layer 4, layer 3, layer 2, stem + layer 1, neck + heads, flow] and the backward's length,
+        # measured on one GPU (profiles/r03_chain_times.txt)
+        fire, bwd = [0.9, 1.25, 1.8, 3.78, 0.5, 1.7], 3.78
+        if len(nbytes) == len(fire):
+            out['exposed_wire_ms_model'] = round(parallel.exposed_wire_ms(nbytes, fire, bwd, max(world, 2)), 4)
+    return out
 
 
 def main():
@@ -208,6 +243,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rccl = None
+    if world > 1 or forced:
+        try:
+            rccl = rccl_probe(dev, world, model)
+        except Exception as e:      # noqa: BLE001 -- a failed probe must not lose the measurement
+            rccl = {'error': f'{type(e).__name__}: {e}'}
     for i in range(args.warmup):
         step(i)
     fence()
@@ -229,6 +270,50 @@ def main():
     model.two_streams, model.key_graphs, model.query_graphs = streams_were, keyg_were, qg_were
     prof = kernels.PROFILE
     kernels.PROFILE = None
+    # -- world size > 1: the step with its gradient buckets NOT sent (a few steps at the very end: the replicas drift apart);
+    # step time - that = the wire time the overlap leaves exposed, measured
+    dt_nocoll = None
+    if (world > 1 or forced) and getattr(model, 'reducer', None) is not None and graphed is None:
+        try:
+            model.reducer.skip = True
+            for i in range(2):
+                step(i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(max(4, args.steps // 2)):
+                step(i)
+            fence()
+            dt_nocoll = (time.perf_counter() - t1) / max(4, args.steps // 2)
+        except Exception as e:      # noqa: BLE001
+            print(f'[bench] no-collective leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+        finally:
+            model.reducer.skip = False
+    # -- variant: the library's deterministic mode (the reference's --deterministic), from a graph of its own, >= 10 replays after
+    # the headline region.  One GPU only; never the headline value.
+    det_variant = None
+    if world == 1 and not forced and graphed is not None and not args.deterministic and not args.no_variants:
+        try:
+            from mscl_amd import lib as _lib
+            from mscl_amd.graph import GraphedStep
+            _lib.set_deterministic(True)
+            gd = GraphedStep(model, opt, batches[0], warmup=2)
+            for i in range(3):
+                gd.step(batches[i % nbatch])
+            torch.cuda.synchronize()
+            nrep = max(10, args.steps)
+            t1 = time.perf_counter()
+            for i in range(nrep):
+                ld = gd.step(batches[i % nbatch])[0]
+            torch.cuda.synchronize()
+            dtd = time.perf_counter() - t1
+            det_variant = {'value': BATCH * nrep / dtd, 'unit': 'clip-pairs/s', 'ms_per_step': 1e3 * dtd / nrep, 'steps': nrep,
+                           'final_loss': float(ld.detach()),
+                           'what': 'mscl_set_deterministic(1): fixed-order sums instead of float atomics, one captured HIP graph per step'}
+            del gd
+        except Exception as e:      # noqa: BLE001
+            det_variant = {'error': f'{type(e).__name__}: {e}'}
+        finally:
+            _lib.set_deterministic(False)
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -243,9 +328,16 @@ def main():
         avg_ms = sum(ms) / max(1, len(ms))
         flops = 2.0 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 27 * 64       # 88.8 GFLOP per launch
         achieved = flops / (avg_ms * 1e-3) / 1e12 if ms else 0.0
+        # second kernel by total time: conv_pp_kernel<128> (layers 2-4, SEPC, FPN); priced on its largest shape, the 128 -> 128
+        # 3x3x3 conv on (8,8,28,28,128) = 44.4 GFLOP per launch, forward launches by the same event pairs
+        ms2 = [a.elapsed_time(b) for mode, d, a, b in prof['events']
+               if mode == 'fwd' and (d[4], d[8], d[9], d[2]) == (128, 128, 3, SIDE // 4)]
+        avg2 = sum(ms2) / max(1, len(ms2))
+        flops2 = 2.0 * BATCH * (T_FRAMES // 2) * (SIDE // 4) ** 2 * 128 * 27 * 128
+        ach2 = flops2 / (avg2 * 1e-3) / 1e12 if ms2 else 0.0
         traffic = None
         tname = None
-        for tname in ('r03_traffic_layer1.json', 'r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
+        for tname in ('r04_traffic_layer1.json', 'r03_traffic_layer1.json', 'r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
             tp = os.path.join(ROOT, 'profiles', tname)
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
@@ -275,6 +367,10 @@ def main():
                          'traffic_source': 'file' if traffic is not None else None,       # read from the committed PMC summary, not measured in this run
 
                          'algorithmic_bytes': 2 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 2 + 64 * 27 * 64 * 2,
+                         'also': [{'bound': 'mfma', 'kernel': 'conv_pp_kernel<128> fwd (+BN statistics), 3x3x3 128->128 on (8,8,28,28,128)',
+                                   'achieved': ach2, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach2 / PEAK_BF16_TFLOPS,
+                                   'launches_timed': len(ms2), 'avg_launch_ms': avg2,
+                                   'algorithmic_bytes': 2 * BATCH * (T_FRAMES // 2) * (SIDE // 4) ** 2 * 128 * 2 + 128 * 27 * 128 * 2}],
                          # the whole step against the same peak: executed conv GFLOP of one step / timed step duration
                          'step_gflop': round(STEP_GFLOP_EXECUTED, 1), 'step_gflop_reference': round(STEP_GFLOP_REFERENCE, 1),
                          'step_tflops': STEP_GFLOP_EXECUTED * 1e-3 / step_s,
@@ -283,6 +379,13 @@ def main():
                          # single-stream eager steps (so the >= 0.70 target of north_star is tracked by this line)
                          'stages': stage_table(prof['events'])},
         }
+        if det_variant is not None:
+            line['variants'] = {'deterministic': det_variant}
+        if rccl is not None:
+            if dt_nocoll is not None:
+                rccl['step_ms_without_grad_collectives'] = round(1e3 * dt_nocoll, 4)
+                rccl['exposed_wire_ms_measured'] = round(1e3 * (step_s - dt_nocoll), 4)
+            line['rccl'] = rccl
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch)
         print(json.dumps(line), flush=True)

@@ -52,9 +52,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
   const float inv_n = 1.f / (float)rows_g;
   const float unbias = rows_g > 1 ? (float)rows_g / (float)(rows_g - 1) : 1.f;
   const bool writer = blockIdx.x == 0;
-  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer, groups, nslots);
-  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer, groups, nslots);
-  __syncthreads();
   const int G = C >> 3;
   const long total = rows * G;
   const unsigned ebound = groups > 1 ? (unsigned)(rows_g * G) : 0xFFFFFFFFu;     // first granule of group 1
@@ -63,17 +60,27 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
   const unsigned gmask = ((G & (G - 1)) == 0) ? (unsigned)(G - 1) : 0xFFFFFFFFu;
   const unsigned total32 = (unsigned)total, step32 = gridDim.x * blockDim.x;
   // UNR granules per trip with every load issued before the first use: a thread makes only ~6 trips on the largest map,
-  // so one 16-byte load in flight per thread leaves the pass latency-bound (2.6 TB/s measured on the layer-1 map)
+  // so one 16-byte load in flight per thread leaves the pass latency-bound (2.6 TB/s measured on the layer-1 map).
+  // The FIRST trip's loads are issued before the per-channel constants are rebuilt from the statistics slots (bn_prepare: a
+  // dependent chain of slot loads, rsqrt and an LDS round trip): on the maps of layers 3-4 a thread makes one trip, and the
+  // launch was two memory round trips one after the other (7-8 us for 0.8-3 MB).
   constexpr int UNR = 4;
-  for (unsigned e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total32; e0 += step32 * UNR) {
-    uint4 v[UNR], rv[UNR];
+  uint4 v[UNR], rv[UNR];
+  auto load_trip = [&](unsigned e0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const unsigned e = e0 + u * step32;
-      const unsigned ec = e < total32 ? e : e0;             // clamped: the duplicate is not stored
+      const unsigned ec = e < total32 ? e : (e0 < total32 ? e0 : 0u);             // clamped: the duplicate is not stored
       v[u] = *reinterpret_cast<const uint4*>(y + (long)ec * 8);
       if (res != nullptr) rv[u] = *reinterpret_cast<const uint4*>(res + (long)ec * 8);
     }
+  };
+  unsigned e0 = blockIdx.x * blockDim.x + threadIdx.x;
+  load_trip(e0);
+  bn_prepare(bn, scale, shift, C, inv_n, unbias, eps, momentum, writer, groups, nslots);
+  if (res_is_bn) bn_prepare(rbn, rscale, rshift, C, inv_n, unbias, eps, momentum, writer, groups, nslots);
+  __syncthreads();
+  for (; e0 < total32; e0 += step32 * UNR) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const unsigned e = e0 + u * step32;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
       }
       *reinterpret_cast<uint4*>(out + (long)e * 8) = pack8(f);
     }
+    if (e0 + step32 * UNR < total32) load_trip(e0 + step32 * UNR);
   }
 }
 
@@ -380,6 +388,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   const bool mask_y = relu && beta != nullptr;
   const long rows_g = rows / groups;         // statistics groups (<= 2): rows below rows_g are group 0
   const float inv_n = 1.f / (float)rows_g;
+  const int G = C >> 3;                      // a power of two (checked by the launcher)
+  const int gsh = 31 - __clz(G);
+  const unsigned total32 = (unsigned)(rows * G), step32 = gridDim.x * blockDim.x, gmask = (unsigned)(G - 1);
+  const unsigned ebound = groups > 1 ? (unsigned)(rows_g * G) : 0xFFFFFFFFu;
+  const long ldg = ldc >> 3, chg = ch >> 3;  // granules per map row, first granule of this chunk
+  // UNR granules per trip, every load of a trip in flight before the first use (one granule per trip ran the pass at 3.0 TB/s
+  // inside the step against 5-6 for the forward pass); the first trip's loads go out before the per-channel constants are
+  // rebuilt from the scratch slots, as in the forward pass
+  constexpr int UNR = 4;
+  const bool need_out = relu && !mask_y;
+  uint4 vd[UNR], vy[UNR], va[UNR], vr[UNR];
+  auto gaddr = [&](unsigned e32) { return ((long)(e32 >> gsh) * ldg + chg + (e32 & gmask)) * 8; };
+  auto load_trip = [&](unsigned e0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned e32 = e0 + u * step32;
+      const long o = gaddr(e32 < total32 ? e32 : (e0 < total32 ? e0 : 0u));
+      vd[u] = *reinterpret_cast<const uint4*>(dout + o);
+      vy[u] = *reinterpret_cast<const uint4*>(y + o);
+      if (need_out) va[u] = *reinterpret_cast<const uint4*>(out + o);
+      if (ry) vr[u] = *reinterpret_cast<const uint4*>(ry + o);
+    }
+  };
+  unsigned e0 = blockIdx.x * blockDim.x + threadIdx.x;
+  load_trip(e0);
   for (int c = threadIdx.x; c < C; c += 256) {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     for (int gq = 0; gq < groups; ++gq) {
@@ -402,42 +435,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
   }
   __syncthreads();
-  const int G = C >> 3;                      // a power of two (checked by the launcher)
-  const int gsh = 31 - __clz(G);
-  const unsigned total32 = (unsigned)(rows * G), step32 = gridDim.x * blockDim.x, gmask = (unsigned)(G - 1);
-  const unsigned ebound = groups > 1 ? (unsigned)(rows_g * G) : 0xFFFFFFFFu;
-  const long ldg = ldc >> 3, chg = ch >> 3;  // granules per map row, first granule of this chunk
-  for (unsigned e32 = blockIdx.x * blockDim.x + threadIdx.x; e32 < total32; e32 += step32) {
-    const long e = (long)(e32 >> gsh) * ldg + chg + (e32 & gmask);      // granule index in the map
-    const int c0 = (int)(e32 & gmask) * 8 + (e32 >= ebound ? C : 0);
-    float d[8], yy[8], o8[8];
-    unpack8(*reinterpret_cast<const uint4*>(dout + e * 8), d);
-    unpack8(*reinterpret_cast<const uint4*>(y + e * 8), yy);
-    if (mask_y) {
+  for (; e0 < total32; e0 += step32 * UNR) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) d[i] = (yy[i] * gi[c0 + i] + msh[c0 + i]) > 0.f ? d[i] : 0.f;
-    } else if (relu) {
-      float a[8]; unpack8(*reinterpret_cast<const uint4*>(out + e * 8), a);
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned e32 = e0 + u * step32;
+      if (e32 >= total32) break;
+      const long o = gaddr(e32);
+      const int c0 = (int)(e32 & gmask) * 8 + (e32 >= ebound ? C : 0);
+      float d[8], yy[8], o8[8];
+      unpack8(vd[u], d);
+      unpack8(vy[u], yy);
+      if (mask_y) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
-    }
+        for (int i = 0; i < 8; ++i) d[i] = (yy[i] * gi[c0 + i] + msh[c0 + i]) > 0.f ? d[i] : 0.f;
+      } else if (relu) {
+        float a[8]; unpack8(va[u], a);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = c0 + i;
-      o8[i] = gi[c] * (d[i] - ca[c] - (yy[i] - mu[c]) * iv[c] * cb[c]);
-    }
-    *reinterpret_cast<uint4*>(dy + e * 8) = pack8(o8);
-    if (ry) {
-      float rr[8]; unpack8(*reinterpret_cast<const uint4*>(ry + e * 8), rr);
+        for (int i = 0; i < 8; ++i) d[i] = a[i] > 0.f ? d[i] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = c0 + i;
-        o8[i] = rgi[c] * (d[i] - ca[c] - (rr[i] - rmu[c]) * riv[c] * rcb[c]);
+        o8[i] = gi[c] * (d[i] - ca[c] - (yy[i] - mu[c]) * iv[c] * cb[c]);
       }
-      *reinterpret_cast<uint4*>(dres + e * 8) = pack8(o8);
-    } else if (identity_dres) {
-      *reinterpret_cast<uint4*>(dres + e * 8) = pack8(d);
+      *reinterpret_cast<uint4*>(dy + o) = pack8(o8);
+      if (ry) {
+        float rr[8]; unpack8(vr[u], rr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = c0 + i;
+          o8[i] = rgi[c] * (d[i] - ca[c] - (rr[i] - rmu[c]) * riv[c] * rcb[c]);
+        }
+        *reinterpret_cast<uint4*>(dres + o) = pack8(o8);
+      } else if (identity_dres) {
+        *reinterpret_cast<uint4*>(dres + o) = pack8(d);
+      }
     }
+    if (e0 + step32 * UNR < total32) load_trip(e0 + step32 * UNR);
   }
 }
 

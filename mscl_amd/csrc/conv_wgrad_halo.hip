@@ -11,6 +11,14 @@
 //  * both operands are position-major, so fragments are column reads: ds_read_b64_tr_b16 (as conv_wgrad.hip);
 //  * pad columns / rows outside the plane are zero in BOTH tiles (buffer range check), so they add nothing;
 //  * items are double-buffered in LDS (2 x 79 KB): the next item's DMA pieces are issued between the k steps.
+// Round 4 (NW = 8, the default): the round-3 form ran ONE wave per SIMD whose single instruction stream also issued the 20 DMA
+// pieces of the next item (60-180 issue cycles each) and waited on its own transposing reads: 6.3 us per item against 1.9 us of
+// MFMA work, 12 GB/s per CU of fill -- neither roof.  Now two waves per SIMD split the k steps of an item (waves 4-7 take
+// positions 128-255 of the tile with a full set of 144 accumulators of their own; the pairs are added through LDS once, at the
+// end of the block), so one wave's DMA issue and read latencies are covered by its partner's MFMAs, and each wave issues half
+// the pieces.  Items are walked tile-major (consecutive planes of one plane tile) and the three kt blocks of a slot get consecutive
+// logical ids on one XCD: the dy tile is fetched by all three at the same time and an x plane at three consecutive items, so
+// beyond the XCD's L2 both maps are read about once instead of three times (393 -> ~180 MB per launch against 103 algorithmic).
 #include "common.h"
 #include <cstdlib>
 
@@ -18,7 +26,8 @@ struct WHGeom {
   int N, T, H, W, HW, Wp, tiles;   // tiles per plane (256 padded-linear positions each)
   int total;                        // plane tiles = N * T * tiles
   int gk;                           // blocks per kt
-  FastDiv dWp, dTiles, dT;
+  int planes;                       // N * T
+  FastDiv dWp, dTiles, dT, dPlanes;
 };
 
 constexpr int WH_XROWS = 376, WH_XBYTES = WH_XROWS * 128, WH_DYBYTES = 256 * 128, WH_STAGE = WH_XBYTES + WH_DYBYTES;
@@ -26,7 +35,12 @@ constexpr int WH_XPASS = 12, WH_DYPASS = 8;
 constexpr unsigned WH_OOB = 0x80000000u;
 constexpr int WH_SLAB = 9 * 64 * 64;
 
-__device__ __forceinline__ int whswz(int row) { return (row & 2) | ((row >> 1) & 4); }
+// XOR key on the 16-byte granule index of a 128-byte row.  The 32 reduction rows of a k step are dealt to the lanes as
+// row = 4 * (lane >> 4) + ((lane >> 2) & 3) + 16 h (h = the first / second transposing read of a fragment) -- any order of the
+// reduction index serves, as long as both operands use the same -- so that h and the k step are IMMEDIATE offsets of one address
+// register per fragment (+2048 / +4096 bytes; bits 1, 2 of the row, which the key is made of, do not move) and a 32-lane group of
+// a read touches 8 consecutive rows: 8 distinct 32-byte slots of the bank row under this key, whatever the tap's row shift.
+__device__ __forceinline__ int whswz(int row) { return row & 6; }
 __device__ __forceinline__ auto wh_rsrc(const void* p) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
@@ -37,17 +51,27 @@ typedef __attribute__((address_space(3))) void* wh_lds_t;
 typedef __attribute__((ext_vector_type(4))) short wh_s16x4;
 typedef __attribute__((ext_vector_type(8))) short wh_s16x8;
 
-__global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, const bf16_t* __restrict__ x,
-                                                              const bf16_t* __restrict__ dy, float* __restrict__ slabs) {
+// NW = waves per block: 4 = one per SIMD (round 3), 8 = two per SIMD that split the k steps of every item (see the header)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g, const bf16_t* __restrict__ x,
+                                                                  const bf16_t* __restrict__ dy, float* __restrict__ slabs) {
+  constexpr int NG = NW / 4;                               // wave groups splitting the 8 k steps of an item
+  constexpr int RPP = 8 * NW;                              // rows per DMA pass (64 * NW threads x 16 B)
+  constexpr int XP = (WH_XROWS + RPP - 1) / RPP, DP = 256 / RPP, NP = XP + DP;      // passes: 12 + 8 / 6 + 4
+  constexpr int TRIPS = 4 / NG;                            // trips of two k steps per item and group
+  static_assert(NW == 4 || NW == 8, "waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kt = blockIdx.x % 3, slot = blockIdx.x / 3;
+  const int wq = wave & 3, grp = wave >> 2;                // ci tile of the wave; k-step group
+  // the three kt blocks of a slot: consecutive logical ids = one XCD (its L2 then serves two of the three reads of every tile)
+  const int lin = NW == 8 ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int kt = lin % 3, slot = lin / 3;
   const auto rs_x = wh_rsrc(x);
   const auto rs_dy = wh_rsrc(dy);
-  // wave tile: all 64 co x ci [16*wave, +16): one B fragment per step feeds 4 MFMAs (a 32 x 32 tile needs twice the
+  // wave tile: all 64 co x ci [16*wq, +16): one B fragment per step feeds 4 MFMAs (a 32 x 32 tile needs twice the
   // transposing reads per MFMA, and those, not the MFMAs, then set the pace)
-  const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int fgp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
 
   // accumulators: [tap 0..8][co tile 0..3]
   f32x4_t acc[9][4];
@@ -56,106 +80,106 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, co
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t9][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // item = plane tile pt (valid when the source plane t + kt - 1 exists)
-  auto next_valid = [&](int pt) {
-    while (pt < g.total) {
-      const int plane = fdiv(pt, g.dTiles);
+  // items of this block.  NW = 4: plane tiles slot, slot + gk, ... (plane-major).  NW = 8: a contiguous range of the TILE-MAJOR
+  // order (item i = tile i / planes of plane i % planes), the same range for the three kt blocks of the slot.
+  const int i_end = NW == 8 ? (int)((long)(slot + 1) * g.total / g.gk) : g.total;
+  const int i_step = NW == 8 ? 1 : g.gk;
+  auto item_plane = [&](int it) { return NW == 8 ? it - fdiv(it, g.dPlanes) * g.planes : fdiv(it, g.dTiles); };
+  auto next_valid = [&](int it) {
+    while (it < i_end) {
+      const int plane = item_plane(it);
       const int t = plane - fdiv(plane, g.dT) * g.T;
       if ((unsigned)(t + kt - 1) < (unsigned)g.T) break;
-      pt += g.gk;
+      it += i_step;
     }
-    return pt;
+    return it;
   };
-  // Per-item DMA state.  Piece k < 12 stages window rows 32k + (tid >> 3), piece 12 + k' dy rows 32k' + (tid >> 3).
-  // Consecutive pieces advance a row's padded-linear position by 32 (no per-piece offset arrays: they would need dynamic
-  // register indexing); the swizzle key of a row is unchanged by +32 (bits 1 and 3), so the lane's source granule is fixed.
+  // Per-item DMA state.  Piece k < XP stages window rows RPP k + (tid >> 3), piece XP + k' dy rows RPP k' + (tid >> 3).
+  // Consecutive pieces advance a row's padded-linear position by RPP (no per-piece offset arrays: they would need dynamic
+  // register indexing); the swizzle key of a row is unchanged by +32 / +64 (bits 1 and 2), so the lane's source granule is fixed.
   const int prow = tid >> 3, pg = tid & 7;
   const unsigned xg = (unsigned)((pg ^ whswz(prow)) * 16), dg = xg;
   int x_q = 0, d_q = 0;                                    // padded-linear position of the row of the NEXT piece of each kind
   unsigned xs = 0, ds = 0;
-  auto prepare = [&](int pt) {
-    const int plane = fdiv(pt, g.dTiles), tile = pt - plane * g.tiles;
+  auto prepare = [&](int it) {
+    int plane, tile;
+    if constexpr (NW == 8) { tile = fdiv(it, g.dPlanes); plane = it - tile * g.planes; }
+    else { plane = fdiv(it, g.dTiles); tile = it - plane * g.tiles; }
     const int q0 = g.Wp + tile * 256;
     x_q = q0 - g.Wp - 1 + prow;                            // >= -1
     d_q = q0 + prow;
     xs = __builtin_amdgcn_readfirstlane((unsigned)((plane + kt - 1) * g.HW) * 128u);
     ds = __builtin_amdgcn_readfirstlane((unsigned)(plane * g.HW) * 128u);
   };
-  auto issue_piece = [&](int k, int stage) {               // k (wave-uniform, runtime) in [0, 20), issued in order
+  auto issue_piece = [&](int k, int stage) {               // k (wave-uniform, runtime) in [0, NP), issued in order
     unsigned char* base = smem + stage * WH_STAGE;
-    if (k < WH_XPASS) {
+    if (k < XP) {
       const int x_hp = fdiv(x_q < 0 ? 0 : x_q, g.dWp), x_wp = x_q - x_hp * g.Wp;
       const bool ok = x_q >= 0 && x_hp >= 1 && x_hp <= g.H && x_wp >= 1 && x_wp <= g.W;
       const unsigned vo = ok ? (unsigned)(((x_hp - 1) * g.W + (x_wp - 1)) * 128) + xg : WH_OOB;
-      x_q += 32;
-      if (!(k == WH_XPASS - 1 && wave == 3))               // rows 376..383 do not exist
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (wh_lds_t)(base + (k * 256 + wave * 64) * 16), 16, vo, xs, 0, 0);
+      x_q += RPP;
+      if (!(k == XP - 1 && wave == NW - 1))                // rows 376..383 do not exist
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (wh_lds_t)(base + (k * 64 * NW + wave * 64) * 16), 16, vo, xs, 0, 0);
     } else {
       const int d_hp = fdiv(d_q, g.dWp), d_wp = d_q - d_hp * g.Wp;
       const bool ok = d_hp <= g.H && d_wp >= 1 && d_wp <= g.W;
       const unsigned vo = ok ? (unsigned)(((d_hp - 1) * g.W + (d_wp - 1)) * 128) + dg : WH_OOB;
-      d_q += 32;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (wh_lds_t)(base + WH_XBYTES + ((k - WH_XPASS) * 256 + wave * 64) * 16), 16, vo, ds, 0, 0);
+      d_q += RPP;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (wh_lds_t)(base + WH_XBYTES + ((k - XP) * 64 * NW + wave * 64) * 16), 16, vo, ds, 0, 0);
     }
   };
 
-  int pt = next_valid(slot);
+  int pt = next_valid(NW == 8 ? (int)((long)slot * g.total / g.gk) : slot);
   int cur = 0;
-  if (pt < g.total) {
+  if (pt < i_end) {
     prepare(pt);
-    for (int k = 0; k < WH_XPASS + WH_DYPASS; ++k) issue_piece(k, 0);
+    for (int k = 0; k < NP; ++k) issue_piece(k, 0);
   }
-  // Per-lane LDS addresses of the transposing reads.  Row r = r_l + 4h + 32*ks + shift(tap); the XOR swizzle key uses
-  // bits 1 and 3 of r, which 32*ks does not touch: one address per (tap, h), the k step goes into the instruction's
+  // Per-lane LDS addresses of the transposing reads.  Row r = r_l + 16h + 32*ks + shift(tap); the XOR swizzle key uses
+  // bits 1 and 2 of r, which 16h and 32*ks do not touch: ONE address per tap, h and the k step go into the instruction's
   // immediate offset, and co tile i is tile 0 XOR 32*i (granule bits 1, 2 of the address are otherwise only keyed).
-  const int r_l = 8 * grp + qq;
+  const int r_l = 4 * fgp + qq;
   const int sub8 = (pp & 1) * 8;
-  int a_addr[2];                           // dy tile, co tile 0, h = 0 / 1 (relative to the stage base)
+  const int a_addr = WH_XBYTES + r_l * 128 + (((pp >> 1) ^ whswz(r_l)) * 16) + sub8;     // dy tile, co tile 0
+  int b_addr[9];                           // window, this wave's ci tile, per tap (relative to the stage base)
 #pragma unroll
-  for (int h = 0; h < 2; ++h) { const int r = r_l + 4 * h; a_addr[h] = WH_XBYTES + r * 128 + (((pp >> 1) ^ whswz(r)) * 16) + sub8; }
-  int b_addr[9][2];                        // window, this wave's ci tile, per tap and h (relative to the stage base)
-#pragma unroll
-  for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = r_l + 4 * h + (t9 / 3) * g.Wp + (t9 % 3);
-      b_addr[t9][h] = r * 128 + (((2 * wave + (pp >> 1)) ^ whswz(r)) * 16) + sub8;
-    }
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int r = r_l + (t9 / 3) * g.Wp + (t9 % 3);
+    b_addr[t9] = r * 128 + (((2 * wq + (pp >> 1)) ^ whswz(r)) * 16) + sub8;
+  }
   // Transposing reads are inline asm with hand-counted lgkmcnt waits: hipcc guards every LDS read it can see with
   // s_waitcnt vmcnt(0) while an LDS-DMA is in flight (it cannot know the DMA fills the OTHER stage), which would put
-  // each of the next item's 20 DMA pieces' full latency into this item's MFMA stream.
+  // each of the next item's DMA pieces' full latency into this item's MFMA stream.
   const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)(smem);
+  const unsigned kofs = (unsigned)(grp * TRIPS * 2 * 4096);       // first k step of this wave's group
 #define WH_TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 
-  while (pt < g.total) {
-    const int nxt = next_valid(pt + g.gk);
+  while (pt < i_end) {
+    const int nxt = next_valid(pt + i_step);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this item's tiles landed
     __syncthreads();                                       // ... for every wave; the other stage is no longer being read
-    const bool has_next = nxt < g.total;
+    const bool has_next = nxt < i_end;
     if (has_next) prepare(nxt);
-    // 72 steps (8 k steps x 9 taps) as 4 trips of 18: static register slots (A double buffer by k-step parity, B ring of
-    // 3), the trip's k base lives in the address registers, the k step inside a trip in the immediate offset.
-    // Operands are fetched two steps ahead; the last trip's look-ahead reads fall beyond the tiles (harmless, never
-    // used) so that the hand-counted waits stay the same on every trip.
-    unsigned pa[2], pb[9][2];
-    const unsigned st = lds0 + (unsigned)(cur * WH_STAGE);
+    // 72 steps (8 k steps x 9 taps) as trips of 18 (4 per wave at NW = 4, 2 at NW = 8): static register slots (A double buffer
+    // by k-step parity, B ring of 3), the trip's k base lives in the address registers, the k step inside a trip in the
+    // immediate offset.  Operands are fetched two steps ahead; the last trip's look-ahead reads fall beyond the wave's k steps
+    // (harmless, never used) so that the hand-counted waits stay the same on every trip.
+    unsigned pa, pb[9];
+    const unsigned st = lds0 + (unsigned)(cur * WH_STAGE) + kofs;
+    pa = st + (unsigned)a_addr;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) pa[h] = st + (unsigned)a_addr[h];
-#pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) pb[t9][h] = st + (unsigned)b_addr[t9][h];
+    for (int t9 = 0; t9 < 9; ++t9) pb[t9] = st + (unsigned)b_addr[t9];
     wh_s16x4 va[2][4][2], vb[3][2];                        // [slot][co tile][h], [slot][h]
 #define WH_READ_A(KSL, SLOT) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { \
-      WH_TR_READ(va[SLOT][i_][0], pa[0] ^ (unsigned)(i_ * 32), (KSL) * 4096); \
-      WH_TR_READ(va[SLOT][i_][1], pa[1] ^ (unsigned)(i_ * 32), (KSL) * 4096); } } while (0)
-#define WH_READ_B(LSTEP, SLOT) do { WH_TR_READ(vb[SLOT][0], pb[(LSTEP) % 9][0], ((LSTEP) / 9) * 4096); \
-                                    WH_TR_READ(vb[SLOT][1], pb[(LSTEP) % 9][1], ((LSTEP) / 9) * 4096); } while (0)
+      WH_TR_READ(va[SLOT][i_][0], pa ^ (unsigned)(i_ * 32), (KSL) * 4096); \
+      WH_TR_READ(va[SLOT][i_][1], pa ^ (unsigned)(i_ * 32), (KSL) * 4096 + 2048); } } while (0)
+#define WH_READ_B(LSTEP, SLOT) do { WH_TR_READ(vb[SLOT][0], pb[(LSTEP) % 9], ((LSTEP) / 9) * 4096); \
+                                    WH_TR_READ(vb[SLOT][1], pb[(LSTEP) % 9], ((LSTEP) / 9) * 4096 + 2048); } while (0)
     WH_READ_A(0, 0);
     WH_READ_B(0, 0);
     WH_READ_B(1, 1);
     int piece = 0;
-    for (int trip = 0; trip < 4; ++trip) {
+    for (int trip = 0; trip < TRIPS; ++trip) {
 #pragma unroll
       for (int ls = 0; ls < 18; ++ls) {
         const int ksl = ls / 9, t9 = ls % 9;
@@ -170,9 +194,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, co
 #undef WH_CASE
           default: break;
         }
-        // next item's tiles: 20 DMA pieces on the odd steps of the first trips, so the last one is >= 1.5 trips old
-        // when the item ends
-        if (has_next && (ls & 1) && piece < WH_XPASS + WH_DYPASS) { issue_piece(piece, cur ^ 1); ++piece; }
+        // next item's tiles.  NW = 4: 20 DMA pieces on the odd steps of the first trips, so the last one is >= 1.5 trips old
+        // when the item ends.  NW = 8: 10 pieces per wave, all in the first of its two trips (odd steps and step 16): a whole trip
+        // (>= 1150 cycles of MFMA work) lies between the last issue and the next item's wait.
+        const bool islot = NW == 4 ? ((ls & 1) != 0) : (trip == 0 && ((ls & 1) != 0 || ls == 16));
+        if (has_next && islot && piece < NP) { issue_piece(piece, cur ^ 1); ++piece; }
         // this step's operands were issued two steps ago: everything younger may stay in flight
         const int y1 = ((ls + 1) % 9 == 0) ? 10 : 2;       // reads issued by the previous step
         const int y0 = ((ls + 2) % 9 == 0) ? 10 : 2;       // ... and by this one
@@ -193,12 +219,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, co
         }
       }
       // next trip: two k steps further
+      pa += 8192u;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) pa[h] += 8192u;
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) pb[t9][h] += 8192u;
+      for (int t9 = 0; t9 < 9; ++t9) pb[t9] += 8192u;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // drain the unused look-ahead reads before the stage is reused
     pt = nxt;
@@ -208,8 +231,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, co
 #undef WH_READ_B
 #undef WH_TR_READ
 
-  // ---- slab store: [block][tap][co][ci], D row = co (16*i + (lane>>4)*4 + r), col = ci (16*wave + (lane & 15)) ----
-  float* slab = slabs + (long)blockIdx.x * WH_SLAB;
+  if constexpr (NW == 8) {
+    // ---- the k-step halves of a SIMD pair: waves 4-7 hand their 144 partial sums per lane over through LDS (4 x 36 KB, the
+    // stages are dead), waves 0-3 add them in a fixed order ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);           // [ci tile][register][lane]
+    if (grp == 1) {
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wq * 144 + (t9 * 4 + i) * 4 + r) << 6) + lane] = acc[t9][i][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t9][i][r] += red[((wq * 144 + (t9 * 4 + i) * 4 + r) << 6) + lane];
+  }
+  // ---- slab store: [slot * 3 + kt][tap][co][ci], D row = co (16*i + (lane>>4)*4 + r), col = ci (16*wq + (lane & 15)) ----
+  float* slab = slabs + (long)lin * WH_SLAB;
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
@@ -217,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo64_kernel(const WHGeom g, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = i * 16 + (lane >> 4) * 4 + r;
-        const int ci = wave * 16 + (lane & 15);
+        const int ci = wq * 16 + (lane & 15);
         slab[(t9 * 64 + co) * 64 + ci] = acc[t9][i][r];
       }
 }
@@ -259,7 +304,8 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
     int dev = 0; (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   int gk = cus / 3;
@@ -267,8 +313,11 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   if (ws == nullptr || (long)gk * 3 * WH_SLAB > ws_floats) gk = (int)(ws ? ws_floats / (3L * WH_SLAB) : 0);
   if (gk < 1) return 0;
   g.gk = gk;
-  g.dWp = make_fastdiv(g.Wp); g.dTiles = make_fastdiv(g.tiles); g.dT = make_fastdiv(d->T);
-  hipLaunchKernelGGL(wgrad_halo64_kernel, dim3((unsigned)(3 * gk)), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
+  g.planes = d->N * d->T;
+  g.dWp = make_fastdiv(g.Wp); g.dTiles = make_fastdiv(g.tiles); g.dT = make_fastdiv(d->T); g.dPlanes = make_fastdiv(g.planes);
+  static MsclTune t_nw("MSCL_WGRAD_HALO_WAVES");            // 8 (default): two waves per SIMD; 4: the round-3 form
+  if (t_nw.get(8) == 4) hipLaunchKernelGGL(wgrad_halo64_kernel<4>, dim3((unsigned)(3 * gk)), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
+  else hipLaunchKernelGGL(wgrad_halo64_kernel<8>, dim3((unsigned)(3 * gk)), dim3(512), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
   MSCL_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((27 * 4096 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, gk);
   MSCL_LAUNCH_CHECK();

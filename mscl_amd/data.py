@@ -311,6 +311,14 @@ class ClipPairLoader:
                 if slot.event is not None:
                     slot.event.synchronize()
                 slot.free.set()
+        # whoever still holds this epoch's generator finds ONE word in its queue: "retired" (the drain above may have eaten the
+        # filler's own, and a consumer must never block on a queue nobody fills)
+        while True:
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                break
+        q.put_nowait(_RETIRED)
         if getattr(self, '_active', None) is st:
             self._active = None
 

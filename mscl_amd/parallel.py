@@ -164,6 +164,44 @@ def _sum_then_scale():
     return dist.get_backend() != 'nccl'
 
 
+@torch.no_grad()
+def grad_rs_ag(seg, pad=None, async_op=False):
+    """`mscl_grad_rs_ag` of SURVEY.md section 8(b) / 5.8: the gradient SUM of one arena bucket as an explicit reduce-scatter +
+    all-gather pair over the process group instead of one all-reduce (reference: the DDP reducer wired at
+    mmaction/apis/train.py:84-88).  Each rank ends up owning the sum of its 1/W share (reduce-scatter), then every rank collects
+    all shares (all-gather): on a point-to-point xGMI mesh both halves can run as direct exchanges between every pair of GPUs
+    over all 7 links at once, where a ring all-reduce is paced by one link.  The bucket is padded to a multiple of W in a
+    scratch buffer (`pad`: reused between steps).  Selected with MSCL_GRAD_COLLECTIVE=rs_ag (GradReducer); the default stays
+    all_reduce until an 8-GPU node has measured the two against each other.  Returns (handle | None, scratch): the caller copies
+    scratch[:n] back into `seg` after waiting (async) -- or gets `seg` updated in place (sync).
+    gloo (CPU tests) has no reduce-scatter: W reduces, one per share, stand in for it."""
+    W, r = world_size(), rank()
+    n = seg.numel()
+    share = (n + W - 1) // W
+    if pad is None or pad.numel() < share * W or pad.dtype != seg.dtype or pad.device != seg.device:
+        pad = torch.empty(share * W, dtype=seg.dtype, device=seg.device)
+    buf = pad[:share * W]
+    buf[:n].copy_(seg.reshape(-1))
+    if share * W > n:
+        buf[n:].zero_()
+    mine = buf[r * share:(r + 1) * share]
+    if dist.get_backend() == 'nccl':
+        # both halves asynchronous: they run in order on the communicator's stream, and a synchronous call would make the
+        # calling (backward) stream wait for the wire
+        dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, async_op=True)       # the own share of buf receives the sum
+        h = dist.all_gather_into_tensor(buf, mine, async_op=True)
+        if not async_op:
+            h.wait()
+    else:
+        for d in range(W):
+            dist.reduce(buf[d * share:(d + 1) * share], dst=d, op=dist.ReduceOp.SUM)
+        h = dist.all_gather(list(buf.chunk(W)), mine.clone(), async_op=async_op)
+    if not async_op:
+        seg.reshape(-1).copy_(buf[:n])
+        return None, pad
+    return h, pad
+
+
 class GradReducer:
     """Bucketed, overlapped mean all-reduce of the flat gradient arena.
 
@@ -173,7 +211,7 @@ class GradReducer:
     while backward continues with the earlier layers; `finish()` waits for all of them before the optimizer.
     Layer 4 alone is 100 MB of the 150 MB: it is reduced under the whole layer3..stem backward."""
 
-    def __init__(self, flat, ranges, need=None, transport=None):
+    def __init__(self, flat, ranges, need=None, transport=None, collective=None):
         """transport: 'fp32' (default: the reference's DDP averages fp32 gradients) or 'bf16' (MSCL_GRAD_TRANSPORT=bf16): each
         bucket travels as bf16 -- half the bytes over the xGMI links, 75 instead of 150 MB per step -- and is widened and
         averaged on arrival.  Every rank receives the same sums, so the replicas stay bit-identical; the values differ from the
@@ -186,6 +224,14 @@ class GradReducer:
         self.transport = transport or os.environ.get('MSCL_GRAD_TRANSPORT', 'fp32')
         if self.transport not in ('fp32', 'bf16'):
             raise ValueError(f'gradient transport {self.transport!r}: fp32 or bf16')
+        # all_reduce (default) | rs_ag: the explicit reduce-scatter + all-gather pair (grad_rs_ag), to A/B on a multi-GPU node
+        self.collective = collective or os.environ.get('MSCL_GRAD_COLLECTIVE', 'all_reduce')
+        if self.collective not in ('all_reduce', 'rs_ag'):
+            raise ValueError(f'gradient collective {self.collective!r}: all_reduce or rs_ag')
+        self._pads = {}
+        # measurement aid (bench.py, "exposed_wire_ms_measured"): buckets are not sent at all -- the replicas then drift apart,
+        # so only ever for a few timed steps at the very end of a run
+        self.skip = False
 
     def bucket_done(self, i, force=False):
         if single() or i in self.launched:
@@ -194,9 +240,16 @@ class GradReducer:
         if self.hits[i] < self.need[i] and not force:
             return                                  # e.g. the flow trunk is traversed twice per step
         self.launched.add(i)
+        if self.skip:
+            return
         a, b = self.ranges[i]
         seg = self.flat[a:b]
-        if self.transport == 'bf16':
+        if self.collective == 'rs_ag':
+            src = seg.to(torch.bfloat16) if self.transport == 'bf16' else seg
+            h, self._pads[i] = grad_rs_ag(src, self._pads.get(i), async_op=True)
+            n = seg.numel()
+            self.works.append((h, seg, self._pads[i][:n]))         # finish(): seg <- sums / W
+        elif self.transport == 'bf16':
             buf = seg.to(torch.bfloat16)
             self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), seg, buf))
         elif _sum_then_scale():

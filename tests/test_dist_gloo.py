@@ -34,15 +34,36 @@ def _worker(rank, world, port, q):
         parallel.allreduce_mean_(g, bucket_elems=300)
         assert torch.allclose(g, torch.full((1000,), (1 + world) * world / 2 / world))
         # bucketed reducer, fp32 and bf16 transport: the mean on every rank, identical across ranks
-        for transport, tol in (('fp32', 0.0), ('bf16', 2 ** -7)):
-            flat = torch.linspace(-3.0, 5.0, 1000) * (rank + 1)
-            want = torch.linspace(-3.0, 5.0, 1000) * (1 + world) / 2
-            red = parallel.GradReducer(flat, [(600, 1000), (0, 600)], need=[1, 2], transport=transport)
+        # ... and with the explicit reduce-scatter + all-gather pair in place of the all-reduce (`mscl_grad_rs_ag`; bucket
+        # sizes that do not divide by the world size exercise its padding)
+        for transport, tol, coll in (('fp32', 0.0, 'all_reduce'), ('bf16', 2 ** -7, 'all_reduce'), ('fp32', 0.0, 'rs_ag'),
+                                     ('bf16', 2 ** -7, 'rs_ag')):
+            flat = torch.linspace(-3.0, 5.0, 1001)[:1000] * (rank + 1)
+            want = torch.linspace(-3.0, 5.0, 1001)[:1000] * (1 + world) / 2
+            red = parallel.GradReducer(flat, [(601, 1000), (0, 601)], need=[1, 2], transport=transport, collective=coll)
             red.bucket_done(0); red.bucket_done(1); red.bucket_done(1)           # the second bucket needs two trigger calls
             red.finish()
-            assert torch.allclose(flat, want, rtol=tol, atol=1e-6 + tol * 0.01), (transport, float((flat - want).abs().max()))
+            assert torch.allclose(flat, want, rtol=tol, atol=1e-6 + tol * 0.01), (transport, coll, float((flat - want).abs().max()))
             both = parallel.all_gather_cat(flat[None])
-            assert torch.equal(both[0], both[1]), transport
+            assert torch.equal(both[0], both[1]), (transport, coll)
+            red.bucket_done(0); red.bucket_done(1); red.bucket_done(1); red.finish()      # a second step reuses the padded scratch
+        # bench.py's "rccl" object (what a driver verifies an N-rank line with): its shape under this 2-rank group
+        import sys
+        import types
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        six = parallel.GradReducer(torch.zeros(6000), [(i * 1000, (i + 1) * 1000) for i in range(6)])
+        info = bench.rccl_probe(torch.device('cpu'), world, types.SimpleNamespace(reducer=six))
+        assert info['backend'] == 'gloo' and info['world_size'] == world and info['ranks_seen'] == list(range(world))
+        assert info['allreduce_busbw_GBps'] > 0 and info['allreduce_100MB_ms'] > 0
+        assert info['grad_collective'] == 'all_reduce' and info['grad_transport'] == 'fp32' and len(info['grad_buckets_MB']) == 6
+        assert isinstance(info['exposed_wire_ms_model'], float)
+        import json as _json
+        _json.dumps(info)
+        # the stand-alone form: the sum of a bucket, in place
+        seg = torch.arange(7, dtype=torch.float32) * (rank + 1)
+        parallel.grad_rs_ag(seg)
+        assert torch.equal(seg, torch.arange(7, dtype=torch.float32) * (1 + world) * world / 2)
         # replicated queue: the oracle's enqueue under 2 ranks keeps queue/ptr/count identical everywhere
         rec = om.MoCoV2('flow', 128, K=16, max_iters=100)
         with torch.no_grad():
