@@ -79,6 +79,10 @@ int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int 
  * applies, the per-split slabs of deterministic mode otherwise (0: none needed) */
 int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias);
 int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
+/* floats of workspace the window-resident weight-gradient kernel wants (conv_wgrad_halo.hip: one 9 x 64 x 64 partial per block,
+ * added in slot order); 0 = the layer is not one of its shapes (3x3x3 / 1 / 1, channels multiples of 64, planes that fill
+ * 256-position tiles).  Included in mscl_conv3d_wgrad_ws. */
+int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d);
 /* floats of workspace the window-resident weight-gradient kernel of the 1x3x3 16- / 32-channel layers wants (conv_thin.hip: one
  * 9 x K x C partial per block, added in block order); 0 = the layer is not one of them.  Included in mscl_conv3d_wgrad_ws. */
 int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);

@@ -23,6 +23,12 @@
 // index mod 4), 2 position slots:
 //   issue for group g+1:   Q0: A0' A1'   Q1: B0' B1'   Q2: B2'
 //   waits:  Q0: B1 (of g) landed = vmcnt(UB + 4)   Q1: B2 landed = vmcnt(2 UB + 4)   Q2: A0', A1', B0' landed = vmcnt(2 UB)
+// Round 4, measured and dropped: issuing the DMA pieces from the M section instead of L -- after the MFMAs (in the time a wave
+// otherwise spends at the closing barrier) or ahead of them -- with the waits left in L and their counts lowered by the pieces no
+// longer ahead of them.  Every shape lost 1-8 % (A/B in one process: 128 -> 128 forward 46.1 vs 50.0 / 50.5 us, input gradient
+// 42.1 vs 45.2 / 45.4; 256 -> 256 37.5 vs 39.0 / 39.3; 512 -> 512 28.8 vs 29.8 / 29.2): the L section is not what the pieces'
+// issue cost lengthens -- a piece issued half a phase later lands half a phase later, and the counted waits of the next L
+// sections then find it still in flight.
 #include "igemm.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -33,12 +39,7 @@ template <int N> struct IC { static constexpr int value = N; };
 #define PP_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
 #define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
 
-// LATE: where a wave issues its share of the next group's LDS-DMA.  0: in its L section, before the counted wait (the round-3
-// schedule).  1: after the MFMAs of its M section, i.e. in the time it would otherwise spend at the closing barrier waiting for
-// its SIMD partner's (longer) L section -- the DMA instructions cost their wave 100-185 issue cycles each beside 16 fragment reads
-// (MI355X_MICROARCH.md, LDS-DMA piece issue cost) and L, not M, sets the phase length.  2: at the head of the M section.  The waits
-// stay in L; their counts drop by the pieces that section no longer issues ahead of them.
-template <int BN, int LATE>
+template <int BN>
 __global__ __launch_bounds__(512) void conv_pp_kernel(
     const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
     const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
@@ -209,15 +210,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
       PP_DSR(fb[ks][0], ba, 0); PP_DSR(fb[ks][1], ba, 2048); PP_DSR(fb[ks][2], ba, 4096); PP_DSR(fb[ks][3], ba, 6144);
     }
     if (has_next) {
-      if constexpr (LATE == 0) {
-        if constexpr (kw == 0) { issue_a(0, a_nxt, soff_n, tb_n); issue_a(1, a_nxt, soff_n, tb_n); PP_VMCNT(UB + 4); }
-        if constexpr (kw == 1) { issue_b(bn0 * B_SLOT, woff_n); issue_b(bn1 * B_SLOT, woff_n + wstep); PP_VMCNT(2 * UB + 4); }
-        if constexpr (kw == 2) { issue_b(bn2 * B_SLOT, woff_n + 2 * wstep); PP_VMCNT(2 * UB); }
-      } else {           // the pieces of this phase are issued in M (Isec): the same units are waited for, fewer may stay in flight
-        if constexpr (kw == 0) PP_VMCNT(UB);
-        if constexpr (kw == 1) PP_VMCNT(4);
-        if constexpr (kw == 2) PP_VMCNT(UB);
-      }
+      if constexpr (kw == 0) { issue_a(0, a_nxt, soff_n, tb_n); issue_a(1, a_nxt, soff_n, tb_n); PP_VMCNT(UB + 4); }
+      if constexpr (kw == 1) { issue_b(bn0 * B_SLOT, woff_n); issue_b(bn1 * B_SLOT, woff_n + wstep); PP_VMCNT(2 * UB + 4); }
+      if constexpr (kw == 2) { issue_b(bn2 * B_SLOT, woff_n + 2 * wstep); PP_VMCNT(2 * UB); }
     } else {
       if constexpr (kw == 0) PP_VMCNT(UB);
       if constexpr (kw == 1) PP_VMCNT(0);
@@ -233,19 +228,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
                      "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
     __builtin_amdgcn_sched_barrier(0);
   };
-  // ---- this phase's share of the next group's DMA, issued from the M section (LATE != 0) ----
-  auto Isec = [&](auto PC) {
-    constexpr int kw = decltype(PC)::value;
-    if (!has_next) return;
-    const unsigned a_nxt = a_cur ^ (unsigned)A_SLOT;
-    const unsigned bs1 = (bq + 1) & 3, bn0 = (bq + 3) & 3, bn1 = bq, bn2 = bs1;
-    if constexpr (kw == 0) { issue_a(0, a_nxt, soff_n, tb_n); issue_a(1, a_nxt, soff_n, tb_n); }
-    if constexpr (kw == 1) { issue_b(bn0 * B_SLOT, woff_n); issue_b(bn1 * B_SLOT, woff_n + wstep); }
-    if constexpr (kw == 2) { issue_b(bn2 * B_SLOT, woff_n + 2 * wstep); }
-  };
   // ---- M: one WM x 64 x 64 product from the fragments the last L section read ----
-  auto Msec = [&](auto PC) {
-    if constexpr (LATE == 2) { Isec(PC); __builtin_amdgcn_sched_barrier(0); }
+  auto Msec = [&]() {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -257,7 +241,6 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
                                                               __builtin_bit_cast(bf16x8_t, fa[ks][i]), acc[j][i], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LATE == 1) { Isec(PC); __builtin_amdgcn_sched_barrier(0); }
   };
   const int ng = g_end - g_beg;
   // Two barriers per phase: [L | barrier | M | barrier], waves 4-7 one barrier behind.  (Measured and dropped: ONE barrier per
@@ -266,9 +249,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   // the barrier between the sections the partners of a SIMD drift into loading together and multiplying together.)
   if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int n = 0; n < ng; ++n) {
-    Lsec(IC<0>{}); __builtin_amdgcn_s_barrier(); Msec(IC<0>{}); __builtin_amdgcn_s_barrier();
-    Lsec(IC<1>{}); __builtin_amdgcn_s_barrier(); Msec(IC<1>{}); __builtin_amdgcn_s_barrier();
-    Lsec(IC<2>{}); __builtin_amdgcn_s_barrier(); Msec(IC<2>{}); __builtin_amdgcn_s_barrier();
+    Lsec(IC<0>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
+    Lsec(IC<1>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
+    Lsec(IC<2>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
     advance();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with the last barrier of waves 4-7
@@ -332,21 +315,16 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
   float* partial = g.ksplit > 1 ? ws : nullptr;
   const size_t lds = 4 * (size_t)BN * 128 + 2 * 256 * 128;
   const bool n64 = BN == 64;
-  static MsclTune t_late("MSCL_PP_LATE");
-  int late = t_late.get(0);
-  if (late < 0 || late > 2) late = 0;
-  static bool attr_done[6] = {false, false, false, false, false, false};    // per kernel (the instantiations share ONE lambda body)
+  static bool attr_done[2] = {false, false};    // per kernel (both instantiations have the same function type: ONE lambda body)
   auto go = [&](auto kern) {
-    if (!attr_done[late * 2 + n64]) {
+    if (!attr_done[n64]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done[late * 2 + n64] = true;
+      attr_done[n64] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(512), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu,
                        partial);
   };
-  if (late == 0) { if (n64) go(conv_pp_kernel<64, 0>); else go(conv_pp_kernel<128, 0>); }
-  else if (late == 1) { if (n64) go(conv_pp_kernel<64, 1>); else go(conv_pp_kernel<128, 1>); }
-  else { if (n64) go(conv_pp_kernel<64, 2>); else go(conv_pp_kernel<128, 2>); }
+  if (n64) go(conv_pp_kernel<64>); else go(conv_pp_kernel<128>);
   MSCL_LAUNCH_CHECK();
   ++g_pp_launches;
   if (g.ksplit > 1) return mscl_launch_splitk_finalize(partial, out, bias, addend, relu, ssum, ssq, out_elems / g.Cr, g.Cr, g.ksplit, 0, st);

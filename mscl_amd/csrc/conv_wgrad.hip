@@ -434,7 +434,10 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   g.dWo = make_fastdiv(d->Wo); g.dHo = make_fastdiv(d->Ho); g.dTo = make_fastdiv(d->To);
   hipStream_t st = (hipStream_t)stream;
   int e;
-  const int hres = ws != nullptr ? mscl_wgrad_halo64(d, x, dy, dw, ws, ws_floats, st) : 0;   // layer-1 shape, window-resident
+  // 3x3x3 / 1 / 1 layers whose planes fill 256-position tiles: window-resident kernel on 64 x 64 channel slices (its slabs are
+  // added in slot order: deterministic as it stands); the tail of `ws` stays free for deterministic mode's bias partials
+  const long btail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
+  const int hres = (ws != nullptr && ws_floats > btail) ? mscl_wgrad_halo64(d, x, dy, dw, ws, ws_floats - btail, st) : 0;
   if (hres < 0 || hres > 1) return hres;
   // deterministic mode: `ws` doubles as the slab workspace of the general kernel ([splits][K][ncols] floats) and, behind it,
   // the partial column sums of the bias gradient ([MSCL_DET_PARTS][K]); mscl_conv3d_wgrad_ws() gives the size to pass
@@ -491,9 +494,11 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
 // the bias partials); 0 outside deterministic mode for layers that do not use the window-resident kernel
 extern "C" int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);
+extern "C" int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) {
   if (!d) return 0;
-  int64_t pp = wgrad_pp_enabled(d) ? mscl_wgrad_pp_ws(d) : 0;
+  int64_t pp = mscl_wgrad_halo_ws(d);
+  if (pp == 0 && wgrad_pp_enabled(d)) pp = mscl_wgrad_pp_ws(d);
   if (pp == 0) pp = mscl_wgrad_thin_ws(d);
   if (!mscl_det()) return pp;
   if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_DET_PARTS * d->K : 0);

@@ -1,37 +1,45 @@
-// Weight gradient of the layer-1 convolution (3x3x3 / stride 1 / pad 1, 64 -> 64) with the input window resident in
-// LDS:  dW[co][kt][a][b][ci] = sum over positions of dy[pos][co] * x[plane t+kt-1][pos + (a-1, b-1)][ci].
+// Weight gradient of the 3x3x3 / stride 1 / pad 1 convolutions with the input window resident in LDS (layer 1: 64 -> 64 on
+// 56 x 56 planes; since round 4 also the 128 -> 128 layers on 28 x 28 planes and the 256 -> 256 layers on 14 x 14 planes, as
+// 64 x 64 channel slices):  dW[co][kt][a][b][ci] = sum over positions of dy[pos][co] * x[plane t+kt-1][pos + (a-1, b-1)][ci].
+// Reference op: the weight gradient autograd computes for Conv3DSimple / BasicBlock (mmaction/models/backbones/r3d.py:16-34,
+// 95-127) and the SEPC PConv3D convolutions (necks/sepc.py:57-135).
 //
 // Why: the general kernel (conv_wgrad.hip) re-stages the x rows once per tap; at 64 x 64 channels a step stages 16 KB
-// for 32 MFMAs = 128 B per MFMA-clock of a CU, twice what the global -> LDS path delivers: 254 us = 350 TFLOP/s.
-// Here a block walks (plane tile, kt) items of ONE kt: per item it stages the 376-row window of the source plane
-// (padded-linear order, see conv_halo.hip) and the 256-position dy tile ONCE (79 KB) and runs all 9 in-plane taps
-// against them, 1152 MFMAs: 69 B per MFMA.  The 9 x 64 x 64 partial products stay in registers (144 accumulators per
-// lane) over all items of the block; at the end every block stores its slab with plain stores and a small second kernel
+// for 32 MFMAs = 128 B per MFMA-clock of a CU, twice what the global -> LDS path delivers: 254 us = 350 TFLOP/s on layer 1.
+// Here a block walks (plane tile, kt) items of ONE kt and ONE (64 co, 64 ci) channel slice: per item it stages the 376-row
+// window of the source plane (padded-linear order, see conv_halo.hip) and the 256-position dy tile ONCE (79 KB) and runs all 9
+// in-plane taps against them, 1152 MFMAs: 69 B per MFMA.  The 9 x 64 x 64 partial products stay in registers (144 accumulators
+// per lane) over all items of the block; at the end every block stores its slab with plain stores and a small second kernel
 // adds the slabs into dW (float atomics of 147 KB per block would cost more than the GEMM, MI355X_MICROARCH.md).
 //  * both operands are position-major, so fragments are column reads: ds_read_b64_tr_b16 (as conv_wgrad.hip);
 //  * pad columns / rows outside the plane are zero in BOTH tiles (buffer range check), so they add nothing;
 //  * items are double-buffered in LDS (2 x 79 KB): the next item's DMA pieces are issued between the k steps.
-// Round 4 (NW = 8, the default): the round-3 form ran ONE wave per SIMD whose single instruction stream also issued the 20 DMA
-// pieces of the next item (60-180 issue cycles each) and waited on its own transposing reads: 6.3 us per item against 1.9 us of
-// MFMA work, 12 GB/s per CU of fill -- neither roof.  Now two waves per SIMD split the k steps of an item (waves 4-7 take
-// positions 128-255 of the tile with a full set of 144 accumulators of their own; the pairs are added through LDS once, at the
-// end of the block), so one wave's DMA issue and read latencies are covered by its partner's MFMAs, and each wave issues half
-// the pieces.  Items are walked tile-major (consecutive planes of one plane tile) and the three kt blocks of a slot get consecutive
-// logical ids on one XCD: the dy tile is fetched by all three at the same time and an x plane at three consecutive items, so
-// beyond the XCD's L2 both maps are read about once instead of three times (393 -> ~180 MB per launch against 103 algorithmic).
+// Round 4: (1) the round-3 form ran ONE wave per SIMD whose single instruction stream also issued the 20 DMA pieces of the next
+// item (60-180 issue cycles each) and waited on its own transposing reads: 6.3 us per item against 1.9 us of MFMA work, 12 GB/s
+// per CU of fill -- neither roof.  Now two waves per SIMD split the k steps of an item (waves 4-7 take positions 128-255 of the
+// tile with a full set of 144 accumulators of their own; the pairs are added through LDS once, at the end of the block), so one
+// wave's DMA issue and read latencies are covered by its partner's MFMAs, and each wave issues half the pieces: layer 1
+// 128.3 -> 97.9 us (A/B in one process).  (2) Items are walked tile-major (consecutive planes of one plane tile) and the blocks
+// of a slot -- its three kt, and its channel slices -- get consecutive logical ids on one XCD: a dy tile is fetched by all of
+// them at the same time and an x plane at three consecutive items, so beyond the XCD's L2 both maps are read about once instead
+// of three times.  (3) The reduction rows of a k step are dealt to the lanes so that the second read of a fragment and the k step
+// are immediate offsets (whswz): 10 address registers fewer, which is what lets 144 accumulators fit two waves per SIMD.
+// (4) Channel slices: a layer with C / K multiples of 64 runs as (K/64) x (C/64) independent 64 x 64 problems on the same
+// positions (row pitch = the map's channel count): the 128-channel layers of the step (four 256-position tiles per 28 x 30
+// padded plane: 82 % of the tile rows live) and the 256-channel layers (one tile per 14 x 16 plane: 87 %).
 #include "common.h"
 #include <cstdlib>
 
 struct WHGeom {
   int N, T, H, W, HW, Wp, tiles;   // tiles per plane (256 padded-linear positions each)
   int total;                        // plane tiles = N * T * tiles
-  int gk;                           // blocks per kt
+  int gk;                           // slots: blocks per (kt, channel slice)
   int planes;                       // N * T
+  int C, K, ncs, nsub;              // channels of x / dy; ci slices (C / 64); blocks per slot = 3 * (K/64) * (C/64)
   FastDiv dWp, dTiles, dT, dPlanes;
 };
 
 constexpr int WH_XROWS = 376, WH_XBYTES = WH_XROWS * 128, WH_DYBYTES = 256 * 128, WH_STAGE = WH_XBYTES + WH_DYBYTES;
-constexpr int WH_XPASS = 12, WH_DYPASS = 8;
 constexpr unsigned WH_OOB = 0x80000000u;
 constexpr int WH_SLAB = 9 * 64 * 64;
 
@@ -51,7 +59,8 @@ typedef __attribute__((address_space(3))) void* wh_lds_t;
 typedef __attribute__((ext_vector_type(4))) short wh_s16x4;
 typedef __attribute__((ext_vector_type(8))) short wh_s16x8;
 
-// NW = waves per block: 4 = one per SIMD (round 3), 8 = two per SIMD that split the k steps of every item (see the header)
+// NW = waves per block: 8 = two per SIMD that split the k steps of every item (see the header); 4 = one per SIMD, the round-3
+// form, kept as the A/B arm (MSCL_WGRAD_HALO_WAVES=4; 64 -> 64 only)
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g, const bf16_t* __restrict__ x,
                                                                   const bf16_t* __restrict__ dy, float* __restrict__ slabs) {
@@ -66,7 +75,9 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
   const int wq = wave & 3, grp = wave >> 2;                // ci tile of the wave; k-step group
   // the three kt blocks of a slot: consecutive logical ids = one XCD (its L2 then serves two of the three reads of every tile)
   const int lin = NW == 8 ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int kt = lin % 3, slot = lin / 3;
+  const int sub = lin % g.nsub, slot = lin / g.nsub;       // sub = (co slice * ncs + ci slice) * 3 + kt
+  const int kt = sub % 3, cs = (sub / 3) % g.ncs, kslice = sub / (3 * g.ncs);
+  const int c2 = g.C * 2, k2 = g.K * 2;                    // row pitch of x / dy in bytes
   const auto rs_x = wh_rsrc(x);
   const auto rs_dy = wh_rsrc(dy);
   // wave tile: all 64 co x ci [16*wq, +16): one B fragment per step feeds 4 MFMAs (a 32 x 32 tile needs twice the
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
   // Consecutive pieces advance a row's padded-linear position by RPP (no per-piece offset arrays: they would need dynamic
   // register indexing); the swizzle key of a row is unchanged by +32 / +64 (bits 1 and 2), so the lane's source granule is fixed.
   const int prow = tid >> 3, pg = tid & 7;
-  const unsigned xg = (unsigned)((pg ^ whswz(prow)) * 16), dg = xg;
+  const unsigned xg = (unsigned)((pg ^ whswz(prow)) * 16 + cs * 128), dg = (unsigned)((pg ^ whswz(prow)) * 16 + kslice * 128);
   int x_q = 0, d_q = 0;                                    // padded-linear position of the row of the NEXT piece of each kind
   unsigned xs = 0, ds = 0;
   auto prepare = [&](int it) {
@@ -108,22 +119,22 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
     const int q0 = g.Wp + tile * 256;
     x_q = q0 - g.Wp - 1 + prow;                            // >= -1
     d_q = q0 + prow;
-    xs = __builtin_amdgcn_readfirstlane((unsigned)((plane + kt - 1) * g.HW) * 128u);
-    ds = __builtin_amdgcn_readfirstlane((unsigned)(plane * g.HW) * 128u);
+    xs = __builtin_amdgcn_readfirstlane((unsigned)((plane + kt - 1) * g.HW) * (unsigned)c2);
+    ds = __builtin_amdgcn_readfirstlane((unsigned)(plane * g.HW) * (unsigned)k2);
   };
   auto issue_piece = [&](int k, int stage) {               // k (wave-uniform, runtime) in [0, NP), issued in order
     unsigned char* base = smem + stage * WH_STAGE;
     if (k < XP) {
       const int x_hp = fdiv(x_q < 0 ? 0 : x_q, g.dWp), x_wp = x_q - x_hp * g.Wp;
       const bool ok = x_q >= 0 && x_hp >= 1 && x_hp <= g.H && x_wp >= 1 && x_wp <= g.W;
-      const unsigned vo = ok ? (unsigned)(((x_hp - 1) * g.W + (x_wp - 1)) * 128) + xg : WH_OOB;
+      const unsigned vo = ok ? (unsigned)(((x_hp - 1) * g.W + (x_wp - 1)) * c2) + xg : WH_OOB;
       x_q += RPP;
       if (!(k == XP - 1 && wave == NW - 1))                // rows 376..383 do not exist
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (wh_lds_t)(base + (k * 64 * NW + wave * 64) * 16), 16, vo, xs, 0, 0);
     } else {
       const int d_hp = fdiv(d_q, g.dWp), d_wp = d_q - d_hp * g.Wp;
       const bool ok = d_hp <= g.H && d_wp >= 1 && d_wp <= g.W;
-      const unsigned vo = ok ? (unsigned)(((d_hp - 1) * g.W + (d_wp - 1)) * 128) + dg : WH_OOB;
+      const unsigned vo = ok ? (unsigned)(((d_hp - 1) * g.W + (d_wp - 1)) * k2) + dg : WH_OOB;
       d_q += RPP;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (wh_lds_t)(base + WH_XBYTES + ((k - XP) * 64 * NW + wave * 64) * 16), 16, vo, ds, 0, 0);
     }
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t9][i][r] += red[((wq * 144 + (t9 * 4 + i) * 4 + r) << 6) + lane];
   }
-  // ---- slab store: [slot * 3 + kt][tap][co][ci], D row = co (16*i + (lane>>4)*4 + r), col = ci (16*wq + (lane & 15)) ----
+  // ---- slab store: [slot * nsub + sub][tap][co][ci], D row = co (16*i + (lane>>4)*4 + r), col = ci (16*wq + (lane & 15)) ----
   float* slab = slabs + (long)lin * WH_SLAB;
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9)
@@ -267,59 +278,97 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
       }
 }
 
-// dw[co][kt*9 + t9][ci] += sum over the gk slabs of kt
-__global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int gk) {
-  const int e = blockIdx.x * 256 + threadIdx.x;            // e = ((kt*9 + t9) * 64 + co) * 64 + ci, 27*4096 elements
-  if (e >= 27 * 4096) return;
-  const int kt = e / (9 * 4096), rem = e - kt * (9 * 4096);
+// dw[co][kt*9 + t9][ci] += sum over the gk slabs of (kt, channel slice), in slot order.  One thread per element of dw.
+__global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int gk, int nsub,
+                                                                  int ncs, int C, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;     // e = (co * 27 + kt * 9 + t9) * C + ci
+  if (e >= total) return;
+  const int ci = (int)(e % C); const long r = e / C;
+  const int tap = (int)(r % 27), co = (int)(r / 27);
+  const int kt = tap / 9, t9 = tap - kt * 9;
+  const int sub = ((co >> 6) * ncs + (ci >> 6)) * 3 + kt;
+  const long rem = ((long)t9 * 64 + (co & 63)) * 64 + (ci & 63);
   float s4[4] = {0.f, 0.f, 0.f, 0.f};        // four independent chains: the loop is a string of dependent-latency loads otherwise
   int b = 0;
   for (; b + 4 <= gk; b += 4) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s4[u] += slabs[(long)((b + u) * 3 + kt) * WH_SLAB + rem];
+    for (int u = 0; u < 4; ++u) s4[u] += slabs[((long)(b + u) * nsub + sub) * WH_SLAB + rem];
   }
-  for (; b < gk; ++b) s4[0] += slabs[(long)(b * 3 + kt) * WH_SLAB + rem];
-  const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  const int t9 = rem >> 12, co = (rem >> 6) & 63, ci = rem & 63;
-  atomicAdd(&dw[(co * 27 + kt * 9 + t9) * 64 + ci], s);
+  for (; b < gk; ++b) s4[0] += slabs[((long)b * nsub + sub) * WH_SLAB + rem];
+  dw[e] += (s4[0] + s4[1]) + (s4[2] + s4[3]);               // one owner per element: a plain add, the same bits every run
 }
 
 static long g_wgrad_halo_launches = 0;
 extern "C" int64_t mscl_debug_wgrad_halo_launches(void) { return g_wgrad_halo_launches; }
 
-// returns 1 if launched, 0 if the shape / workspace is not covered, <0 / >0 on error
-int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
-                      hipStream_t st) {
-  if (d->C != 64 || d->K != 64 || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
-      d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
-  WHGeom g{};
-  g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
-  if (256 + 2 * g.Wp + 2 > WH_XROWS || (long)d->N * d->T * g.HW * 64 * 2 >= (1L << 31)) return 0;
-  if ((long)d->H * g.Wp < 1024) return 0;          // small planes: the general kernel
-  g.tiles = (d->H * g.Wp + 255) / 256;
-  g.total = d->N * d->T * g.tiles;
+static int wh_cus() {
   static int cus = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (cus == 0) {
     int dev = 0; (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+// which layers take this kernel: 3x3x3 / 1 / 1, channel counts multiples of 64, planes whose padded rows fit the 376-row window;
+// planes of at least MSCL_WGRAD_HALO_MIN padded positions (default 200: the 14 x 16 planes of layer 3 fill 87 % of one
+// 256-position tile; the 7 x 9 planes of layer 4 would fill 25 % and stay with the general kernel)
+static bool wh_shape(const mscl_conv_desc* d) {
+  if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
+  if ((d->C % 64) || (d->K % 64) || d->C > 512 || d->K > 512) return false;
+  const int Wp = d->W + 2;
+  if (256 + 2 * Wp + 2 > WH_XROWS) return false;
+  if ((long)d->N * d->T * d->H * d->W * d->C * 2 >= (1L << 31) || (long)d->N * d->T * d->H * d->W * d->K * 2 >= (1L << 31)) return false;
+  static MsclTune t_min("MSCL_WGRAD_HALO_MIN");
+  if ((long)d->H * Wp < t_min.get(200)) return false;
+  static MsclTune t_ch("MSCL_WGRAD_HALO_MAXC");             // widest layer that takes it (A/B: 64 = layer 1 only, the round-3 scope)
+  const int maxc = t_ch.get(512);
+  if (d->C > maxc || d->K > maxc) return false;
+  const int nsub = 3 * (d->C / 64) * (d->K / 64);
+  return nsub <= wh_cus();
+}
+static int wh_slots(const mscl_conv_desc* d) {
+  const int nsub = 3 * (d->C / 64) * (d->K / 64);
+  const int tiles = (d->H * (d->W + 2) + 255) / 256;
+  int gk = wh_cus() / nsub;
+  if (gk > d->N * d->T * tiles) gk = d->N * d->T * tiles;
+  return gk < 1 ? 1 : gk;
+}
+// floats of workspace mscl_wgrad_halo64 wants (0: the layer is not covered)
+extern "C" int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d) {
+  if (!d || !wh_shape(d)) return 0;
+  return (int64_t)wh_slots(d) * 3 * (d->C / 64) * (d->K / 64) * WH_SLAB;
+}
+
+// returns 1 if launched, 0 if the shape / workspace is not covered, <0 / >0 on error
+int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
+                      hipStream_t st) {
+  if (!wh_shape(d)) return 0;
+  WHGeom g{};
+  g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
+  g.C = d->C; g.K = d->K; g.ncs = d->C / 64; g.nsub = 3 * g.ncs * (d->K / 64);
+  g.tiles = (d->H * g.Wp + 255) / 256;
+  g.total = d->N * d->T * g.tiles;
+  static bool attr_done = false;
+  if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  int gk = cus / 3;
-  if (gk > g.total) gk = g.total;
-  if (ws == nullptr || (long)gk * 3 * WH_SLAB > ws_floats) gk = (int)(ws ? ws_floats / (3L * WH_SLAB) : 0);
+  int gk = wh_slots(d);
+  if (ws == nullptr || (long)gk * g.nsub * WH_SLAB > ws_floats) gk = (int)(ws ? ws_floats / ((long)g.nsub * WH_SLAB) : 0);
   if (gk < 1) return 0;
   g.gk = gk;
   g.planes = d->N * d->T;
   g.dWp = make_fastdiv(g.Wp); g.dTiles = make_fastdiv(g.tiles); g.dT = make_fastdiv(d->T); g.dPlanes = make_fastdiv(g.planes);
-  static MsclTune t_nw("MSCL_WGRAD_HALO_WAVES");            // 8 (default): two waves per SIMD; 4: the round-3 form
-  if (t_nw.get(8) == 4) hipLaunchKernelGGL(wgrad_halo64_kernel<4>, dim3((unsigned)(3 * gk)), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
-  else hipLaunchKernelGGL(wgrad_halo64_kernel<8>, dim3((unsigned)(3 * gk)), dim3(512), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
+  static MsclTune t_nw("MSCL_WGRAD_HALO_WAVES");            // 8 (default): two waves per SIMD; 4: the round-3 form (64 -> 64 only)
+  const unsigned blocks = (unsigned)(g.nsub * gk);
+  if (t_nw.get(8) == 4 && g.nsub == 3) hipLaunchKernelGGL(wgrad_halo64_kernel<4>, dim3(blocks), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
+  else hipLaunchKernelGGL(wgrad_halo64_kernel<8>, dim3(blocks), dim3(512), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
   MSCL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((27 * 4096 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, gk);
+  const long total = (long)d->K * 27 * d->C;
+  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, gk, g.nsub,
+                     g.ncs, d->C, total);
   MSCL_LAUNCH_CHECK();
   ++g_wgrad_halo_launches;
   return 1;

@@ -106,9 +106,6 @@ def conv3d_dgrad(dy, wT, d, addend=None):
     return dx
 
 
-WGRAD_HALO_WS = 256 * 9 * 64 * 64       # floats: per-block partial slabs of the window-resident layer-1 weight-gradient kernel
-
-
 def conv_halo64_dgrad_bn(dy, wT, d, bn_y, bn_mask, bn_mean, bn_invstd, scratch, addend=None):
     """layer-1 input gradient with the consuming BatchNorm's backward reduce fused in: returns dz (masked gradient) or None
     when the shape is not covered (nothing launched); sums land in `scratch` ([STAT_SLOTS][4C], zeroed)"""
@@ -125,9 +122,7 @@ def conv_halo64_dgrad_bn(dy, wT, d, bn_y, bn_mask, bn_mean, bn_invstd, scratch, 
 def wgrad_ws_floats(d, with_bias):
     """floats of fp32 scratch the weight gradient of this layer wants (a function of the descriptor and of the library's mode:
     callers on the hot path cache it per (module, shape, lib.DET_GEN))"""
-    if (d.C, d.K, d.kT, d.kH, d.kW, d.sT, d.sH, d.sW, d.pT, d.pH, d.pW) == (64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1):
-        return max(WGRAD_HALO_WS, lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(with_bias)))
-    # slabs of the shared-tap / window-resident kernels, or deterministic mode's per-split slabs (+ bias partials)
+    # slabs of the window-resident / shared-tap kernels, or deterministic mode's per-split slabs (+ bias partials)
     return lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(with_bias))
 
 

@@ -134,6 +134,9 @@ def test_conv_real_layer_shapes(case, dev):
     from mscl_amd import lib
     n_halo, n_wh = lib.call_raw('mscl_debug_halo_launches'), lib.call_raw('mscl_debug_wgrad_halo_launches')
     test_conv_fwd_dgrad_wgrad(case, dev)
+    if case[0] in ('real_l2_128_128', 'real_l3_256_256'):
+        # since round 4 the 128- / 256-channel 3x3x3 layers run the window-resident weight gradient as 64 x 64 channel slices
+        assert lib.call_raw('mscl_debug_wgrad_halo_launches') == n_wh + 2, f'{case[0]} did not take the window-resident weight gradient'
     if case[0] == 'real_l1_64_64':
         # the forward with statistics, 2 input gradients (plain / + addend), 2 weight gradients (the forward with bias + ReLU is the
         # implicit-GEMM family's: the window-resident kernel has no such epilogue)
@@ -160,14 +163,10 @@ PP_CASES = [
 ]
 
 
-@pytest.mark.parametrize('late', [0, 1, 2], ids=['inL', 'afterM', 'beforeM'])
 @pytest.mark.parametrize('case', PP_CASES, ids=[c[0] for c in PP_CASES])
-def test_conv_pp_forced(case, late, dev, monkeypatch):
-    """late: where a wave issues its share of the next group's LDS-DMA (conv_pp.hip, LATE): every placement is a schedule of its own
-    and gets the full parity + repeat-launch race screen"""
+def test_conv_pp_forced(case, dev, monkeypatch):
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K, kern, stride, pad, ksplit = case
-    monkeypatch.setenv('MSCL_PP_LATE', str(late))
     monkeypatch.setenv('MSCL_PP', '2')
     monkeypatch.setenv('MSCL_HALO', '0')          # (the window-resident layer-1 kernel would take the 64 -> 64 cases first)
     if ksplit:
@@ -238,6 +237,58 @@ def test_conv_wgrad_pp_forced(case, late, dev, monkeypatch):
     close(db, dy.float().sum(dim=(0, 1, 2, 3)), F32_TOL, 'wgrad_pp dbias')
     first = dw.clone()
     K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, None)           # accumulates; fixed-order slab sums: the same bits every run
+    assert torch.equal(dw, 2 * first)
+    for _ in range(5):
+        dw2 = torch.zeros_like(dw)
+        K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw2, None)
+        assert torch.equal(dw2, first)
+
+
+# conv_wgrad_halo.hip (window-resident weight gradient on 64 x 64 channel slices) forced onto small shapes (MSCL_WGRAD_HALO_MIN=1: a
+# plane smaller than one 256-position tile is a tile of mostly zero rows): one and several channel slices each way, more blocks
+# than slots and fewer, several items per block (tile-major ranges that cross sample and tile boundaries), T = 1 / 2 (planes
+# without a neighbour on one or both sides: every item of kt = 0 / 2 skipped), a plane of several tiles with a ragged last one,
+# accumulation into a non-zero dw with a bias gradient, and the same bits on every run (slot-ordered slab sums).  The round-3
+# form (one wave per SIMD) stays covered as the A/B arm on the 64 -> 64 cases.
+WGRAD_HALO_CASES = [
+    ('wh_64_64', 2, 4, 12, 12, 64, 64),
+    ('wh_64_64_T1', 3, 1, 10, 9, 64, 64),
+    ('wh_64_64_plane56', 1, 3, 56, 56, 64, 64),
+    ('wh_128_128', 1, 3, 9, 10, 128, 128),
+    ('wh_128_64', 2, 3, 13, 11, 128, 64),
+    ('wh_64_192_T2', 2, 2, 11, 13, 64, 192),
+    ('wh_256_256', 1, 2, 7, 7, 256, 256),
+    ('wh_128_128_plane28', 2, 3, 28, 28, 128, 128),
+    ('wh_256_128_many_items', 8, 4, 14, 14, 256, 128),
+]
+
+
+@pytest.mark.parametrize('waves', [8, 4])
+@pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=[c[0] for c in WGRAD_HALO_CASES])
+def test_conv_wgrad_halo_forced(case, waves, dev, monkeypatch):
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, C, K = case
+    if waves == 4 and (C, K) != (64, 64):
+        pytest.skip('the one-wave-per-SIMD arm covers 64 -> 64 only')
+    kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    monkeypatch.setenv('MSCL_WGRAD_HALO_MIN', '1')
+    monkeypatch.setenv('MSCL_WGRAD_HALO_WAVES', str(waves))
+    lib.tune()
+    x = bf(rnd((N, T, H, W, C), 41)); w = rnd((K, *kern, C), 42)
+    d = K_.conv_desc(x.shape, K, kern, stride, pad)
+    xr = x.float(); wr = w.clone().requires_grad_(True)
+    yr = _conv_ref(xr, wr, stride, pad)
+    dy = bf(rnd(tuple(yr.shape), 43))
+    yr.backward(dy.float())
+    dw = torch.zeros((K, *kern, C), dtype=torch.float32, device=dev)
+    db = torch.zeros((K,), dtype=torch.float32, device=dev)
+    n0 = lib.call_raw('mscl_debug_wgrad_halo_launches')
+    K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, db)
+    assert lib.call_raw('mscl_debug_wgrad_halo_launches') == n0 + 1, 'the weight gradient did not take the window-resident kernel'
+    close(dw, wr.grad, F32_TOL, 'wgrad_halo')
+    close(db, dy.float().sum(dim=(0, 1, 2, 3)), F32_TOL, 'wgrad_halo dbias')
+    first = dw.clone()
+    K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, None)           # accumulates; slot-ordered slab sums: the same bits every run
     assert torch.equal(dw, 2 * first)
     for _ in range(5):
         dw2 = torch.zeros_like(dw)

@@ -107,6 +107,44 @@ def logs_within_bf16_yardstick(got, ref, auto, what, rows, pos_rows):
             assert abs(got[k] - v) <= 1e-6, f'{what} {k}: hip {got[k]} vs ref {v}'
 
 
+def features_and_gradients_match(model, orc, yard, what, arch='r18', auto_feat=None):
+    """q / k feature rows and per-tensor gradients of a HIP step against the fp32 oracle step on the same batch (both after
+    backward): features cosine >= 0.995 per row (r50: what autocast reaches on the same rows, less 0.01); every tensor carrying
+    >= 1 % of the gradient norm at cosine >= min(0.995, yardstick - 0.06), `yard` = the per-tensor cosine PyTorch's own bf16
+    autocast run of the oracle reaches (_autocast_yardstick); tensors the oracle leaves without a gradient must have none;
+    global norm within 8 %.  Returns (hip norm, oracle norm)."""
+    cos = torch.nn.functional.cosine_similarity
+    for nm, a, grp, w in (('q_rgb', model._dbg['q_rgb'], 'img', 'q'), ('k_rgb', model._dbg['k_rgb'], 'img', 'k'),
+                          ('q_flow', model._dbg['q_fb'], 'base', 'q'), ('q_flow_aug', model._dbg['q_fa'], 'aug', 'q')):
+        b = orc._features[grp][w].detach()
+        c = cos(a.float().cpu(), b, dim=1).min().item()
+        bar = 0.995 if arch == 'r18' else min(0.995, cos(auto_feat[grp][w], b, dim=1).min().item() - 0.01)
+        assert c >= bar, f'{what} {nm} cosine {c} (bar {bar})'
+    tot_h, tot_o, bad = 0.0, 0.0, []
+    gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
+    for (n, p), (n2, q) in zip(model.named_parameters(), orc.named_parameters()):
+        assert n == n2
+        if not p.requires_grad:
+            continue
+        gh = p.grad.detach().float().cpu()
+        if q.grad is None:
+            assert float(gh.abs().max()) == 0.0, f'{what} {n} must receive no gradient'
+            continue
+        go = q.grad
+        tot_h += float((gh.double() ** 2).sum()); tot_o += float((go.double() ** 2).sum())
+        if float(go.norm()) >= 0.01 * gn_o:
+            c = float(cos(gh.flatten(), go.flatten(), dim=0))
+            y = yard[n] if yard[n] == yard[n] else 0.97       # CPU autocast itself can produce NaN gradients
+            if y < 0.5:
+                continue        # a tensor whose direction PyTorch's own bf16 run cannot resolve at this batch size
+                                # (r2d_50's 8-channel layers at B = 2: yardstick 0.12-0.27); the norm check covers it
+            if c < min(0.995, y - 0.06):
+                bad.append((n, c, yard[n]))
+    assert not bad, (what, bad)
+    assert abs(tot_h ** 0.5 - tot_o ** 0.5) <= 0.08 * tot_o ** 0.5, (what, tot_h ** 0.5, tot_o ** 0.5)
+    return tot_h ** 0.5, tot_o ** 0.5
+
+
 @pytest.mark.parametrize('tag', ['step_b2_t8_h112', 'step_b2_t16_h112', 'r50_step_b2_t8_h64', 'r50_step_b2_t8_h112'])
 def test_step_vs_golden_and_oracle(tag, dev):
     """T=8 is the shipped config's clip length, T=16 the benchmark's (BASELINE.json); both goldens come from the reference's
@@ -146,37 +184,8 @@ def test_step_vs_golden_and_oracle(tag, dev):
                 pos_rows = B * cfg.model.sup_head.t
                 logs_within_bf16_yardstick(out['log_vars'], gold, auto_logs, f'{tag} golden step{s}', B, pos_rows)
                 logs_within_bf16_yardstick(out['log_vars'], oo['log_vars'], auto_logs, f'{tag} oracle step{s}', B, pos_rows)
-            for nm, a, grp, w in (('q_rgb', model._dbg['q_rgb'], 'img', 'q'), ('k_rgb', model._dbg['k_rgb'], 'img', 'k'),
-                                  ('q_flow', model._dbg['q_fb'], 'base', 'q'), ('q_flow_aug', model._dbg['q_fa'], 'aug', 'q')):
-                b = orc._features[grp][w].detach()
-                c = cos(a.float().cpu(), b, dim=1).min().item()
-                # r18: 0.995 flat; r50: what autocast reaches on the same rows, less 0.01 (see logs_within_bf16_yardstick)
-                bar = 0.995 if arch == 'r18' else min(0.995, cos(auto_feat[grp][w], b, dim=1).min().item() - 0.01)
-                assert c >= bar, f'{nm} cosine {c} (bar {bar})'
-            # gradients
-            tot_h, tot_o, bad = 0.0, 0.0, []
-            gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
-            for (n, p), (n2, q) in zip(model.named_parameters(), orc.named_parameters()):
-                assert n == n2
-                if not p.requires_grad:
-                    continue
-                gh = p.grad.detach().float().cpu()
-                if q.grad is None:
-                    assert float(gh.abs().max()) == 0.0, f'{n} must receive no gradient'
-                    continue
-                go = q.grad
-                tot_h += float((gh.double() ** 2).sum()); tot_o += float((go.double() ** 2).sum())
-                if float(go.norm()) >= 0.01 * gn_o:
-                    c = float(cos(gh.flatten(), go.flatten(), dim=0))
-                    y = yard[n] if yard[n] == yard[n] else 0.97       # CPU autocast itself can produce NaN gradients
-                    if y < 0.5:
-                        continue        # a tensor whose direction PyTorch's own bf16 run cannot resolve at this batch size
-                                        # (r2d_50's 8-channel layers at B = 2: yardstick 0.12-0.27); the norm check covers it
-                    if c < min(0.995, y - 0.06):
-                        bad.append((n, c, yard[n]))
-            assert not bad, bad
-            assert abs(tot_h ** 0.5 - tot_o ** 0.5) <= 0.08 * tot_o ** 0.5, (tot_h ** 0.5, tot_o ** 0.5)
-            loss_close(tot_o ** 0.5 / 100, float(g['s0_grad_norm']) / 100, 'golden grad norm (oracle)')
+            _, gn_oracle = features_and_gradients_match(model, orc, yard, tag, arch, auto_feat)
+            loss_close(gn_oracle / 100, float(g['s0_grad_norm']) / 100, 'golden grad norm (oracle)')
             if arch == 'r50':
                 # the LMCL head's flow transform (local_cl_head.py:30-33,65) carries under 1 % of the gradient norm, so the loop above
                 # skips its direction: check it by name -- its gradient is produced in the loss node and must survive the
@@ -976,7 +985,15 @@ def test_rccl_backend_single_rank_forced(dev):
 def test_step_other_shapes(B, T, H, W, dev):
     """Shapes that switch kernel paths: odd map widths (45 / 29 after the stem: paired stem with an odd pixel count, ragged
     halo tiles), a batch that is not a power of two, and 224^2 clips whose layer-1 planes (W = 112) are too wide for the
-    window-resident kernels.  Losses as in the step test, gradient norm within 8 % of the fp32 oracle, queue state equal."""
+    window-resident kernels.  Checked like the canonical step test: q / k feature rows (cosine >= 0.995; observed >= 0.99996),
+    per-tensor gradients by the autocast rule, gradient norm within 8 %, queue state equal, every loss term printed with its
+    deviation.  The loss bar: 3e-3 relative, or -- for the terms that bf16 itself cannot hold tighter at these shapes -- twice
+    the largest deviation PyTorch's OWN bf16 autocast run of the oracle shows on any term of the same step.  Which terms those
+    are (tools/other_shapes_diag.py, profiles/r04_other_shapes.md): the cross-modal InfoNCE terms and the LMCL term, whose
+    positive logit q_a . k_b / 0.07 joins two DIFFERENT encoders' features and moves in first order with their bf16 rounding
+    (cosine 0.99996 = 9 mrad = up to 0.1 of a logit), on queues of 16 B keys where one logit is a visible share of the loss;
+    the intra-modal terms (q and k of one encoder, parallel at step 0) sit at 1e-7.  Autocast shows 5.9e-3 at (2,4,70,58) and
+    1.1e-2 at (3,8,90,90), the HIP path 1.6e-3 .. 5.4e-3 (deterministic mode included: it is rounding, not summation order)."""
     from mscl_amd import ClipSGD, Config, build_model
     from mscl_amd.fill import fill_module
     from mscl_amd.synthetic import synthetic_batch
@@ -991,12 +1008,21 @@ def test_step_other_shapes(B, T, H, W, dev):
     torch.manual_seed(100)
     ref = orc.train_step(batch)
     ref['loss'].backward()
-    for k, v in ref['log_vars'].items():
-        if 'loss' in k:
-            loss_close(out['log_vars'][k], v, f'{(B, T, H, W)} {k}', tol=1e-2)      # (B = 2 .. 3 at odd sizes: batch statistics over a few hundred positions; run-to-run spread seen: 0.40 .. 0.51 %)
-    gn_o = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in orc.parameters() if p.grad is not None)))
-    gn_h = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.requires_grad and p.grad is not None)))
-    assert abs(gn_h - gn_o) <= 0.08 * gn_o, (gn_h, gn_o)
+    yard = _autocast_yardstick(batch, T, Kq, {n: p.grad for n, p in orc.named_parameters()})
+    auto_logs, _ = _autocast_yardstick.last
+    terms = [k for k in ref['log_vars'] if 'loss' in k and k != 'loss']
+    rel = lambda got, v: (got - v) / max(1.0, abs(v))
+    print(f'\n{(B, T, H, W)} relative deviation per term, hip | autocast: ' +
+          '  '.join(f'{k} {rel(out["log_vars"][k], ref["log_vars"][k]):+.1e} | {rel(auto_logs[k], ref["log_vars"][k]):+.1e}'
+                    for k in terms + ['loss']))
+    D = max(abs(rel(auto_logs[k], ref['log_vars'][k])) for k in terms)
+    S = sum(abs(auto_logs[k] - ref['log_vars'][k]) for k in terms)
+    for k in terms:
+        v = ref['log_vars'][k]
+        assert abs(rel(out['log_vars'][k], v)) <= max(3e-3, 2 * D), f'{(B, T, H, W)} {k}: hip {out["log_vars"][k]} vs ref {v} (autocast {auto_logs[k]})'
+    v = ref['log_vars']['loss']
+    assert abs(out['log_vars']['loss'] - v) <= max(3e-3 * abs(v), 2 * S), (out['log_vars']['loss'], v, auto_logs['loss'])
+    features_and_gradients_match(model, orc, yard, f'{(B, T, H, W)}')
     opt.step()
     assert int(model.recognizer.queue_ptr) == int(orc.recognizer.queue_ptr) == B % Kq
     assert torch.equal(model.recognizer_flow.count.cpu(), orc.recognizer_flow.count)
