@@ -49,12 +49,10 @@ int mscl_abi_version(void);
  * gradient, the InfoNCE gradient, the LMCL loss -- is taken in a fixed order (per-block partials in slots or slabs, added in
  * index order), so two runs on the same inputs give bit-identical results.  Costs one extra read of each conv output (the
  * statistics pass, mscl_bn_stats), a fold launch per BatchNorm sum and a slab pass per weight gradient.  Process-wide; set it before the first step.
- * Not covered: mscl_conv_halo64 called directly with statistics pointers, mscl_conv_halo64_dgrad_bn (both opt-in paths). */
+ * Not covered: mscl_conv_halo64 called directly with statistics pointers. */
 /* test aid: number of launches the ping-pong shared-tap conv kernel (conv_pp.hip) has taken in this process, so that a parity
  * test can assert which kernel family produced the result it checked */
 int64_t mscl_debug_pp_launches(void);
-/* the same for the persistent window-resident 64 -> 64 kernel (conv_win64.hip) */
-int64_t mscl_debug_win64_launches(void);
 /* the same for the window-resident 1x3x3 kernel of the 16- / 32-channel maps (conv_thin.hip) */
 /* the same for the window-resident layer-1 kernels: forward / input gradient (conv_halo.hip), weight gradient (conv_wgrad_halo.hip) */
 int64_t mscl_debug_halo_launches(void);
@@ -75,10 +73,9 @@ int mscl_tuning_reload(void);
 int64_t mscl_det_parts_floats(int64_t rows, int C, int groups, int vecs);
 int mscl_bn_stats(const uint16_t* y, float* ssum, float* ssq, int64_t rows, int C, int groups, float* parts, int64_t parts_floats,
                   void* stream);
-/* floats of workspace mscl_conv3d_wgrad wants for this layer: the slabs of the shared-tap kernel (conv_wgrad_pp.hip) where it
- * applies, the per-split slabs of deterministic mode otherwise (0: none needed) */
+/* floats of workspace mscl_conv3d_wgrad wants for this layer: the slabs of the window-resident kernels (conv_wgrad_halo.hip,
+ * conv_thin.hip) where they apply, the per-split slabs of deterministic mode otherwise (0: none needed) */
 int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias);
-int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
 /* floats of workspace the window-resident weight-gradient kernel wants (conv_wgrad_halo.hip: one 9 x 64 x 64 partial per block,
  * added in slot order); 0 = the layer is not one of its shapes (3x3x3 / 1 / 1, channels multiples of 64, planes that fill
  * 256-position tiles).  Included in mscl_conv3d_wgrad_ws. */
@@ -86,8 +83,6 @@ int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d);
 /* floats of workspace the window-resident weight-gradient kernel of the 1x3x3 16- / 32-channel layers wants (conv_thin.hip: one
  * 9 x K x C partial per block, added in block order); 0 = the layer is not one of them.  Included in mscl_conv3d_wgrad_ws. */
 int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);
-/* test aid: launches taken by the shared-tap weight-gradient kernel (conv_wgrad_pp.hip) in this process */
-int64_t mscl_debug_wgrad_pp_launches(void);
 
 /* ---- Conv3d as implicit GEMM on MFMA (bf16 in, fp32 accumulate) --------------------------------
  * replaces nn.Conv3d forward in r3d.py:16-34,176-184,285-288 / fastonly.py:61-80,185-193 /
@@ -114,15 +109,6 @@ int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x, const uin
  * handled the shape, 0 when the shape is not covered (mscl_conv3d_fwd / _dgrad call it first and fall back). */
 int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                      const uint16_t* addend, float* stat_sum, float* stat_sq, void* stream);
-
-/* Layer-1 input gradient (mode 1 of mscl_conv_halo64) fused with the backward REDUCE of the BatchNorm(+ReLU) that consumes
- * it (r3d.py:116-127 run backwards: conv2's input gradient feeds bn1/relu, conv1's + the shortcut feed the previous block's
- * bn2/relu): writes dz = (conv_transpose(dy, wT) + addend) * (bn_mask > 0) and accumulates sum(dz), sum(dz * xhat) into
- * `scratch` ([MSCL_STAT_SLOTS][4*C] floats, zeroed; xhat = (bn_y - mean) * invstd).  Follow with mscl_bn_act_bwd(relu = 2).
- * Returns 1 when launched, 0 when the shape is not covered (caller falls back to mscl_conv3d_dgrad + the full mscl_bn_act_bwd). */
-int mscl_conv_halo64_dgrad_bn(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT, uint16_t* dz,
-                              const uint16_t* addend, const uint16_t* bn_y, const uint16_t* bn_mask,
-                              const float* bn_mean, const float* bn_invstd, float* scratch, void* stream);
 
 /* dx = conv_transpose(dy, w) [+ addend]; wT_bf16 is the kernel re-laid out [Cin][kT][kH][kW][Cout]
  * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient. */
@@ -177,8 +163,7 @@ int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* bn,
  * into the fp32 gradient buffers, caller-zeroed) and keeps the sums in `scratch` (MSCL_STAT_SLOTS * 4*C
  * floats, caller-zeroed: blocks spread their partial sums over the slots); pass 2 writes dy (and dres: dz itself for an identity residual, the BN input
  * gradient for a normalised residual).
- * relu: 0 none, 1 mask by out > 0, 2 = `dout` is dz already and `scratch` already holds the sums (written by
- * mscl_conv_halo64_dgrad_bn): only pass 2 runs (no residual in this mode).
+ * relu: 0 none, 1 mask by out > 0.
  * beta (optional; only with relu and no residual of either kind): the ReLU mask is recomputed as
  * gamma*invstd*(y - mean) + beta > 0, the forward's own arithmetic, and `out` is not read (may be NULL):
  * one map less per pass for the conv1 / stem BatchNorms (r3d.py:116-118, :176-184). */
@@ -191,7 +176,7 @@ int mscl_bn_act_bwd(const uint16_t* dout, const uint16_t* out, const uint16_t* y
                     float* scratch, int64_t rows, int C, int relu, void* stream);
 
 /* with statistics groups: save_mean / save_invstd (and the residual's) are [G][C], scratch is [G][MSCL_STAT_SLOTS][4*C];
- * dgamma / dbeta receive the sum over the groups (relu = 2 is not available with G > 1).
+ * dgamma / dbeta receive the sum over the groups.
  * det_parts: deterministic mode's scratch for the per-block partial sums, >= mscl_det_parts_floats(rows, C, groups, 4) floats
  * (NULL or smaller: the slots of `scratch` hold them, 16 blocks); ignored outside deterministic mode. */
 int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out, const uint16_t* y,

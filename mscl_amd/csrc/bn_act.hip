@@ -494,12 +494,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
                                       int groups, float* det_parts, int64_t det_parts_floats, void* stream) {
   if (!dout || !y || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dy || !scratch) return MSCL_E_ARG;
   if (groups < 1 || groups > 2 || rows % groups != 0) return MSCL_E_SHAPE;
-  if (groups > 1 && relu == 2) return MSCL_E_ARG;
-  // relu == 2: `dout` is dz already (masked by the producer) and `scratch` already holds the two sums -- the fused epilogue of
-  // mscl_conv_halo64_dgrad_bn did this pass's work; only the apply pass runs
-  const bool pre = relu == 2;
-  if (pre && (res_y || want_identity_dres || beta)) return MSCL_E_ARG;
-  if (pre) relu = 0;
+  if (relu != 0 && relu != 1) return MSCL_E_ARG;
   if (beta && (res_y || want_identity_dres || !relu)) return MSCL_E_ARG;     // the mask depends on the residual too: pass `out`
   if (relu && !out && !beta) return MSCL_E_ARG;
   if (rows <= 0 || C <= 0) return MSCL_E_ARG;
@@ -518,7 +513,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   const bool det = mscl_det();
   const bool own = det && det_parts != nullptr && det_parts_floats >= mscl_det_parts_floats(rows, C, groups, 4);
   if (det) blocks = own ? det_parts_of(rows_g, C) : (blocks > MSCL_STAT_SLOTS ? MSCL_STAT_SLOTS : blocks);
-  if (!pre) {
+  {
     float* part = det ? (own ? det_parts : scratch) : nullptr;
     const long pgs = (own ? blocks : (long)MSCL_STAT_SLOTS) * 4 * C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, chunks, groups), dim3(256), (size_t)12 * Cc * sizeof(float), st, dout,
@@ -542,7 +537,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2, achunks), dim3(256), (size_t)10 * groups * Ca * sizeof(float), st, dout, out, y,
                      gamma, save_mean, save_invstd, res_y, res_gamma, res_mean, res_invstd, scratch, dy, dres,
                      want_identity_dres, (long)rows, Ca, relu, dgamma, dbeta, res_dgamma, res_dbeta, beta, groups, C,
-                     pre ? MSCL_STAT_ACTIVE : mscl_stat_nslots());      // (relu = 2: the fused producer is an atomic one)
+                     mscl_stat_nslots());
   MSCL_LAUNCH_CHECK();
   return 0;
 }

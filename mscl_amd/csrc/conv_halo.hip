@@ -31,11 +31,6 @@ struct HaloGeom {
   int stat_stride;                 // floats between two statistics slots (2 * C: forward [slot][2][C]; 4 * C: BatchNorm-backward scratch)
 };
 
-// Input-gradient mode only: the BatchNorm(+ReLU) that consumes this gradient.  With y != NULL the epilogue writes
-// dz = (gradient + addend) * (mask > 0) instead of the gradient and accumulates sum(dz) -> stat_sum, sum(dz * xhat) -> stat_sq
-// (xhat = (y - mean) * invstd): that BatchNorm's backward reduce pass (three map reads) rides on values already in registers.
-struct HaloBn { const bf16_t* y; const bf16_t* mask; const float* mean; const float* inv; };
-
 __device__ __forceinline__ auto halo_rsrc(const void* p, unsigned bytes) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
@@ -63,7 +58,7 @@ template <int NW, int BM, int RING>
 __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
-                                                             float* __restrict__ stat_sq, const HaloBn bn) {
+                                                             float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // The three source planes are visited one after the other, so TWO window slots suffice: the third plane streams into
   // the first one's slot while the second is in use.  The freed LDS holds a deeper weight ring (tiles issued RING taps
@@ -258,46 +253,6 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       for (int j = 0; j < 4; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
-  // ---- fused BatchNorm-backward reduce (input-gradient mode): acc <- dz, per-lane partial sums ----
-  const bool fused_bn = bn.y != nullptr;
-  float sl[4][4], ql[4][4];
-  if (fused_bn) {
-    // Branch-free (dropped rows read row 0 and are masked out below) with EVERY load of the lane issued before the first use:
-    // at one block per CU nothing else covers an epilogue's latency, and bytes in flight are what its bandwidth is made of
-    // (12 loads in flight per lane read the two extra maps at 2.7 TB/s, +38 us on the layer-1 map).
-    uint2 av4[4][IM], mv4[4][IM], yv4[4][IM];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < IM; ++i) {
-        const long ro = (orow[i] < 0 ? 0 : orow[i]) + j * 16 + fq * 4;
-        av4[j][i] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + ro) : make_uint2(0u, 0u);
-        mv4[j][i] = *reinterpret_cast<const uint2*>(bn.mask + ro);
-        yv4[j][i] = *reinterpret_cast<const uint2*>(bn.y + ro);
-      }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float mu[4], iv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { mu[r] = bn.mean[j * 16 + fq * 4 + r]; iv[r] = bn.inv[j * 16 + fq * 4 + r]; sl[j][r] = 0.f; ql[j][r] = 0.f; }
-#pragma unroll
-      for (int i = 0; i < IM; ++i) {
-        const bool live = orow[i] >= 0;
-        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-        const uint2 av = av4[j][i], mv = mv4[j][i], yv = yv4[j][i];
-        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
-        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
-        const float m4[4] = {__uint_as_float(mv.x << 16), __uint_as_float(mv.x & 0xFFFF0000u), __uint_as_float(mv.y << 16), __uint_as_float(mv.y & 0xFFFF0000u)};
-        const float y4[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xFFFF0000u), __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xFFFF0000u)};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // the sums are taken over the bf16-rounded dz, the value the apply pass will read back
-          const float dz = (live && m4[r] > 0.f) ? __uint_as_float(pack2bf(v[r], 0.f) << 16) : 0.f;
-          acc[j][i][r] = dz; sl[j][r] += dz; ql[j][r] += dz * ((y4[r] - mu[r]) * iv[r]);
-        }
-      }
-    }
-  }
   // ---- epilogue: BatchNorm statistics ----
   // Every wave plain-stores its 64-channel sums as one LDS row ([wave][2][64], eight 16-byte writes per wave); 128 threads add the
   // rows (no LDS atomics).  This section costs the forward 12-13 us on the layer-1 map (108 vs 95 us for the same kernel as input
@@ -312,15 +267,10 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-      if (fused_bn) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s[r] = sl[j][r]; q[r] = ql[j][r]; }
-      } else {
+      for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int i = 0; i < IM; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
-      }
+        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s[r] += v; q[r] += v * v; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
@@ -339,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
       atomicAdd(tid < HC ? &stat_sum[so + tid] : &stat_sq[so + tid - HC], t);
     }
   }
-  const bool plain_add = addend != nullptr && !fused_bn;
+  const bool plain_add = addend != nullptr;
   uint2 add4[4][IM];                                   // all of the lane's addend loads in flight at once (see the fused pass)
   if (plain_add) {
 #pragma unroll
@@ -366,40 +316,238 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same convolution with TWO blocks per CU.  The kernel above keeps one 128-KB block per CU, and what that block
+// does besides its 27 taps -- dispatch gap, the exposed window prologue (48 KB before the first MFMA), the statistics epilogue and
+// the output stores -- was 43 % of a block slot by the in-kernel stamps of round 1; persistent forms removed it and lost inside the
+// three-stream step three times.  Here a block is small enough for a second one beside it (80 KB of LDS, <= 128 registers per
+// lane), so one block's prologue / epilogue / plane switches run under the other's taps, with the same weight traffic per
+// position as the one-block form (the 128-position two-block tile of round 2 doubled it):
+//  * ONE window slot: the three source planes are staged one after the other into the same 48 KB; a plane switch (taps 8 -> 9,
+//    17 -> 18) is [all waves done with the old plane | 6 DMA pieces per thread | second k step of the old tap | landed | barrier];
+//  * half-tap operand pipeline: the fragments of (tap, k step 1) are read while (tap, k step 0) multiplies and those of
+//    (tap + 1, k step 0) while (tap, k step 1) multiplies -- two sets of 6 fragments instead of two sets of 12: 48 operand
+//    registers instead of 96, which is what brings the kernel under 128 registers;
+//  * one barrier per tap as before (publishes the next tap's weight tile, frees this tap's ring stage), RING stages of 8 KB.
+template <int RING>
+__global__ __launch_bounds__(512, 4) void conv_halo64b_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
+                                                              const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
+                                                              const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
+                                                              float* __restrict__ stat_sq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = 8, BM = 256;
+  constexpr int RPP = 8 * NW;                              // window rows per DMA pass
+  constexpr int NHK = (BM + 128 + RPP - 1) / RPP * RPP;    // 384 window rows (BM + 2 * (W + 2) + 2, W <= 61)
+  constexpr int PLANE = NHK * 128;
+  constexpr int NPS = NHK / RPP;                           // 6 DMA pieces per thread per plane
+  constexpr int WPOS = BM / NW, IM = WPOS / 16;            // 32 positions per wave, 2 position tiles
+  static_assert(RING >= 2 && RING <= 4, "weight ring");
+  unsigned char* const Hs = smem;                          // [NHK][128 B] the one window slot, row j <-> q0 - Wp - 1 + j
+  unsigned char* const Ws = smem + PLANE;                  // [RING][64][128 B] weight ring
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = bid % g.tiles, plane = bid / g.tiles;   // plane = n*T + t
+  const int t = plane % g.T;
+  const int q0 = g.Wp + tile * BM;
+  const int mode = __builtin_amdgcn_readfirstlane(g.mode);
+  const auto rs_src = halo_rsrc(src, 0x7FFFFFFFu);
+  const auto rs_wgt = halo_rsrc(wgt, 0x7FFFFFFFu);
+
+  unsigned win_voff[NPS];
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) {
+    const int j = ps * RPP + (tid >> 3), pg = tid & 7;
+    const int lg = pg ^ (j & 7);                           // source-side swizzle keyed on the window row
+    const int q = q0 - g.Wp - 1 + j;
+    const int hp = fdiv(q < 0 ? 0 : q, g.dWp), wp = q - hp * g.Wp;
+    const bool ok = q >= 0 && hp >= 1 && hp <= g.H && wp >= 1 && wp <= g.W;
+    win_voff[ps] = ok ? (unsigned)((((hp - 1) * g.W + (wp - 1)) * HC + lg * 8) * 2) : HOOB;
+  }
+  auto issue_plane = [&](int hp) {                         // source plane t + hp - 1 into the window slot (rows outside the clip: zeros)
+    const bool okp = (unsigned)(t + hp - 1) < (unsigned)g.T;
+    const unsigned so = __builtin_amdgcn_readfirstlane(okp ? (unsigned)((plane + hp - 1) * g.HW) * (HC * 2) : 0u);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const unsigned vo = okp ? win_voff[ps] : HOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(Hs + (ps * 64 * NW + wave * 64) * 16), 16, vo, so, 0, 0);
+    }
+  };
+  const int w_row = tid >> 3, w_lg = tid & 7;
+  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);     // source-side swizzle
+  auto issue_weights = [&](int tap) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(Ws + (tap % RING) * (64 * 128) + wave * 1024), 16, w_voff0, so, 0, 0);
+  };
+  auto tap_plane = [&](int kt) { return mode ? 2 - kt : kt; };
+  auto tap_shift = [&](int kh, int kw) { return mode ? (2 - kh) * g.Wp + (2 - kw) : kh * g.Wp + kw; };
+
+  // ---- prologue: first plane, the first RING weight tiles ----
+  issue_plane(tap_plane(0));
+#pragma unroll
+  for (int w0 = 0; w0 < RING; ++w0) issue_weights(w0);
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int arow0 = wave * WPOS + fr;
+  const int b_addr[2] = {fr * 128 + ((0 + fq) ^ (fr & 7)) * 16, fr * 128 + ((4 + fq) ^ (fr & 7)) * 16};
+
+  bf16x8_t fa[2][IM], fb[2][4];                            // [set][fragment]: set s holds the operands of one half tap
+  auto read_half = [&](int tap, int ks, int set) {
+    const int kh = (tap % 9) / 3, kw = tap % 3;
+    const unsigned char* wb = Ws + (tap % RING) * (64 * 128) + b_addr[ks];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const bf16x8_t*>(wb + j * 2048);
+    const int row = arow0 + tap_shift(kh, kw);
+    const unsigned char* hb = Hs + row * 128 + (((ks * 4 + fq) ^ (row & 7)) * 16);
+#pragma unroll
+    for (int i = 0; i < IM; ++i) fa[set][i] = *reinterpret_cast<const bf16x8_t*>(hb + i * 2048);
+  };
+  f32x4_t acc[4][IM];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], acc[j][i], 0, 0, 0);
+  };
+#define HB_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
+  // plane + tap-0 weights landed; the other RING - 1 weight tiles stay in flight
+  if constexpr (RING == 4) HB_WAIT(3); else if constexpr (RING == 3) HB_WAIT(2); else HB_WAIT(1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_half(0, 0, 0);
+
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    read_half(tap, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap + 1 < 27) {
+      if ((tap + 1) % 9 == 0) {
+        // plane switch: every wave holds the last fragments of the old plane in registers
+        HB_WAIT(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_plane(tap_plane((tap + 1) / 9));
+        if (tap + RING < 27) issue_weights(tap + RING);    // (its ring stage was last read for this tap: free behind the barrier too)
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);                                            // the old tap's second k step runs under the DMA
+        __builtin_amdgcn_sched_barrier(0);
+        HB_WAIT(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_half(tap + 1, 0, 0);
+        continue;
+      }
+      // wait for the weight tile of tap + 1 (everything issued after it may stay in flight: RING - 2 tiles, fewer at the end),
+      // retire this wave's reads of tap's stage; the barrier publishes the one and frees the other
+      const int younger = (RING - 2) < (25 - tap) ? (RING - 2) : (25 - tap > 0 ? 25 - tap : 0);
+      if (younger >= 2) HB_WAIT(2); else if (younger == 1) HB_WAIT(1); else HB_WAIT(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tap + RING < 27) issue_weights(tap + RING);
+      read_half(tap + 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef HB_WAIT
+  __syncthreads();                  // the epilogue reuses the window memory
+
+  long orow[IM];
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    const int q = q0 + wave * WPOS + i * 16 + fr;
+    const int hp = fdiv(q, g.dWp), wp = q - hp * g.Wp;
+    const bool ok = hp <= g.H && wp >= 1 && wp <= g.W;
+    orow[i] = ok ? ((long)plane * g.HW + (hp - 1) * g.W + (wp - 1)) * HC : -1;
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // ---- epilogue: BatchNorm statistics (as conv_halo64_kernel) ----
+  if (stat_sum != nullptr) {
+    float* red = reinterpret_cast<float*>(smem);      // [NW][2][64]
+    const int wv = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s4[r] += v; q4[r] += v * v; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s4[r] = row16_sum(s4[r]); q4[r] = row16_sum(q4[r]); }
+      if (fr == 0) {
+        *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * HC + j * 16 + fq * 4]) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+        *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * HC + j * 16 + fq * 4]) = make_float4(q4[0], q4[1], q4[2], q4[3]);
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * HC) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) tsum += red[w8 * 2 * HC + tid];
+      const int so = (int)(blockIdx.x % MSCL_STAT_ACTIVE) * g.stat_stride;
+      atomicAdd(tid < HC ? &stat_sum[so + tid] : &stat_sq[so + tid - HC], tsum);
+    }
+  }
+  uint2 add4[4][IM];
+  if (addend != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+        add4[j][i] = *reinterpret_cast<const uint2*>(addend + (orow[i] < 0 ? 0 : orow[i]) + j * 16 + fq * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    if (orow[i] < 0) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = j * 16 + fq * 4;
+      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      if (addend != nullptr) {
+        const uint2 av = add4[j][i];
+        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
+        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
+      }
+      uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
+    }
+  }
+}
+
 // (A persistent plane-walking variant of this kernel -- one block per CU walking 192-position items, two of three planes kept
 // resident, statistics once per block -- was measured in rounds 1 and 2: faster alone on the forward conv, 112 vs 125-134 us at
 // the time, slower inside the three-stream step, 785-793 vs 804-808 clip-pairs/s, and was removed in round 3.  Its successor is
-// conv_win64.hip, which shows the same pattern: 101 vs 107 us alone, 970 vs 1007 clip-pairs/s in the step.)
+// a window-resident ping-pong kernel with the K split between SIMD partners (conv_win64.hip, round 3), which showed the same pattern --
+// 101 vs 107 us alone, 970 vs 1007 clip-pairs/s in the step -- and was removed in round 4.)
 
 static long g_halo_launches = 0;
 extern "C" int64_t mscl_debug_halo_launches(void) { return g_halo_launches; }      // tests: which kernel family took a launch
 
 // returns 1 if launched, 0 if the shape is not covered (caller falls back to the implicit-GEMM kernel), <0 / >0 on error
 static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
-                       const uint16_t* addend, float* ssum, float* ssq, HaloBn bn, int stat_stride, void* stream);
+                       const uint16_t* addend, float* ssum, float* ssq, int stat_stride, void* stream);
 
 extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream) {
-  return halo_launch(d, mode, src, w, out, addend, ssum, ssq, HaloBn{nullptr, nullptr, nullptr, nullptr}, 2 * HC, stream);
+  return halo_launch(d, mode, src, w, out, addend, ssum, ssq, 2 * HC, stream);
 }
 
-// Input gradient of the layer-1 convolution with the backward reduce of the BatchNorm(+ReLU) that consumes it fused into the
-// epilogue: dz = (conv_transpose(dy, w) + addend) * (bn_mask > 0) is written instead of the gradient, and
-// scratch[slot][0:C) += sum(dz), scratch[slot][C:2C) += sum(dz * (bn_y - mean) * invstd) with slot stride 4 * C -- the layout
-// mscl_bn_act_bwd keeps between its two passes, so that call then runs with relu = 2 (apply pass only).
-// Returns 1 if launched, 0 if the shape is not covered (nothing written), <0 / >0 on error.
-extern "C" int mscl_conv_halo64_dgrad_bn(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT, uint16_t* dz,
-                                         const uint16_t* addend, const uint16_t* bn_y, const uint16_t* bn_mask,
-                                         const float* bn_mean, const float* bn_invstd, float* scratch, void* stream) {
-  if (!bn_y || !bn_mask || !bn_mean || !bn_invstd || !scratch) return MSCL_E_ARG;
-  static MsclTune t("MSCL_HALO");
-  if (t.read() && t.c0 == '0') return 0;
-  if (!(t.read() && t.c0 == '1') && d && (long)d->H * (d->W + 2) < 1024) return 0;          // as halo_enabled() in conv_igemm.hip
-  return halo_launch(d, 1, dy, wT, dz, addend, scratch, scratch + HC, HaloBn{bn_y, bn_mask, bn_mean, bn_invstd}, 4 * HC, stream);
-}
-
+// (Round 1-3 kept a fused form of the input gradient, mscl_conv_halo64_dgrad_bn: the backward reduce of the BatchNorm + ReLU that
+// consumes the gradient computed in this kernel's epilogue.  It broke even at best -- the epilogue's two extra map reads cost 38 us at
+// one block per CU against 36-42 us saved in the BatchNorm pass -- and was removed in round 4 with its plumbing.)
 static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
-                       const uint16_t* addend, float* ssum, float* ssq, HaloBn bn, int stat_stride, void* stream) {
+                       const uint16_t* addend, float* ssum, float* ssq, int stat_stride, void* stream) {
   if (!d || !src || !w || !out) return MSCL_E_ARG;
   if (d->C != HC || d->K != HC || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
       d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
@@ -418,9 +566,31 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
   // Two waves per SIMD, 256-position tiles, 4-stage weight ring.  Measured and dropped (all inside the three-stream step, alternating
   // pairs in one call): one wave per SIMD (920-923 vs 927-931 clip-pairs/s), 128-position tiles at two blocks per CU (901-902 vs
   // 903-907), a 2-stage ring that leaves room for another chain's block on the CU (no gain).
+  // MSCL_HALO_BLOCKS: 1 = one 128-KB block per CU (conv_halo64_kernel, the round-1..3 form), 2 = two blocks per CU with one window
+  // slot each (conv_halo64b_kernel); MSCL_HALO_RING: weight ring stages of the two-block form (2..4; 4 = 80 KB, the LDS of a CU split
+  // exactly in two)
+  static MsclTune t_blocks("MSCL_HALO_BLOCKS"), t_ring("MSCL_HALO_RING");
+  const unsigned nblk = (unsigned)(d->N * d->T * g.tiles);
+  if (t_blocks.get(1) == 2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2 = true;
+    }
+    const int ring = t_ring.get(4);
+    const size_t lds2 = (size_t)384 * 128 + (size_t)(ring < 2 ? 2 : (ring > 4 ? 4 : ring)) * 64 * 128;
+    if (ring <= 2) hipLaunchKernelGGL((conv_halo64b_kernel<2>), dim3(nblk), dim3(512), lds2, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
+    else if (ring == 3) hipLaunchKernelGGL((conv_halo64b_kernel<3>), dim3(nblk), dim3(512), lds2, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
+    else hipLaunchKernelGGL((conv_halo64b_kernel<4>), dim3(nblk), dim3(512), lds2, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
+    MSCL_LAUNCH_CHECK();
+    ++g_halo_launches;
+    return 1;
+  }
   const size_t lds = (size_t)2 * 384 * 128 + 4 * 64 * 128;
-  hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3((unsigned)(d->N * d->T * g.tiles)), dim3(512), lds, (hipStream_t)stream, g, src, w,
-                     out, addend, ssum, ssq, bn);
+  hipLaunchKernelGGL((conv_halo64_kernel<8, 256, 4>), dim3(nblk), dim3(512), lds, (hipStream_t)stream, g, src, w,
+                     out, addend, ssum, ssq);
   MSCL_LAUNCH_CHECK();
   ++g_halo_launches;
   return 1;

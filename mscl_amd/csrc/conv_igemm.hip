@@ -598,15 +598,6 @@ static int check_desc(const mscl_conv_desc* d) {
 
 extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                                 const uint16_t* addend, float* ssum, float* ssq, void* stream);
-extern "C" int mscl_conv_win64(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
-                               const uint16_t* addend, float* ssum, float* ssq, void* stream);
-// persistent window-resident ping-pong kernel for 64 -> 64 (conv_win64.hip); MSCL_WIN64=0 falls back to conv_halo.hip
-static bool win64_enabled(const mscl_conv_desc* d) {
-  static MsclTune t("MSCL_WIN64");
-  if (!t.read() || t.c0 == '0') return false;
-  if (t.c0 == '2') return true;                             // forced (tests: small planes too)
-  return t.c0 == '1' && (long)d->H * (d->W + 2) >= 1024;
-}
 // layer-1 shape (3x3x3 s1 p1, 64 -> 64): halo-resident kernel, 131 / 109 us vs 156 / 135 us (fwd / dgrad) for the
 // implicit-GEMM kernel; MSCL_HALO=0 switches it off
 static bool halo_enabled(const mscl_conv_desc* d) {
@@ -650,10 +641,6 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
                                  (hipStream_t)stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
-  if (stat_groups == 1 && bias == nullptr && !relu && win64_enabled(d)) {
-    const int h = mscl_conv_win64(d, 0, x, w, y, addend, ssum, ssq, stream);
-    if (h != 0) return h == 1 ? 0 : h;
-  }
   if (stat_groups == 1 && bias == nullptr && !relu && halo_enabled(d)) {   // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)
     const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
     if (h != 0) return h == 1 ? 0 : h;
@@ -677,10 +664,6 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
   if (thin_shape(d)) {
     const int h = mscl_conv_thin(d->N * d->T, d->H, d->W, d->K, d->C, 1, dy, wT, dx, nullptr, addend, 0, nullptr, nullptr, 1,
                                  (hipStream_t)stream);
-    if (h != 0) return h == 1 ? 0 : h;
-  }
-  if (win64_enabled(d)) {
-    const int h = mscl_conv_win64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
   if (halo_enabled(d)) {

@@ -392,20 +392,8 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
 
 int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                       hipStream_t st);           // conv_wgrad_halo.hip
-int mscl_wgrad_pp(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
-                  hipStream_t st);               // conv_wgrad_pp.hip
 int mscl_wgrad_thin(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                     hipStream_t st);             // conv_thin.hip
-// shared-tap ping-pong kernel (conv_wgrad_pp.hip): MSCL_WGRAD_PP 0 (default) = off, 1 = maps of >= 16384 positions, 2 = wherever it
-// applies.  Opt-in: alone it ties the 128 x 128 kernel below on layer 2 (82.5 vs 81.0 us) and loses on the small maps (layer 4: 56 vs
-// 40 us); inside the step 1010 / 1000 vs 1033 clip-pairs/s (levels 1 / 2 vs 0) -- see the header of conv_wgrad_pp.hip for why.
-static bool wgrad_pp_enabled(const mscl_conv_desc* d) {
-  static MsclTune t("MSCL_WGRAD_PP");
-  const int level = t.get(0);
-  if (level <= 0) return false;
-  return level >= 2 || (long)d->N * d->To * d->Ho * d->Wo >= 16384;
-}
-
 // 128 x 128 tile, 2 x 2 waves of 64 x 64: per 64-position step a wave makes 16 transposing reads for 16 MFMAs (the 64 x 64
 // tile with the columns split four ways makes 10 for 4 and asks the LDS for 320 B/clk), and a block stages 32 KB for 128
 // MFMAs instead of 16 KB for 32.
@@ -447,14 +435,12 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
     dws = ws; dfl = ws_floats - tail;
     if (dfl < 0) return MSCL_E_ARG;
   }
-  // (NCOL = 192, three taps sharing one dy tile, measured slower than 64 -- fewer blocks per CU -- and was dropped)
-  int pres = 0;
-  if (hres == 0 && wgrad_pp_enabled(d)) {
-    // its slabs are added in split order, so the result is deterministic as it stands: same path in deterministic mode
-    const long tail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
-    pres = mscl_wgrad_pp(d, x, dy, dw, ws, ws != nullptr ? ws_floats - tail : 0, st);
-    if (pres < 0 || pres > 1) return pres;
-  }
+  // (NCOL = 192, three taps sharing one dy tile, measured slower than 64 -- fewer blocks per CU -- and was dropped; so was the
+  // shared-tap ping-pong kernel of round 3, conv_wgrad_pp.hip: a tie with the 128 x 128 tile at best, with two or three ring slots and
+  // with the DMA pieces issued from either section -- 82.9-84.9 vs 84.7 us on 128 -> 128 -- because its L sections, 20 transposing
+  // reads + 4 pieces + their row decode for 24 MFMAs, are three times as long as its M sections; the window-resident kernel on
+  // channel slices, conv_wgrad_halo.hip, takes those layers at 62 us)
+  const int pres = 0;
   int tres = 0;
   if (hres == 0 && pres == 0 && ws != nullptr) {          // 1x3x3 between 16- / 32-channel maps: window-resident kernel (conv_thin.hip)
     const long tail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
@@ -492,13 +478,11 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
 
 // floats of `ws` mscl_conv3d_wgrad wants for this layer in deterministic mode (at most 64 slabs of the weight gradient plus
 // the bias partials); 0 outside deterministic mode for layers that do not use the window-resident kernel
-extern "C" int64_t mscl_wgrad_pp_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) {
   if (!d) return 0;
   int64_t pp = mscl_wgrad_halo_ws(d);
-  if (pp == 0 && wgrad_pp_enabled(d)) pp = mscl_wgrad_pp_ws(d);
   if (pp == 0) pp = mscl_wgrad_thin_ws(d);
   if (!mscl_det()) return pp;
   if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_DET_PARTS * d->K : 0);

@@ -325,7 +325,13 @@ static bool wh_shape(const mscl_conv_desc* d) {
   const int maxc = t_ch.get(512);
   if (d->C > maxc || d->K > maxc) return false;
   const int nsub = 3 * (d->C / 64) * (d->K / 64);
-  return nsub <= wh_cus();
+  if (nsub > wh_cus()) return false;
+  // enough plane tiles for every block to walk a few: a block that stages one or two items pays its prologue, its pair reduction
+  // and its 147-KB slab for nothing (128 -> 128 on the 4 x 14 x 14 pyramid level, 32 items over 21 x 12 blocks: 27.8 vs 23.0 us
+  // for the general kernel)
+  const long items = (long)d->N * d->T * ((d->H * Wp + 255) / 256);
+  static MsclTune t_items("MSCL_WGRAD_HALO_ITEMS");
+  return items * nsub >= (long)t_items.get(4) * wh_cus();
 }
 static int wh_slots(const mscl_conv_desc* d) {
   const int nsub = 3 * (d->C / 64) * (d->K / 64);

@@ -106,19 +106,6 @@ def conv3d_dgrad(dy, wT, d, addend=None):
     return dx
 
 
-def conv_halo64_dgrad_bn(dy, wT, d, bn_y, bn_mask, bn_mean, bn_invstd, scratch, addend=None):
-    """layer-1 input gradient with the consuming BatchNorm's backward reduce fused in: returns dz (masked gradient) or None
-    when the shape is not covered (nothing launched); sums land in `scratch` ([STAT_SLOTS][4C], zeroed)"""
-    dz = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
-    h = lib.call_raw('mscl_conv_halo64_dgrad_bn', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dz), ptr(addend), ptr(bn_y), ptr(bn_mask),
-                     ptr(bn_mean), ptr(bn_invstd), ptr(scratch), stream_ptr())
-    if h == 1:
-        return dz
-    if h == 0:
-        return None
-    raise lib.MsclError(f'mscl_conv_halo64_dgrad_bn -> {h}')
-
-
 def wgrad_ws_floats(d, with_bias):
     """floats of fp32 scratch the weight gradient of this layer wants (a function of the descriptor and of the library's mode:
     callers on the hot path cache it per (module, shape, lib.DET_GEN))"""

@@ -33,7 +33,6 @@ _SIGS = {
     'mscl_abi_version': [],
     'mscl_set_deterministic': [c_int],
     'mscl_debug_pp_launches': [],
-    'mscl_debug_win64_launches': [],
     'mscl_debug_thin_launches': [],
     'mscl_debug_halo_launches': [],
     'mscl_debug_wgrad_halo_launches': [],
@@ -43,15 +42,12 @@ _SIGS = {
     'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P, c_int64, P],
     'mscl_det_parts_floats': [c_int64, c_int, c_int, c_int],
     'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],
-    'mscl_wgrad_pp_ws': [POINTER(ConvDesc)],
     'mscl_wgrad_halo_ws': [POINTER(ConvDesc)],
     'mscl_wgrad_thin_ws': [POINTER(ConvDesc)],
-    'mscl_debug_wgrad_pp_launches': [],
     'mscl_conv3d_fwd': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, P, c_int64, P],
     'mscl_conv3d_fwd_groups': [POINTER(ConvDesc), P, P, P, P, P, c_int, P, P, c_int, P, c_int64, P],
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
     'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
-    'mscl_conv_halo64_dgrad_bn': [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P],
     'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],
     'mscl_weight_transpose_batched': [P, c_int, c_int, P],
@@ -99,7 +95,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_wgrad_halo_ws', 'mscl_debug_halo_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_wgrad_pp_ws', 'mscl_debug_pp_launches', 'mscl_debug_win64_launches', 'mscl_debug_wgrad_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
+_INT64_RESULT = ('mscl_wgrad_halo_ws', 'mscl_debug_halo_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
 EXPORTS = tuple(_SIGS)
 
 _lib = None

@@ -198,55 +198,22 @@ def cba_eval(conv, bn, x, residual, relu):
     return out
 
 
-# Off (nn.FUSE_BN_REDUCE = True turns it on, tests do): measured on the layer-1 map (tools/bench_fused_bn.py) the fused epilogue adds 38 us to the
-# input-gradient kernel (two more maps read at the 2.7 TB/s a one-block-per-CU epilogue reaches) and takes 36-42 us off the
-# BatchNorm backward: no gain on the step (900 vs 907-918 clip-pairs/s).  Staging the epilogue's operands into the window slot
-# that is free during the last nine taps is what would make it pay.
-FUSE_BN_REDUCE = False
-# gradient tensors that are dz already, with their BatchNorm's sums reduced by the producing kernel: data_ptr -> scratch.
-# Filled by cba_bwd(next_bn=...), consumed by the cba_bwd of that BatchNorm -- in the same autograd node (conv2 -> bn1) or
-# in the previous block's / the stem's node (conv1 + shortcut -> bn2 / stem bn).  Cleared at every step start.
-PRE_REDUCED = {}
-# forward side channel: output tensor of a BatchNorm+ReLU producer (stem / block) -> (y, out, save), looked up by the block that
-# consumes it so that its backward knows which BatchNorm its input gradient feeds.  data_ptr -> (y, out, save).
-LAST_BN = {}
-
-
-def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_addend=None, next_bn=None):
+def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_addend=None):
     """backward of cba_fwd: BN(+ReLU) input gradient, conv weight gradient (into the arena), conv input
     gradient (optionally fused with `dx_addend`).  Returns (dx|None, dres|None).
-    next_bn = (y, out, save) of the BatchNorm+ReLU that consumes dx: on the layer-1 shape the input-gradient kernel then
-    writes that BatchNorm's dz and reduces its two sums in its epilogue (mscl_conv_halo64_dgrad_bn); the tensor returned as dx
-    is registered in PRE_REDUCED and the consumer's cba_bwd runs the apply pass only."""
+    (Rounds 1-3 carried an opt-in fused form -- the layer-1 input-gradient kernel reducing the consuming BatchNorm's sums in its
+    epilogue -- that broke even at best; removed in round 4, see conv_halo.hip.)"""
     rt = bn._rt
     C = conv.out_channels
     G = save.shape[1] if save.dim() == 3 else 1                # statistics groups of the forward pass
-    pre = PRE_REDUCED.pop(dout.data_ptr(), None) if (relu and G == 1) else None
-    if pre is not None and (pre[1].shape != dout.shape or pre[1].data_ptr() != dout.data_ptr()):
-        pre = None
-    if pre is not None:
-        pre = pre[0]
-        # dout is dz (masked by the producer), sums are in `pre`: apply pass only; the identity-shortcut gradient is dz itself
-        dy, _ = K.bn_act_bwd(dout, None, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], 2, pre)
-        dres = dout if want_dres else None
-    else:
-        scratch = K.ZEROS.take(G * K.STAT_SLOTS * 4 * C, dout.device)
-        dy, dres = K.bn_act_bwd(dout, out, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], relu, scratch,
-                                want_identity_dres=want_dres, beta=rt['beta'] if (relu and not want_dres and y.numel() >= MASK_FROM_Y_MIN) else None,
-                                groups=G)
+    scratch = K.ZEROS.take(G * K.STAT_SLOTS * 4 * C, dout.device)
+    dy, dres = K.bn_act_bwd(dout, out, y, rt['gamma'], save[0], save[1], rt['dgamma'], rt['dbeta'], relu, scratch,
+                            want_identity_dres=want_dres, beta=rt['beta'] if (relu and not want_dres and y.numel() >= MASK_FROM_Y_MIN) else None,
+                            groups=G)
     rt['slot_g'].touched = True
     rt['slot_b'].touched = True
     _wgrad(conv, x, dy)
-    dx = None
-    if need_dx:
-        if next_bn is not None and FUSE_BN_REDUCE and G == 1 and conv.halo_shape and conv._rt.get('wT') is not None:
-            ny, nout, nsave = next_bn
-            nscr = K.ZEROS.take(K.STAT_SLOTS * 4 * conv.in_channels, dout.device)
-            dx = K.conv_halo64_dgrad_bn(dy, conv.wT(), conv.desc(x.shape), ny, nout, nsave[0], nsave[1], nscr, addend=dx_addend)
-            if dx is not None:
-                PRE_REDUCED[dx.data_ptr()] = (nscr, dx)      # the reference keeps the address from being reused while registered
-        if dx is None:
-            dx = conv.dgrad(dy, x.shape, addend=dx_addend)
+    dx = conv.dgrad(dy, x.shape, addend=dx_addend) if need_dx else None
     return dx, dres
 
 
@@ -318,8 +285,6 @@ class _StemFn(torch.autograd.Function):
         y, out, save = cba_fwd(conv, bn, x, None, True)
         ctx.stem = stem
         ctx.save_for_backward(x, y, out, save)
-        if FUSE_BN_REDUCE and ctx.needs_input_grad[1]:       # (not for the gradient-free key encoder)
-            LAST_BN[out.data_ptr()] = (y, out, save)
         return out
 
     @staticmethod
@@ -357,15 +322,6 @@ class _BlockFn(torch.autograd.Function):
         y2, out, s2 = cba_fwd(c2, b2, a1, res, True)
         ctx.block = block
         ctx.has_ds = yd is not None
-        ctx.prev_bn = None
-        if FUSE_BN_REDUCE and ctx.needs_input_grad[0]:
-            # the BatchNorm+ReLU whose output this block reads (and is its only reader inside a layer): the gradient this
-            # block returns for x is that BatchNorm's dout
-            if c1.halo_shape and yd is None:
-                prev = LAST_BN.pop(x.data_ptr(), None)
-                if prev is not None and prev[1].shape == x.shape and prev[1].data_ptr() == x.data_ptr():
-                    ctx.prev_bn = prev
-            LAST_BN[out.data_ptr()] = (y2, out, s2)
         if ctx.has_ds:
             ctx.save_for_backward(x, y1, a1, s1, y2, out, s2, yd, sd)
         else:
@@ -381,14 +337,13 @@ class _BlockFn(torch.autograd.Function):
             x, y1, a1, s1, y2, out, s2 = ctx.saved_tensors
         c1, b1 = block.conv1[0], block.conv1[1]
         c2, b2 = block.conv2[0], block.conv2[1]
-        da1, dz = cba_bwd(c2, b2, dout.contiguous(), out, y2, s2, a1, True, need_dx=True, want_dres=True,
-                          next_bn=(y1, a1, s1))
+        da1, dz = cba_bwd(c2, b2, dout.contiguous(), out, y2, s2, a1, True, need_dx=True, want_dres=True)
         if ctx.has_ds:
             dxd, _ = cba_bwd(block.downsample[0], block.downsample[1], dz, None, yd, sd, x, False, need_dx=True)
             shortcut_grad = dxd
         else:
             shortcut_grad = dz
-        dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad, next_bn=ctx.prev_bn)
+        dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
         _bucket_done(block)
         return dx, None
 
@@ -472,7 +427,6 @@ class VideoResNetHip(nn.Module):
             raise ValueError(f'batch of {x.shape[0]} does not split into {bn_groups} BatchNorm groups')
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
-        PRE_REDUCED.clear(); LAST_BN.clear()       # entries only live inside one forward / one backward
         BN_GROUPS[0] = bn_groups
         try:
             x = _StemFn.apply(x, self._anchor, self.stem)
@@ -620,7 +574,6 @@ class _BottleneckTrunk(nn.Module):
             raise ValueError(f'batch of {x.shape[0]} does not split into {bn_groups} BatchNorm groups')
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
-        PRE_REDUCED.clear(); LAST_BN.clear()
         BN_GROUPS[0] = bn_groups               # see VideoResNetHip.forward
         try:
             x = _MaxPoolFn.apply(_StemFn.apply(x, self._anchor, self._stem()))

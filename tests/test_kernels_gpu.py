@@ -203,45 +203,53 @@ def test_conv_pp_forced(case, dev, monkeypatch):
         assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
 
 
-# conv_wgrad_pp.hip (shared-tap ping-pong weight gradient) forced onto small shapes: position tails inside a 62-position K tile,
-# several position splits and a single one, 2 x 2 / 4 x 4 channel tiles, kT = 1, strides along T / H, accumulation into a
-# non-zero dw, and the layer shapes of the step that take it by default (>= 16384 positions) via REAL_CASES above.
-WGRAD_PP_CASES = [c for c in PP_CASES if c[5] % 128 == 0 and c[6] % 128 == 0]
+# conv_halo64b_kernel (conv_halo.hip: two blocks per CU, one window slot, half-tap operand pipeline) with every weight-ring depth:
+# planes smaller than a tile and of several tiles with a ragged last one, the widest plane the window takes (W = 61), T = 1 / 2 (a
+# missing neighbour plane on one or both sides: a zero window), forward with statistics and with an addend, input gradient with and
+# without addend, and the same launch many times over (a race between the window / ring DMA and the fragment reads shows as a
+# changed output).
+HALO2_CASES = [('h2_small', 2, 4, 12, 12), ('h2_plane56', 1, 3, 56, 56), ('h2_tail', 3, 5, 13, 11), ('h2_w61', 1, 2, 9, 61), ('h2_T1', 2, 1, 20, 20)]
 
 
-# a long single map so that every block walks many K tiles through all three ring slots (the small cases stop after 1-6 tiles)
-WGRAD_PP_CASES.append(('pp_ring', 2, 4, 28, 28, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 0))
-
-
-@pytest.mark.parametrize('late', [1, 0], ids=['late', 'inL'])
-@pytest.mark.parametrize('case', WGRAD_PP_CASES, ids=['wg' + c[0] for c in WGRAD_PP_CASES])
-def test_conv_wgrad_pp_forced(case, late, dev, monkeypatch):
-    """late: the DMA pieces issued from the M sections (the default) / from L of phase 0 (the A/B arm), both on the three-slot ring"""
+@pytest.mark.parametrize('ring', [4, 3, 2])
+@pytest.mark.parametrize('case', HALO2_CASES, ids=[c[0] for c in HALO2_CASES])
+def test_conv_halo_two_blocks(case, ring, dev, monkeypatch):
     from mscl_amd import kernels as K_, lib
-    name, N, T, H, W, C, K, kern, stride, pad, _ = case
-    monkeypatch.setenv('MSCL_WGRAD_PP', '2')
-    monkeypatch.setenv('MSCL_WGRAD_PP_LATE', str(late))
+    name, N, T, H, W = case
+    C = K = 64
+    kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    monkeypatch.setenv('MSCL_HALO', '1')
+    monkeypatch.setenv('MSCL_HALO_BLOCKS', '2')
+    monkeypatch.setenv('MSCL_HALO_RING', str(ring))
     lib.tune()
-    x = bf(rnd((N, T, H, W, C), 31)); w = rnd((K, *kern, C), 32)
+    x = bf(rnd((N, T, H, W, C), 51)); w = bf(rnd((K, *kern, C), 52, scale=(2.0 / (C * 27)) ** 0.5))
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
-    xr = x.float(); wr = w.clone().requires_grad_(True)
+    xg, wg = x.to(dev), w.to(dev)
+    n0 = lib.call_raw('mscl_debug_halo_launches')
+    st = torch.zeros((K_.STAT_SLOTS, 2, K), device=dev)
+    y = K_.conv3d_fwd(xg, wg, d, stats=(st[0, 0], st[0, 1]))
+    assert lib.call_raw('mscl_debug_halo_launches') == n0 + 1, 'the forward did not take the window-resident kernel'
+    xr = x.float().requires_grad_(True); wr = w.float()
     yr = _conv_ref(xr, wr, stride, pad)
-    dy = bf(rnd(tuple(yr.shape), 33))
+    close(y, yr, BF16_TOL, 'halo2 fwd')
+    close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'halo2 bn sum')
+    close(st[:, 1].sum(0), (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'halo2 bn sumsq')
+    a = bf(rnd(tuple(yr.shape), 54))
+    close(K_.conv3d_fwd(xg, wg, d, addend=a.to(dev)), yr.detach() + a.float(), BF16_TOL, 'halo2 fwd + addend')
+    dy = bf(rnd(tuple(yr.shape), 55))
     yr.backward(dy.float())
-    dw = torch.zeros((K, *kern, C), dtype=torch.float32, device=dev)
-    db = torch.zeros((K,), dtype=torch.float32, device=dev)
-    n0 = lib.call_raw('mscl_debug_wgrad_pp_launches')
-    K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, db)
-    assert lib.call_raw('mscl_debug_wgrad_pp_launches') == n0 + 1, 'the weight gradient did not take the shared-tap kernel'
-    close(dw, wr.grad, F32_TOL, 'wgrad_pp')
-    close(db, dy.float().sum(dim=(0, 1, 2, 3)), F32_TOL, 'wgrad_pp dbias')
-    first = dw.clone()
-    K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw, None)           # accumulates; fixed-order slab sums: the same bits every run
-    assert torch.equal(dw, 2 * first)
-    for _ in range(5):
-        dw2 = torch.zeros_like(dw)
-        K_.conv3d_wgrad(x.to(dev), dy.to(dev), d, dw2, None)
-        assert torch.equal(dw2, first)
+    wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(wg, wT, K, 27, C)
+    n1 = lib.call_raw('mscl_debug_halo_launches')
+    dx = K_.conv3d_dgrad(dy.to(dev), wT, d)
+    add = bf(rnd(tuple(x.shape), 56))
+    dx2 = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
+    assert lib.call_raw('mscl_debug_halo_launches') == n1 + 2, 'the input gradient did not take the window-resident kernel'
+    close(dx, xr.grad, BF16_TOL, 'halo2 dgrad')
+    close(dx2, xr.grad + add.float(), BF16_TOL, 'halo2 dgrad + addend')
+    y0 = K_.conv3d_fwd(xg, wg, d)
+    for _ in range(20):
+        assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
 
 
 # conv_wgrad_halo.hip (window-resident weight gradient on 64 x 64 channel slices) forced onto small shapes (MSCL_WGRAD_HALO_MIN=1: a
@@ -271,7 +279,8 @@ def test_conv_wgrad_halo_forced(case, waves, dev, monkeypatch):
     if waves == 4 and (C, K) != (64, 64):
         pytest.skip('the one-wave-per-SIMD arm covers 64 -> 64 only')
     kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
-    monkeypatch.setenv('MSCL_WGRAD_HALO_MIN', '1')
+    monkeypatch.setenv('MSCL_WGRAD_HALO_MIN', '1')            # planes of any size
+    monkeypatch.setenv('MSCL_WGRAD_HALO_ITEMS', '0')          # ... and any number of them
     monkeypatch.setenv('MSCL_WGRAD_HALO_WAVES', str(waves))
     lib.tune()
     x = bf(rnd((N, T, H, W, C), 41)); w = rnd((K, *kern, C), 42)
@@ -363,59 +372,6 @@ def test_conv_thin(case, dev):
         lib.tune(MSCL_THIN=None)
 
 
-# conv_win64.hip (persistent window-resident ping-pong kernel, 64 -> 64, 3x3 in plane): tiles that straddle planes and samples,
-# a map smaller than one tile, more tiles than blocks would need on a small grid (the persistent walk), kT = 1, the widest plane
-# (W = 61), the real layer-1 map (1654 tiles over 256 blocks: 6-7 tiles per block, windows prefetched across tile boundaries).
-WIN64_CASES = [
-    ('win64_small', 2, 3, 13, 11, (3, 3, 3), (1, 1, 1)),
-    ('win64_tail', 3, 5, 13, 11, (3, 3, 3), (1, 1, 1)),
-    ('win64_tiny', 1, 2, 5, 6, (3, 3, 3), (1, 1, 1)),
-    ('win64_plane56', 1, 3, 56, 56, (3, 3, 3), (1, 1, 1)),
-    ('win64_133', 2, 4, 14, 14, (1, 3, 3), (0, 1, 1)),
-    ('win64_w61', 1, 2, 10, 61, (3, 3, 3), (1, 1, 1)),
-    ('win64_many_tiles', 6, 16, 56, 56, (3, 3, 3), (1, 1, 1)),
-    ('win64_layer1', 8, 16, 56, 56, (3, 3, 3), (1, 1, 1)),
-]
-
-
-@pytest.mark.parametrize('case', WIN64_CASES, ids=[c[0] for c in WIN64_CASES])
-def test_conv_win64_forced(case, dev, monkeypatch):
-    from mscl_amd import kernels as K_, lib
-    name, N, T, H, W, kern, pad = case
-    C = K = 64
-    stride = (1, 1, 1)
-    monkeypatch.setenv('MSCL_WIN64', '2')
-    lib.tune()
-    x = bf(rnd((N, T, H, W, C), 21)); w = bf(rnd((K, *kern, C), 22, scale=(2.0 / (C * np.prod(kern))) ** 0.5))
-    d = K_.conv_desc(x.shape, K, kern, stride, pad)
-    xg, wg = x.to(dev), w.to(dev)
-    n0 = lib.call_raw('mscl_debug_win64_launches')
-    st = torch.zeros((K_.STAT_SLOTS, 2, K), device=dev)
-    y = K_.conv3d_fwd(xg, wg, d, stats=(st[0, 0], st[0, 1]))
-    assert lib.call_raw('mscl_debug_win64_launches') == n0 + 1, 'the forward did not take the window kernel'
-    xr = x.float().requires_grad_(True); wr = w.float()
-    yr = _conv_ref(xr, wr, stride, pad)
-    close(y, yr, BF16_TOL, 'win64 fwd')
-    close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'win64 bn sum')
-    close(st[:, 1].sum(0), (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'win64 bn sumsq')
-    a = bf(rnd(tuple(yr.shape), 24))
-    y2 = K_.conv3d_fwd(xg, wg, d, addend=a.to(dev))
-    close(y2, yr.detach() + a.float(), BF16_TOL, 'win64 fwd + addend')
-    dy = bf(rnd(tuple(yr.shape), 25))
-    yr.backward(dy.float())
-    wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
-    K_.weight_transpose(wg, wT, K, int(np.prod(kern)), C)
-    add = bf(rnd(tuple(x.shape), 26))
-    n1 = lib.call_raw('mscl_debug_win64_launches')
-    dx = K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev))
-    assert lib.call_raw('mscl_debug_win64_launches') == n1 + 1, 'the input gradient did not take the window kernel'
-    close(dx, xr.grad + add.float(), BF16_TOL, 'win64 dgrad + addend')
-    # race screen: the outputs (not the atomically summed statistics) are a fixed function of the inputs
-    y0 = K_.conv3d_fwd(xg, wg, d)
-    for _ in range(10):
-        assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
-
-
 @pytest.mark.parametrize('W', [24, 23])
 def test_stem_w_paired_equals_plain_stem(W, dev):
     """RGB stem (r3d.py:176-184: Conv3d(3,64,(3,7,7),(1,2,2),(1,3,3))) run on W-paired input (mscl_pair_w): same outputs,
@@ -447,44 +403,6 @@ def test_stem_w_paired_equals_plain_stem(W, dev):
     K_.pair_w_grad_fold(dw8, g)
     close(g, wr.grad, F32_TOL, 'paired stem wgrad')
     assert float(dw8[..., 6:].abs().max()) == 0.0          # (slot j = 3, p = 1 is kw = 7: real pixels, no kernel column -- dropped by the fold)
-
-
-@pytest.mark.parametrize('with_addend', [False, True])
-def test_halo_dgrad_with_fused_bn_reduce(with_addend, dev):
-    """mscl_conv_halo64_dgrad_bn + mscl_bn_act_bwd(relu = 2) against the separate path (mscl_conv3d_dgrad, then the full
-    two-pass mscl_bn_act_bwd) on a real layer-1 plane: same dz, same BatchNorm input gradient, same dgamma / dbeta."""
-    from mscl_amd import kernels as K_
-    N, T, H, W, C = 1, 3, 56, 56, 64
-    d = K_.conv_desc((N, T, H, W, C), C, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-    dy = bf(rnd((N, T, H, W, C), 1)).to(dev)
-    w = bf(rnd((C, 3, 3, 3, C), 2, scale=(2.0 / (C * 27)) ** 0.5)).to(dev)
-    wT = torch.empty((C, 3, 3, 3, C), dtype=torch.bfloat16, device=dev)
-    K_.weight_transpose(w, wT, C, 27, C)
-    add = bf(rnd((N, T, H, W, C), 3)).to(dev) if with_addend else None
-    y = bf(rnd((N, T, H, W, C), 4) * 1.5 + 0.2).to(dev)                 # the consuming BatchNorm's input (conv output) ...
-    gamma = (1 + 0.1 * rnd((C,), 5)).to(dev); beta = (0.1 * rnd((C,), 6)).to(dev)
-    f = y.float().reshape(-1, C)
-    mean = f.mean(0); inv = torch.rsqrt(f.var(0, unbiased=False) + 1e-5)
-    out = torch.relu((y.float() - mean) * inv * gamma + beta).to(torch.bfloat16)          # ... and its ReLU output (the mask)
-    # separate path
-    dx = K_.conv3d_dgrad(dy, wT, d, addend=add)
-    dg0, db0 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    dyb0, dz0 = K_.bn_act_bwd(dx, out, y, gamma, mean, inv, dg0, db0, True, torch.zeros(K_.STAT_SLOTS * 4 * C, device=dev),
-                              want_identity_dres=True)
-    # fused path
-    scr = torch.zeros(K_.STAT_SLOTS * 4 * C, device=dev)
-    dz = K_.conv_halo64_dgrad_bn(dy, wT, d, y, out, mean, inv, scr, addend=add)
-    assert dz is not None, 'the layer-1 plane must be covered by the window-resident kernel'
-    assert torch.equal(dz, dz0)
-    dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    dyb1, _ = K_.bn_act_bwd(dz, None, y, gamma, mean, inv, dg1, db1, 2, scr)
-    close(dyb1, dyb0, 2e-3, 'bn input gradient (fused reduce)')
-    close(dg1, dg0, 1e-4, 'dgamma (fused reduce)'); close(db1, db0, 1e-4, 'dbeta (fused reduce)')
-    # a small plane is not covered: nothing launched, caller falls back
-    d2 = K_.conv_desc((1, 2, 8, 8, C), C, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-    small = torch.zeros((1, 2, 8, 8, C), dtype=torch.bfloat16, device=dev)
-    if os.environ.get('MSCL_HALO') != '1':
-        assert K_.conv_halo64_dgrad_bn(small, wT, d2, small, small, mean, inv, scr) is None
 
 
 @pytest.mark.parametrize('C,relu,resmode', [(64, True, 'none'), (64, True, 'identity'), (128, True, 'bn'),

@@ -1028,43 +1028,6 @@ def test_step_other_shapes(B, T, H, W, dev):
     assert torch.equal(model.recognizer_flow.count.cpu(), orc.recognizer_flow.count)
 
 
-def test_fused_bn_reduce_path_matches_default(dev):
-    """MSCL_FUSE_BN_REDUCE=1 (layer-1 input gradients reduce the consuming BatchNorm's sums in their epilogue, within a block
-    and across blocks / into the stem): same trunk gradients as the default two-pass BatchNorm backward."""
-    from mscl_amd import nn as nn_hip
-    from mscl_amd.synthetic import synthetic_batch
-    B, T, H = 2, 4, 112
-    x = synthetic_batch(B, T, H, H, 0, 0)['imgs'][0].to(dev)
-    grads = []
-    for fused in (False, False, True):      # two default runs calibrate the run-to-run noise (fp32 atomics reorder, BatchNorm
-                                            # backward amplifies it: ~0.97 cosine on the conv kernels of this tiny batch)
-        old = nn_hip.FUSE_BN_REDUCE
-        nn_hip.FUSE_BN_REDUCE = fused
-        try:
-            model, _ = build(T, 64, dev)
-            model.zero_grad()
-            maps = model.recognizer.encoder_q(model.aug_gpu.pack_rgb(x))
-            (maps[-1].float().mean() + maps[0].float().mean()).backward()
-            torch.cuda.synchronize()
-            grads.append({n: p.grad.detach().float().clone() for n, p in model.recognizer.encoder_q.named_parameters()})
-            if fused:
-                assert not nn_hip.PRE_REDUCED, 'every pre-reduced gradient must have been consumed'
-        finally:
-            nn_hip.FUSE_BN_REDUCE = old
-    cos = torch.nn.functional.cosine_similarity
-    tot = sum(float(g.double().pow(2).sum()) for g in grads[0].values()) ** 0.5
-    for n, g0 in grads[0].items():
-        g0b, g1 = grads[1][n], grads[2][n]
-        if float(g0.norm()) < 1e-3 * tot:
-            continue
-        noise = float(cos(g0.flatten(), g0b.flatten(), dim=0))
-        c = float(cos(g0.flatten(), g1.flatten(), dim=0))
-        # a wrong pairing of gradient, mask and statistics gives unrelated gradients; the two draws of the noise themselves
-        # differ by a few hundredths, so the bar is the lower of 0.90 and what the default path reaches against itself
-        assert c >= min(0.90, noise - 0.05), (n, c, noise)
-        assert abs(float(g1.norm()) - float(g0.norm())) <= 0.08 * float(g0.norm()) + abs(float(g0b.norm()) - float(g0.norm())), n
-
-
 def test_r3d18_single_stream_full_size(dev):
     """BASELINE.json configs[1]: the R3D-18 trunk alone, forward + backward on one (8, 3, 16, 112, 112) batch, loss = mean
     of the layer-4 map, against the oracle trunk on the host (fp32).  bf16 storage tolerances as in the step test:
