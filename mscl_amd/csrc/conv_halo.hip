@@ -329,19 +329,22 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
 //    (tap + 1, k step 0) while (tap, k step 1) multiplies -- two sets of 6 fragments instead of two sets of 12: 48 operand
 //    registers instead of 96, which is what brings the kernel under 128 registers;
 //  * one barrier per tap as before (publishes the next tap's weight tile, frees this tap's ring stage), RING stages of 8 KB.
-template <int RING>
-__global__ __launch_bounds__(512, 4) void conv_halo64b_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
+// NW = 8: 32 positions x 64 channels per wave, 12 fragment reads per 16 MFMAs -- with two blocks on the CU the LDS then moves 110 KB per
+// tap and block against 512 MFMA-clocks: 84 % as busy as the matrix pipes.  NW = 4: 64 x 64 per wave, 16 reads per 32 MFMAs, 75 KB.
+template <int NW, int RING>
+__global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                               const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
                                                               float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NW = 8, BM = 256;
+  constexpr int BM = 256;
   constexpr int RPP = 8 * NW;                              // window rows per DMA pass
   constexpr int NHK = (BM + 128 + RPP - 1) / RPP * RPP;    // 384 window rows (BM + 2 * (W + 2) + 2, W <= 61)
   constexpr int PLANE = NHK * 128;
-  constexpr int NPS = NHK / RPP;                           // 6 DMA pieces per thread per plane
-  constexpr int WPOS = BM / NW, IM = WPOS / 16;            // 32 positions per wave, 2 position tiles
-  static_assert(RING >= 2 && RING <= 4, "weight ring");
+  constexpr int NPS = NHK / RPP;                           // 6 / 12 DMA pieces per thread per plane
+  constexpr int WPOS = BM / NW, IM = WPOS / 16;            // 32 / 64 positions per wave, 2 / 4 position tiles
+  constexpr int WP = 8 / NW;                               // DMA instructions per weight tile per wave
+  static_assert(RING >= 2 && RING <= 4 && (NW == 8 || NW == 4), "configuration");
   unsigned char* const Hs = smem;                          // [NHK][128 B] the one window slot, row j <-> q0 - Wp - 1 + j
   unsigned char* const Ws = smem + PLANE;                  // [RING][64][128 B] weight ring
   const int tid = threadIdx.x, lane = tid & 63;
@@ -375,9 +378,12 @@ __global__ __launch_bounds__(512, 4) void conv_halo64b_kernel(const HaloGeom g, 
   };
   const int w_row = tid >> 3, w_lg = tid & 7;
   const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);     // source-side swizzle
+  const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
   auto issue_weights = [&](int tap) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(Ws + (tap % RING) * (64 * 128) + wave * 1024), 16, w_voff0, so, 0, 0);
+    unsigned char* dst = Ws + (tap % RING) * (64 * 128) + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
+    if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
   };
   auto tap_plane = [&](int kt) { return mode ? 2 - kt : kt; };
   auto tap_shift = [&](int kh, int kw) { return mode ? (2 - kh) * g.Wp + (2 - kw) : kh * g.Wp + kw; };
@@ -415,8 +421,9 @@ __global__ __launch_bounds__(512, 4) void conv_halo64b_kernel(const HaloGeom g, 
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], acc[j][i], 0, 0, 0);
   };
 #define HB_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
-  // plane + tap-0 weights landed; the other RING - 1 weight tiles stay in flight
-  if constexpr (RING == 4) HB_WAIT(3); else if constexpr (RING == 3) HB_WAIT(2); else HB_WAIT(1);
+  // plane + tap-0 weights landed; the other RING - 1 weight tiles (WP instructions each) stay in flight
+  if constexpr (WP * (RING - 1) == 6) HB_WAIT(6); else if constexpr (WP * (RING - 1) == 4) HB_WAIT(4);
+  else if constexpr (WP * (RING - 1) == 3) HB_WAIT(3); else if constexpr (WP * (RING - 1) == 2) HB_WAIT(2); else HB_WAIT(1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   read_half(0, 0, 0);
@@ -446,8 +453,8 @@ __global__ __launch_bounds__(512, 4) void conv_halo64b_kernel(const HaloGeom g, 
       }
       // wait for the weight tile of tap + 1 (everything issued after it may stay in flight: RING - 2 tiles, fewer at the end),
       // retire this wave's reads of tap's stage; the barrier publishes the one and frees the other
-      const int younger = (RING - 2) < (25 - tap) ? (RING - 2) : (25 - tap > 0 ? 25 - tap : 0);
-      if (younger >= 2) HB_WAIT(2); else if (younger == 1) HB_WAIT(1); else HB_WAIT(0);
+      const int younger = WP * ((RING - 2) < (25 - tap) ? (RING - 2) : (25 - tap > 0 ? 25 - tap : 0));
+      if (younger >= 4) HB_WAIT(4); else if (younger == 2) HB_WAIT(2); else if (younger == 1) HB_WAIT(1); else HB_WAIT(0);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (tap + RING < 27) issue_weights(tap + RING);
@@ -566,24 +573,29 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
   // Two waves per SIMD, 256-position tiles, 4-stage weight ring.  Measured and dropped (all inside the three-stream step, alternating
   // pairs in one call): one wave per SIMD (920-923 vs 927-931 clip-pairs/s), 128-position tiles at two blocks per CU (901-902 vs
   // 903-907), a 2-stage ring that leaves room for another chain's block on the CU (no gain).
-  // MSCL_HALO_BLOCKS: 1 = one 128-KB block per CU (conv_halo64_kernel, the round-1..3 form), 2 = two blocks per CU with one window
-  // slot each (conv_halo64b_kernel); MSCL_HALO_RING: weight ring stages of the two-block form (2..4; 4 = 80 KB, the LDS of a CU split
-  // exactly in two)
+  // MSCL_HALO_BLOCKS: 2 (default) = two blocks per CU with one window slot each (conv_halo64b_kernel), 1 = one 128-KB block per CU
+  // (conv_halo64_kernel, the round-1..3 form).  Measured in one process (fwd / dgrad of the layer-1 map): 108-111 / 95-96 us -> 92-93 /
+  // 81-82 us; step 1078-1082 -> 1097-1101 clip-pairs/s.  MSCL_HALO_RING: weight ring stages of the two-block form (2, 3, 4 measured
+  // alike: 93.3 / 92.1 / 92.8 us; 3 = 72 KB per block is the default)
   static MsclTune t_blocks("MSCL_HALO_BLOCKS"), t_ring("MSCL_HALO_RING");
   const unsigned nblk = (unsigned)(d->N * d->T * g.tiles);
-  if (t_blocks.get(1) == 2) {
+  if (t_blocks.get(2) == 2) {
     static bool attr2 = false;
     if (!attr2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr2 = true;
     }
-    const int ring = t_ring.get(4);
+    static MsclTune t_waves("MSCL_HALO_WAVES");           // waves per block of the two-block form: 8 (default) or 4 (ring of 3)
+    const int ring = t_ring.get(3);
     const size_t lds2 = (size_t)384 * 128 + (size_t)(ring < 2 ? 2 : (ring > 4 ? 4 : ring)) * 64 * 128;
-    if (ring <= 2) hipLaunchKernelGGL((conv_halo64b_kernel<2>), dim3(nblk), dim3(512), lds2, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
-    else if (ring == 3) hipLaunchKernelGGL((conv_halo64b_kernel<3>), dim3(nblk), dim3(512), lds2, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
-    else hipLaunchKernelGGL((conv_halo64b_kernel<4>), dim3(nblk), dim3(512), lds2, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
+    hipStream_t hs = (hipStream_t)stream;
+    if (t_waves.get(8) == 4) hipLaunchKernelGGL((conv_halo64b_kernel<4, 3>), dim3(nblk), dim3(256), (size_t)384 * 128 + 3 * 64 * 128, hs, g, src, w, out, addend, ssum, ssq);
+    else if (ring <= 2) hipLaunchKernelGGL((conv_halo64b_kernel<8, 2>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
+    else if (ring == 3) hipLaunchKernelGGL((conv_halo64b_kernel<8, 3>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
+    else hipLaunchKernelGGL((conv_halo64b_kernel<8, 4>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
     MSCL_LAUNCH_CHECK();
     ++g_halo_launches;
     return 1;

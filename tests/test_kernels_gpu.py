@@ -211,15 +211,19 @@ def test_conv_pp_forced(case, dev, monkeypatch):
 HALO2_CASES = [('h2_small', 2, 4, 12, 12), ('h2_plane56', 1, 3, 56, 56), ('h2_tail', 3, 5, 13, 11), ('h2_w61', 1, 2, 9, 61), ('h2_T1', 2, 1, 20, 20)]
 
 
-@pytest.mark.parametrize('ring', [4, 3, 2])
+@pytest.mark.parametrize('blocks,waves,ring', [(2, 8, 3), (2, 8, 4), (2, 8, 2), (2, 4, 3), (1, 8, 4)],
+                         ids=['b2w8r3', 'b2w8r4', 'b2w8r2', 'b2w4r3', 'one_block'])
 @pytest.mark.parametrize('case', HALO2_CASES, ids=[c[0] for c in HALO2_CASES])
-def test_conv_halo_two_blocks(case, ring, dev, monkeypatch):
+def test_conv_halo_two_blocks(case, blocks, waves, ring, dev, monkeypatch):
+    """every form of the window-resident layer-1 conv: two blocks per CU (the default: 8 waves, ring of 3) with each ring depth and
+    with 4 waves per block, and the one-block-per-CU form of rounds 1-3 (the A/B arm)"""
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W = case
+    monkeypatch.setenv('MSCL_HALO_WAVES', str(waves))
     C = K = 64
     kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     monkeypatch.setenv('MSCL_HALO', '1')
-    monkeypatch.setenv('MSCL_HALO_BLOCKS', '2')
+    monkeypatch.setenv('MSCL_HALO_BLOCKS', str(blocks))
     monkeypatch.setenv('MSCL_HALO_RING', str(ring))
     lib.tune()
     x = bf(rnd((N, T, H, W, C), 51)); w = bf(rnd((K, *kern, C), 52, scale=(2.0 / (C * 27)) ** 0.5))
@@ -264,7 +268,7 @@ WGRAD_HALO_CASES = [
     ('wh_64_64_plane56', 1, 3, 56, 56, 64, 64),
     ('wh_128_128', 1, 3, 9, 10, 128, 128),
     ('wh_128_64', 2, 3, 13, 11, 128, 64),
-    ('wh_64_192_T2', 2, 2, 11, 13, 64, 192),
+    ('wh_64_256_T2', 2, 2, 11, 13, 64, 256),
     ('wh_256_256', 1, 2, 7, 7, 256, 256),
     ('wh_128_128_plane28', 2, 3, 28, 28, 128, 128),
     ('wh_256_128_many_items', 8, 4, 14, 14, 256, 128),
