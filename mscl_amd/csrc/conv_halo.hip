@@ -585,15 +585,14 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr2 = true;
     }
-    static MsclTune t_waves("MSCL_HALO_WAVES");           // waves per block of the two-block form: 8 (default) or 4 (ring of 3)
+    // (4 waves per block, 64 x 64 per wave -- 16 fragment reads per 32 MFMAs instead of 12 per 16 -- measured like 8: 91.6 vs 95.4 us
+    // forward, 83.2 vs 82.1 input gradient, step 1074-1090 vs 1076-1082; the template still takes NW = 4)
     const int ring = t_ring.get(3);
     const size_t lds2 = (size_t)384 * 128 + (size_t)(ring < 2 ? 2 : (ring > 4 ? 4 : ring)) * 64 * 128;
     hipStream_t hs = (hipStream_t)stream;
-    if (t_waves.get(8) == 4) hipLaunchKernelGGL((conv_halo64b_kernel<4, 3>), dim3(nblk), dim3(256), (size_t)384 * 128 + 3 * 64 * 128, hs, g, src, w, out, addend, ssum, ssq);
-    else if (ring <= 2) hipLaunchKernelGGL((conv_halo64b_kernel<8, 2>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
+    if (ring <= 2) hipLaunchKernelGGL((conv_halo64b_kernel<8, 2>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
     else if (ring == 3) hipLaunchKernelGGL((conv_halo64b_kernel<8, 3>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
     else hipLaunchKernelGGL((conv_halo64b_kernel<8, 4>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
     MSCL_LAUNCH_CHECK();
