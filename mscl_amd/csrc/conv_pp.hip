@@ -298,225 +298,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
                                             stat_sq, relu, partial);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Round 4: the same kernel with TWO blocks per CU (conv_pp2_kernel).  In-kernel stamps (profiles/r04_pp_stamps.md) put the main
-// loop of conv_pp_kernel<128> at ~80 % matrix-pipe busy -- L 510, M 530, barrier waits 230 cycles per phase and wave -- while the
-// launch as a whole runs at 0.39-0.42 of peak on the 128 -> 128 layer and far less on the split-K layers: the time is OUTSIDE the loop
-// (212 blocks on 256 CUs, an 80-KB prologue before the first MFMA, the statistics / store epilogue, the launch ramp; 27 or 14 phases
-// per block on layers 3 / 4).  Here a block is half the size -- 128 rows (126 stored), 80 KB of LDS, <= 128 registers -- so two share
-// a CU and one's prologue and epilogue run under the other's phases, and a 50176-position map makes 427 blocks for 512 slots.
-//  * 8 waves as 4 (positions) x 2 (channels) of 32 x 64: 12 fragment reads and 16 MFMAs per phase and wave;
-//  * THREE weight slots (tile kw of every group lives in slot kw) and two 16-KB position slots.  Issue, per group g:
-//      Q0: A(g+1), B(g,2)      Q1: B(g+1,0)      Q2: B(g+1,1)
-//    waits (after the issues of the same L section):  Q0: B(g,1) landed = vmcnt(NA + UB)   Q1: B(g,2) landed = vmcnt(UB)
-//    Q2: A(g+1), B(g+1,0) landed = vmcnt(UB).  Every unit is waited for one phase after its issue and first read one phase after that
-//    (R1); a slot is re-issued in the L section after the one that read it last (R2): B slot kw was read in L of phase kw and is
-//    refilled in L of phase kw + 1, the position slot of group g - 1 was last read in L of its phase 2 and is refilled in L of Q0(g).
-//  Twice the weight traffic per position of the one-block form (a weight tile serves 126 rows instead of 254).
-template <int BN>
-__global__ __launch_bounds__(512, 4) void conv_pp2_kernel(
-    const IGemmGeom g, const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
-    const float* __restrict__ bias, const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
-    float* __restrict__ stat_sq, const int relu, float* __restrict__ partial) {
-  constexpr int BM = 128, KW = 3, HALO = 1, OUT_ROWS = BM - 2 * HALO, NB = 3;
-  constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;
-  constexpr int UB = BN / 64;                     // DMA instructions per thread per weight tile
-  constexpr int NA = BM / 64;                     // ... per position tile
-  constexpr int A_BASE = NB * B_SLOT;             // weight ring first: the row "-1" read of position fragment 0 stays inside LDS
-  constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N, WM = BM / WAVES_M, WN = 64;
-  constexpr int IM = WM / 16, JN = WN / 16;
-  constexpr unsigned OOB = 0x80000000u;
-  static_assert(BN == 128 && JN == 4 && IM == 2, "tile config");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                      // 0: waves 0-3, 1: waves 4-7 (the SIMD partners of 0-3), one barrier behind
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = bid % g.ksplit; bid /= g.ksplit;
-  const int nt = bid % g.ntiles; const int mt = bid / g.ntiles;
-  const int n0 = nt * BN;
-  const int q0 = mt * OUT_ROWS - HALO;            // padded-linear position of LDS row 0
-  const int mode = __builtin_amdgcn_readfirstlane(g.mode);      // 0 forward, 1 stride-1 input gradient
-  const int Wp = g.Wr + 2 * HALO, Mp = g.M;
-  const int cs2 = g.Cs * 2;
-  const int maxlin = ((g.kT - 1) * g.Hs + (g.kH - 1)) * g.Ws;
-  const int padlin = (g.pT * g.Hs + g.pH) * g.Ws + HALO;
-  const int bias_bytes = (mode == 0 ? padlin : maxlin) * cs2;
-
-  const int rg = tid & 7, rr = tid >> 3;          // granule column / row inside a 64-row staging pass
-  auto skey = [&](int row) { return row & 7; };
-  const int rgl = rg ^ skey(rr);                  // logical granule this lane fetches
-  unsigned wrow_voff[UB];
-#pragma unroll
-  for (int p = 0; p < UB; ++p) {
-    const int r = p * 64 + rr;
-    wrow_voff[p] = (n0 + r < g.Cr) ? (unsigned)((n0 + r) * g.KG * 16 + rgl * 16) : OOB;
-  }
-  const unsigned char* src_b = reinterpret_cast<const unsigned char*>(src) - bias_bytes;
-  const auto rs_src = make_uniform_rsrc(src_b, 0x7FFFFFFFu);
-  const auto rs_wgt = make_uniform_rsrc(wgt, 0x7FFFFFFFu);
-
-  const int subs = g.cgs - 3, submask = (1 << subs) - 1;        // 64-channel parts per tap = Cs / 64
-  const int ng_all = (g.kT * g.kH) << subs;
-  const int g_beg = (int)((long)ng_all * split / g.ksplit), g_end = (int)((long)ng_all * (split + 1) / g.ksplit);
-  auto group_soff = [&](int gi, unsigned& soff, int& tb, unsigned& woff) {
-    const int tk = gi >> subs, cpart = gi & submask;
-    const int kt = fdiv(tk, g.dKH), kh = tk - kt * g.kH;
-    const int lin = (kt * g.Hs + kh) * g.Ws;
-    soff = __builtin_amdgcn_readfirstlane((unsigned)((mode == 0 ? lin : maxlin - lin) * cs2 + cpart * 128));
-    tb = __builtin_amdgcn_readfirstlane((1 << kt) | (1 << (8 + kh)));
-    woff = __builtin_amdgcn_readfirstlane((unsigned)((((tk * KW) << subs) + cpart) * 128));      // kw = 0; kw adds Cs * 2 bytes
-  };
-  auto issue_b = [&](unsigned slot, unsigned woff) {
-    unsigned char* b = smem + slot + wave * 1024;
-#pragma unroll
-    for (int p = 0; p < UB; ++p) {
-      const unsigned wv = wrow_voff[p];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(b + p * 8192), 16, wv, woff, 0, 0);
-    }
-  };
-  unsigned soff_c = 0, woff_c = 0; int tb_c = 0;  // current group
-  unsigned soff_n = 0, woff_n = 0; int tb_n = 0;  // next group
-  const unsigned wstep = (unsigned)cs2;           // bytes from a (kt, kh, kw) weight tile to the (kt, kh, kw + 1) one
-  // ---- prologue, part 1: weight tiles 0 and 1 of the first group need no row state; they travel while the rows are set up ----
-  group_soff(g_beg, soff_c, tb_c, woff_c);
-  issue_b(0 * B_SLOT, woff_c);
-  issue_b(1 * B_SLOT, woff_c + wstep);
-  int row_voff[NA], row_mask[NA];
-#pragma unroll
-  for (int p = 0; p < NA; ++p) {
-    const int q = q0 + p * 64 + rr;
-    int mask = 0, base = 0;
-    if (q >= 0 && q < Mp) {
-      const int nth = fdiv(q, g.dW), w0 = q - nth * Wp - HALO;
-      if ((unsigned)w0 < (unsigned)g.Ws) {
-        const int q2 = fdiv(nth, g.dH), hr = nth - q2 * g.Hr;
-        const int n = fdiv(q2, g.dT), tr = q2 - n * g.Tr;
-        int t0, h0;
-        if (mode == 0) { t0 = tr * g.sT - g.pT; h0 = hr * g.sH - g.pH; }
-        else { t0 = tr + g.pT; h0 = hr + g.pH; }
-        const int tlo = (mode == 0) ? max(0, -t0) : max(0, t0 - g.Ts + 1), thi = (mode == 0) ? min(g.kT, g.Ts - t0) : min(g.kT, t0 + 1);
-        const int hlo = (mode == 0) ? max(0, -h0) : max(0, h0 - g.Hs + 1), hhi = (mode == 0) ? min(g.kH, g.Hs - h0) : min(g.kH, h0 + 1);
-        mask = (thi > tlo ? ((1 << thi) - (1 << tlo)) : 0) | (hhi > hlo ? (((1 << hhi) - (1 << hlo)) << 8) : 0);
-        base = ((n * g.Ts + t0) * g.Hs + h0) * g.Ws + w0;
-      }
-    }
-    row_voff[p] = base * cs2 + (mode == 0 ? bias_bytes : 0) + rgl * 16;      // >= 0 for every row with a valid tap
-    row_mask[p] = mask;
-  }
-  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4_t acc[JN][IM];
-#pragma unroll
-  for (int j = 0; j < JN; ++j)
-#pragma unroll
-    for (int i = 0; i < IM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  unsigned a_off[KW][2], b_off[2];
-#pragma unroll
-  for (int kw = 0; kw < KW; ++kw)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int row = wm0 + fr + (mode == 0 ? kw - HALO : HALO - kw);        // may be -1 / BM on the two rows that are not stored
-      a_off[kw][ks] = lds_base + A_BASE + (unsigned)(row * 128 + (((ks * 4 + fq) ^ skey(row)) * 16));
-    }
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int row = wn0 + fr;
-    b_off[ks] = lds_base + (unsigned)(row * 128 + (((ks * 4 + fq) ^ skey(row)) * 16));
-  }
-  auto issue_a = [&](unsigned slot, unsigned soff, int tb) {
-    unsigned char* a = smem + A_BASE + slot + wave * 1024;
-#pragma unroll
-    for (int p = 0; p < NA; ++p) {
-      const unsigned off = ((row_mask[p] & tb) == tb) ? (unsigned)row_voff[p] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_ptr_t)(a + p * 8192), 16, off, soff, 0, 0);
-    }
-  };
-  unsigned a_cur = 0;                             // byte offset of the current group's position slot (0 / A_SLOT)
-
-  // ---- prologue, part 2: the first position tile; tile 2 of the first group is issued by its own Q0 ----
-  issue_a(0, soff_c, tb_c);
-  PP_VMCNT(0);
-  __builtin_amdgcn_s_barrier();
-
-  u32x4_t fa[2][IM], fb[2][JN];
-  int gi = g_beg;
-  bool has_next = gi + 1 < g_end;
-  if (has_next) group_soff(gi + 1, soff_n, tb_n, woff_n);
-  auto advance = [&]() {
-    a_cur ^= (unsigned)A_SLOT;
-    ++gi;
-    soff_c = soff_n; tb_c = tb_n; woff_c = woff_n;
-    has_next = gi + 1 < g_end;
-    if (has_next) group_soff(gi + 1, soff_n, tb_n, woff_n);
-  };
-  auto Lsec = [&](auto PC) {
-    constexpr int kw = decltype(PC)::value;
-    const unsigned a_nxt = a_cur ^ (unsigned)A_SLOT;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned aa = a_off[kw][ks] + a_cur, ba = b_off[ks] + (unsigned)(kw * B_SLOT);
-      PP_DSR(fa[ks][0], aa, 0); PP_DSR(fa[ks][1], aa, 2048);
-      PP_DSR(fb[ks][0], ba, 0); PP_DSR(fb[ks][1], ba, 2048); PP_DSR(fb[ks][2], ba, 4096); PP_DSR(fb[ks][3], ba, 6144);
-    }
-    if constexpr (kw == 0) {
-      if (has_next) issue_a(a_nxt, soff_n, tb_n);
-      issue_b(2 * B_SLOT, woff_c + 2 * wstep);                 // this group's own third tile (slot 2 was read in L of the last phase)
-      if (has_next) PP_VMCNT(NA + UB); else PP_VMCNT(UB);     // B(g,1) landed
-    }
-    if constexpr (kw == 1) {
-      if (has_next) { issue_b(0 * B_SLOT, woff_n); PP_VMCNT(UB); } else PP_VMCNT(0);      // B(g,2) landed
-    }
-    if constexpr (kw == 2) {
-      if (has_next) { issue_b(1 * B_SLOT, woff_n + wstep); PP_VMCNT(UB); }                // A(g+1), B(g+1,0) landed
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fa[1][0]),
-                   "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto Msec = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int i = 0; i < IM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb[ks][j]),
-                                                              __builtin_bit_cast(bf16x8_t, fa[ks][i]), acc[j][i], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  const int ng = g_end - g_beg;
-  if (grp == 1) __builtin_amdgcn_s_barrier();
-  for (int n = 0; n < ng; ++n) {
-    Lsec(IC<0>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
-    Lsec(IC<1>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
-    Lsec(IC<2>{}); __builtin_amdgcn_s_barrier(); Msec(); __builtin_amdgcn_s_barrier();
-    advance();
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with the last barrier of waves 4-7
-
-  long orow[IM];
-#pragma unroll
-  for (int i = 0; i < IM; ++i) {
-    const int idx = wm0 + i * 16 + fr;
-    const int q = q0 + idx;
-    long o = -1;
-    if (idx >= HALO && idx < BM - HALO && q < Mp) {
-      const int nth = fdiv(q, g.dW), w0 = q - nth * Wp - HALO;
-      if ((unsigned)w0 < (unsigned)g.Wr) o = ((long)nth * g.Wr + w0) * g.Cr;
-    }
-    orow[i] = o;
-  }
-  igemm_epilogue_rows<BM, BN, IM, JN, true>(g, acc, smem, tid, fr, fq, 0, n0, wm0, wn0, split, 0, orow, out, bias, addend, stat_sum,
-                                            stat_sq, relu, partial);
-}
+// Round 4, measured and dropped: the same kernel with TWO blocks per CU (128-row blocks, three weight slots, 80 KB of LDS, 104
+// registers), built because the stamps of profiles/r04_pp_stamps.md put the main loop at ~80 % matrix-pipe busy and the launch's loss
+// outside it (212 blocks on 256 CUs, the 80-KB prologue, the epilogue; 27 / 14 phases per block on the split-K layers).  Correct
+// (parity + race screen) and a tie: 128 -> 128 forward / input gradient 47.5 / 43.5 vs 47.0 / 43.8 us, 256 -> 256 37.8 / 32.8 vs
+// 38.6 / 33.7, 512 -> 512 32.5 / 30.7 vs 28.6 / 26.9, SEPC 44.3 / 41.4 vs 42.1 / 39.5, the 1x3x3 pyramid level 17.4 / 15.0 vs 20.7 /
+// 18.1; step 1080-1083 vs 1078-1097 clip-pairs/s.  A half-size block halves the MFMAs of a phase but not its DMA instructions (the
+// weight tile of a phase stays 16 KB) and reads 1.5 x the LDS bytes per MFMA: what the second block hides, the longer L sections and
+// the doubled weight traffic give back.  (Unlike the layer-1 kernel, conv_halo.hip, whose window is read once whatever the block size.)
 
 // ------------------------------------------------------------------------------------------------------------- host side
 static long g_pp_launches = 0;
@@ -525,12 +314,9 @@ extern "C" int64_t mscl_debug_pp_launches(void) { return g_pp_launches; }     //
 // Returns 0 when launched, MSCL_PP_SKIP when the shape is outside this kernel (the caller falls back to conv_igemm.hip).
 int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const float* bias, const bf16_t* addend,
                         float* ssum, float* ssq, int relu, float* ws, long ws_floats, hipStream_t st) {
+  constexpr int OUT_ROWS = 254;
   const int BN = (g.Cr % 128 == 0) ? 128 : 64;
-  // MSCL_PP_BLOCKS: 2 = two 128-row blocks per CU (conv_pp2_kernel; 128-multiple output channels only), 1 = one 256-row block per CU
-  static MsclTune t_blk("MSCL_PP_BLOCKS");
-  const bool two = BN == 128 && t_blk.get(1) == 2;
-  const int OUT_ROWS = two ? 126 : 254;
-  const long slots = two ? 512 : 256;             // blocks of one round
+  constexpr long slots = 256;                     // blocks of one round
   if (g.mode == 2 || g.nclass != 0 || g.grp_rows != 0) return MSCL_PP_SKIP;
   if (g.kW != 3 || g.pW != 1 || g.sW != 1 || g.Wr != g.Ws) return MSCL_PP_SKIP;
   if (g.cgs < 3 || (g.Cs & 63) != 0 || (g.Cr % 64) != 0) return MSCL_PP_SKIP;
@@ -562,9 +348,9 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     if (want >= 1 && want <= ng && (want == 1 || (ws != nullptr && want * out_elems <= ws_floats && g.Cr <= 512))) g.ksplit = (int)want;
   }
   float* partial = g.ksplit > 1 ? ws : nullptr;
-  const size_t lds = two ? (size_t)3 * 128 * 128 + 2 * 128 * 128 : 4 * (size_t)BN * 128 + 2 * 256 * 128;
-  const int which = two ? 2 : (BN == 64 ? 1 : 0);
-  static bool attr_done[3] = {false, false, false};    // per kernel (the instantiations have the same function type: ONE lambda body)
+  const size_t lds = 4 * (size_t)BN * 128 + 2 * 256 * 128;
+  const int which = BN == 64 ? 1 : 0;
+  static bool attr_done[2] = {false, false};    // per kernel (the instantiations have the same function type: ONE lambda body)
   auto go = [&](auto kern) {
     if (!attr_done[which]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -573,7 +359,7 @@ int mscl_launch_conv_pp(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * g.ksplit)), dim3(512), lds, st, g, src, wgt, out, bias, addend, ssum, ssq, relu,
                        partial);
   };
-  if (which == 2) go(conv_pp2_kernel<128>); else if (which == 1) go(conv_pp_kernel<64>); else go(conv_pp_kernel<128>);
+  if (which == 1) go(conv_pp_kernel<64>); else go(conv_pp_kernel<128>);
   MSCL_LAUNCH_CHECK();
   ++g_pp_launches;
   if (g.ksplit > 1) return mscl_launch_splitk_finalize(partial, out, bias, addend, relu, ssum, ssq, out_elems / g.Cr, g.Cr, g.ksplit, 0, st);

@@ -163,16 +163,10 @@ PP_CASES = [
 ]
 
 
-@pytest.mark.parametrize('blocks', [2, 1], ids=['two_blocks', 'one_block'])
 @pytest.mark.parametrize('case', PP_CASES, ids=[c[0] for c in PP_CASES])
-def test_conv_pp_forced(case, blocks, dev, monkeypatch):
-    """blocks: conv_pp2_kernel (two 128-row blocks per CU, three weight slots; layers with 128-multiple output channels) / conv_pp_kernel
-    (one 256-row block per CU, four weight slots) -- two schedules, each with the full parity + repeat-launch race screen"""
+def test_conv_pp_forced(case, dev, monkeypatch):
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K, kern, stride, pad, ksplit = case
-    if blocks == 2 and K % 128:
-        pytest.skip('the two-block form covers 128-multiple output channels')
-    monkeypatch.setenv('MSCL_PP_BLOCKS', str(blocks))
     monkeypatch.setenv('MSCL_PP', '2')
     monkeypatch.setenv('MSCL_HALO', '0')          # (the window-resident layer-1 kernel would take the 64 -> 64 cases first)
     if ksplit:
