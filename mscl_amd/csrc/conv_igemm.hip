@@ -374,15 +374,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_fast_kernel
     }
   };
 
-  static_assert(STAGES == 2, "two LDS stages");
+  // STAGES == 1: layers whose whole reduction is ONE K step (1x1x1 convs from 64 channels: the write-heavy convs of the Bottleneck
+  // trunks).  Nothing is ever staged behind the first tile, so half the LDS serves and twice the blocks share a CU -- for a launch
+  // that is a staging round trip, 0.15 us of MFMA work and an epilogue per block, resident blocks are what hides the latency.
+  static_assert(STAGES == 2 || STAGES == 1, "LDS stages");
   if (k_beg < k_end) {
     issue(k_beg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   for (int kt = k_beg; kt < k_end; ++kt) {
-    const int cur = (kt - k_beg) & 1;
-    if (kt + 1 < k_end) issue(kt + 1, cur ^ 1);
+    const int cur = STAGES == 2 ? ((kt - k_beg) & 1) : 0;
+    if constexpr (STAGES == 2) { if (kt + 1 < k_end) issue(kt + 1, cur ^ 1); }
     compute(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -486,14 +489,21 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
     if (g.mode != 2 && g.cgs >= 3 && span < (1L << 31)) {
       g.dKW = make_fastdiv(g.kW); g.dKH = make_fastdiv(g.kH);
       const long nblk = blocks * g.ksplit;
-      auto kern = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 2>;
-      static bool attr_done_f = false;
-      if (!attr_done_f) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done_f = true;
+      static MsclTune t_one("MSCL_ONE_STAGE");              // 0: two LDS stages also for one-step layers (A/B)
+      if (nk == 1 && g.ksplit == 1 && t_one.get(1) != 0) {
+        auto kern1 = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 1>;
+        hipLaunchKernelGGL(kern1, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), (size_t)(BM + BN) * BK * 2, st, g, src, wgt, out, bias,
+                           addend, ssum, ssq, relu, partial);
+      } else {
+        auto kern = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 2>;
+        static bool attr_done_f = false;
+        if (!attr_done_f) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_done_f = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), (size_t)2 * (BM + BN) * BK * 2, st, g, src, wgt, out, bias,
+                           addend, ssum, ssq, relu, partial);
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), (size_t)2 * (BM + BN) * BK * 2, st, g, src, wgt, out, bias,
-                         addend, ssum, ssq, relu, partial);
       MSCL_LAUNCH_CHECK();
       launched = true;
     }
