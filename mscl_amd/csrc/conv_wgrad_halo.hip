@@ -288,14 +288,14 @@ __global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float* _
   const int kt = tap / 9, t9 = tap - kt * 9;
   const int sub = ((co >> 6) * ncs + (ci >> 6)) * 3 + kt;
   const long rem = ((long)t9 * 64 + (co & 63)) * 64 + (ci & 63);
-  float s4[4] = {0.f, 0.f, 0.f, 0.f};        // four independent chains: the loop is a string of dependent-latency loads otherwise
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight independent chains: the loop is a string of dependent-latency loads otherwise
   int b = 0;
-  for (; b + 4 <= gk; b += 4) {
+  for (; b + 8 <= gk; b += 8) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s4[u] += slabs[((long)(b + u) * nsub + sub) * WH_SLAB + rem];
+    for (int u = 0; u < 8; ++u) s8[u] += slabs[((long)(b + u) * nsub + sub) * WH_SLAB + rem];
   }
-  for (; b < gk; ++b) s4[0] += slabs[((long)b * nsub + sub) * WH_SLAB + rem];
-  dw[e] += (s4[0] + s4[1]) + (s4[2] + s4[3]);               // one owner per element: a plain add, the same bits every run
+  for (; b < gk; ++b) s8[b & 7] += slabs[((long)b * nsub + sub) * WH_SLAB + rem];
+  dw[e] += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));   // one owner per element: a plain add, the same bits every run
 }
 
 static long g_wgrad_halo_launches = 0;
