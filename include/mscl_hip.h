@@ -64,11 +64,6 @@ int mscl_get_deterministic(void);
 /* The library's tuning switches (MSCL_* environment variables) are read once and cached; after this call every
  * switch re-reads its variable at its next use (tests and A/B sweeps that flip a switch inside one process). */
 int mscl_tuning_reload(void);
-/* Auxiliary stream for leaf reductions of the backward pass (NULL: off, the default): the slab sums of the window-resident weight
- * gradient then run on `stream`, behind an event on the calling stream, instead of on the calling stream's chain.  The caller
- * (a) joins `stream` before anything reads the weight gradients, (b) passes a workspace that stays private to the layer until
- * then.  Ignored in deterministic mode.  Process-wide. */
-int mscl_set_aux_stream(void* stream);
 /* BatchNorm batch statistics of a stored bf16 map (rows, C) in `groups` statistics groups, summed in a fixed order and stored
  * into slot 0 of ssum / ssq ([group][slot][2][C], ssq = ssum + C; the other slots must hold zeros and do so afterwards).
  * Two levels: per-block partials over contiguous row shares, then one add per channel in partial order; the number of partials

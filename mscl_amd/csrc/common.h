@@ -141,13 +141,6 @@ struct MsclTune {
   int get(int dflt) { return read() ? val : dflt; }
 };
 
-// Auxiliary stream (mscl_set_aux_stream): leaf reductions that nothing on the calling stream's chain reads -- the slab sums of the
-// window-resident weight gradient into the gradient arena -- are launched there, behind an event on the calling stream, so that the
-// chain (the next input gradient) does not wait for them.  The caller joins the auxiliary stream before it reads the gradients
-// (MSCLWithAug.sync_streams) and keeps their workspace alive and private until then.  Never in deterministic mode.
-extern hipStream_t g_mscl_aux_stream;
-hipEvent_t mscl_aux_event();                      // next event of a small ring (created once, timing disabled)
-
 #define MSCL_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 static inline int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -788,15 +788,6 @@ extern "C" int mscl_weight_transpose_batched(const void* table, int n, int total
 extern "C" int mscl_abi_version(void) { return 1; }
 
 int g_mscl_deterministic = 0;
-hipStream_t g_mscl_aux_stream = nullptr;
-extern "C" int mscl_set_aux_stream(void* stream) { g_mscl_aux_stream = (hipStream_t)stream; return 0; }
-hipEvent_t mscl_aux_event() {
-  static hipEvent_t ring[64];
-  static int made = 0, next = 0;
-  if (made < 64) { (void)hipEventCreateWithFlags(&ring[made], hipEventDisableTiming); return ring[made++]; }
-  next = (next + 1) & 63;
-  return ring[next];
-}
 int g_mscl_tune_gen = 0;
 extern "C" int mscl_tuning_reload(void) { ++g_mscl_tune_gen; return 0; }
 extern "C" int mscl_set_deterministic(int on) { g_mscl_deterministic = on ? 1 : 0; return 0; }

@@ -373,19 +373,9 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   else hipLaunchKernelGGL(wgrad_halo64_kernel<8>, dim3(blocks), dim3(512), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
   MSCL_LAUNCH_CHECK();
   const long total = (long)d->K * 27 * d->C;
-  // The slab sums are a leaf of the backward chain (nothing reads dW before the optimizer): with an auxiliary stream set they run
-  // there, beside the input gradient that follows on `st` (an HBM-bound 10-us pass next to an MFMA-bound kernel).  The caller keeps
-  // `ws` private to this call until it has joined the auxiliary stream (nn.Conv3dHip.wgrad: one persistent workspace per layer and
-  // shape, used once between two joins).
-  hipStream_t rs = st;
-  if (g_mscl_aux_stream != nullptr && g_mscl_aux_stream != st && !mscl_det()) {
-    hipEvent_t ev = mscl_aux_event();
-    if (hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(g_mscl_aux_stream, ev, 0) == hipSuccess) rs = g_mscl_aux_stream;
-  }
-  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rs, (const float*)ws, dw, gk, g.nsub,
+  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, gk, g.nsub,
                      g.ncs, d->C, total);
   MSCL_LAUNCH_CHECK();
-
   ++g_wgrad_halo_launches;
   return 1;
 }

@@ -113,12 +113,10 @@ def wgrad_ws_floats(d, with_bias):
     return lib.call_raw('mscl_conv3d_wgrad_ws', ctypes.byref(d), int(with_bias))
 
 
-def conv3d_wgrad(x, dy, d, dw, dbias=None, ws_floats=None, ws=None):
-    """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated).  ws: the caller's own workspace (>= the layer's
-    wgrad_ws_floats): what a caller passes that lets the slab sums run on the auxiliary stream (lib.set_aux_stream)."""
-    if ws is None:
-        n = wgrad_ws_floats(d, dbias is not None) if ws_floats is None else ws_floats
-        ws = torch.empty((n,), dtype=torch.float32, device=x.device) if n > 0 else None
+def conv3d_wgrad(x, dy, d, dw, dbias=None, ws_floats=None):
+    """dw (fp32 [K][taps][C], accumulated), dbias (fp32 [K], accumulated)."""
+    n = wgrad_ws_floats(d, dbias is not None) if ws_floats is None else ws_floats
+    ws = torch.empty((n,), dtype=torch.float32, device=x.device) if n > 0 else None
     e0 = prof_begin()
     call('mscl_conv3d_wgrad', ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws),
          ws.numel() if ws is not None else 0, stream_ptr())

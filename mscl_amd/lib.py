@@ -39,7 +39,6 @@ _SIGS = {
     'mscl_debug_thin_wgrad_launches': [],
     'mscl_get_deterministic': [],
     'mscl_tuning_reload': [],
-    'mscl_set_aux_stream': [P],
     'mscl_bn_stats': [P, P, P, c_int64, c_int, c_int, P, c_int64, P],
     'mscl_det_parts_floats': [c_int64, c_int, c_int, c_int],
     'mscl_conv3d_wgrad_ws': [POINTER(ConvDesc), c_int],
@@ -183,18 +182,6 @@ def tune(**switches):
         else:
             os.environ[k] = str(v)
     call('mscl_tuning_reload')
-
-
-_AUX = [None]
-
-
-def set_aux_stream(stream):
-    """torch.cuda.Stream (or None) on which the library runs the leaf reductions of the backward pass (mscl_set_aux_stream);
-    process-wide, re-sent only when it changes"""
-    key = None if stream is None else stream.cuda_stream
-    if key != _AUX[0]:
-        call('mscl_set_aux_stream', key)
-        _AUX[0] = key
 
 
 DET_GEN = 0

@@ -85,45 +85,13 @@ class Conv3dHip(nn.Module):
         rt = self._rt
         d = self.desc(x.shape)
         key = ('w', tuple(x.shape), lib.DET_GEN)
-        plan = self._plans.get(key)
-        if plan is None:          # (one ctypes query per (shape, mode) instead of per launch: the eager step is host-bound)
-            n = K.wgrad_ws_floats(d, rt['dbias'] is not None)
-            # layers of the window-resident weight gradient keep ONE persistent workspace per shape: their slab sums may then run on
-            # the auxiliary stream (AUX[0]) past the end of this call -- an allocation of this call's own would be handed to the
-            # next tensor of the backward chain while the sums still read it
-            keep = n > 0 and not lib.DET and lib.call_raw('mscl_wgrad_halo_ws', ctypes.byref(d)) > 0
-            plan = self._plans[key] = [n, torch.empty((n,), dtype=torch.float32, device=x.device) if keep else None, -1]
-        n, ws, used = plan
-        if ws is not None and AUX[0] is not None and used != AUX_EPOCH[0] and not lib.DET:
-            # (used == this epoch: a second application of this layer and shape before the streams were joined -- its sums stay on
-            #  the chain, on a workspace of its own.)  The library is told about the auxiliary stream for THIS call only: no other
-            # caller of the C ABI in this process inherits it.
-            plan[2] = AUX_EPOCH[0]
-            lib.set_aux_stream(AUX[0])
-            try:
-                K.conv3d_wgrad(x, dy, d, rt['dw'], rt['dbias'], ws=ws)
-            finally:
-                lib.set_aux_stream(None)
-        else:
-            K.conv3d_wgrad(x, dy, d, rt['dw'], rt['dbias'], ws_floats=n)
+        n = self._plans.get(key)
+        if n is None:             # (one ctypes query per (shape, mode) instead of per launch: the eager step is host-bound)
+            n = self._plans[key] = K.wgrad_ws_floats(d, rt['dbias'] is not None)
+        K.conv3d_wgrad(x, dy, d, rt['dw'], rt['dbias'], ws_floats=n)
         rt['slot_w'].touched = True
         if rt['slot_b'] is not None:
             rt['slot_b'].touched = True
-
-
-# The auxiliary stream of the backward pass (lib.set_aux_stream): set by the model that owns the step's streams (MSCLWithAug: the
-# RGB key stream, idle during backward), None = every reduction stays on its chain.  AUX_EPOCH counts the joins of that stream
-# (MSCLWithAug.sync_streams): a persistent weight-gradient workspace is used once per epoch.
-AUX = [None]
-AUX_EPOCH = [0]
-
-
-def set_aux(stream):
-    AUX[0] = stream
-
-
-def aux_joined():
-    AUX_EPOCH[0] += 1
 
 
 class TransposeState:
@@ -271,9 +239,6 @@ def _bucket_done(mod):
     if HOLD_BUCKETS[0]:
         return                  # nothing executes during capture; the replaying node fires the trigger itself
     buckets = getattr(mod, '_grad_buckets', ())
-    if buckets and AUX[0] is not None and not parallel.single():
-        torch.cuda.current_stream().wait_stream(AUX[0])       # the bucket's weight gradients may still be summed on the auxiliary stream
-        aux_joined()
     for red, i in buckets:
         red.bucket_done(i)
 

@@ -617,7 +617,6 @@ class MSCLWithAug(nn.Module):
         self.two_streams = os.environ.get('MSCL_STREAMS', '3') != '1'
         self.stream_probing = True     # side streams chosen by the overlap probe (streams.py); False: the first ones created
         self.defer_transpose = True
-        self.aux_reduce = os.environ.get('MSCL_AUX_REDUCE', '1') != '0'     # leaf reductions of the backward pass on the idle key stream (nn.set_aux)
         self._wt = None
         self.loss_fork = True          # RGB-queue InfoNCE pass beside the flow-queue passes
         # ... and (attribute, off) the post-enqueue flow-queue pass on a "virtual" snapshot beside the pre-enqueue one:
@@ -939,7 +938,6 @@ class MSCLWithAug(nn.Module):
         if self._side is not None:
             for st in self._side:
                 torch.cuda.current_stream().wait_stream(st)
-            nn_hip.aux_joined()                 # (the auxiliary stream of the backward pass is one of them)
 
     def _shuffle(self, x, slot):
         if parallel.single():
@@ -1019,9 +1017,6 @@ class MSCLWithAug(nn.Module):
         side_k = self._side_stream(1) if side is not main else main   # RGB key chain on its own stream (on the flow stream: -7 %)
         if side_k is not main:
             side_k.wait_stream(main)
-        # the key stream is idle from the loss on: the leaf reductions of the backward pass (slab sums of the window-resident weight
-        # gradients) run there, off the RGB query chain; sync_streams joins it before the gradients are read
-        nn_hip.set_aux(side_k if (side_k is not main and self.aux_reduce) else None)
         if self._wt.stale or torch.cuda.is_current_stream_capturing():      # (a captured step always carries the refresh)
             with torch.cuda.stream(s_fq):
                 self._wt.refresh()                                          # deferred by refresh_after_optimizer; joined before the loss
