@@ -141,8 +141,8 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
   // step out.  Measured (caps 512 / 512 / 512 for forward / reduce / apply against 2048 / 1024 / 2048, alternating in one call):
   // step 951.6 vs 926.5-928.8 clip-pairs/s, R3D-18 trunk alone 1750 vs 1701 clips/s, SlowOnly-50 trunk at 8 x 32 x 224^2 424.7 vs
   // 400.4 clips/s; 256 and 384 measured like 512 on the step, 768-1024 in between.  MSCL_BN_FWD_CAP / _RED_CAP / _APPLY_CAP override.
-  static MsclTune t_fcap("MSCL_BN_FWD_CAP");
-  const long fwd_cap = t_fcap.get(512);
+  constexpr long fwd_cap = 512;                // (round 4, re-swept inside the step with the two-block layer-1 kernels: 256 / 512 / 1024 for each
+                                               // of the three passes within +-0.5 % of one another; 512 stays)
   constexpr long gpt = 1;                      // granules per thread (swept 1 / 2 / 4 inside the step: no gain)
   long blocks = (total + 256 * gpt - 1) / (256 * gpt); if (blocks > fwd_cap) blocks = fwd_cap;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * groups * C * sizeof(float),
@@ -507,8 +507,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
   const int RP = 256 / (Cc / 8);
   const long rows_g = rows / groups;
   long blocks = (rows_g + RP * 8 - 1) / (RP * 8);
-  static MsclTune t_rcap("MSCL_BN_RED_CAP");
-  const long red_cap = t_rcap.get(512);        // see mscl_bn_act_fwd_groups
+  constexpr long red_cap = 512;                // see mscl_bn_act_fwd_groups
   const long cap = red_cap / (chunks * groups);                    // wider grids measured slower (more atomics)
   if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
   // deterministic mode: partial x of block x (in the caller's `det_parts`, or in the slots themselves: 16 blocks), folded into slot 0
@@ -533,8 +532,7 @@ extern "C" int mscl_bn_act_bwd_groups(const uint16_t* dout, const uint16_t* out,
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   }
   const long total = rows * (Ca / 8);
-  static MsclTune t_acap("MSCL_BN_APPLY_CAP");
-  const long app_cap = t_acap.get(512);        // see mscl_bn_act_fwd_groups
+  constexpr long app_cap = 512;                // see mscl_bn_act_fwd_groups
   constexpr long gpt = 1;                      // granules per thread (swept 1 / 2 / 4 inside the step: no gain)
   long b2 = (total + 256 * gpt - 1) / (256 * gpt); if (b2 > app_cap / achunks) b2 = app_cap / achunks; if (b2 < 1) b2 = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)b2, achunks), dim3(256), (size_t)10 * groups * Ca * sizeof(float), st, dout, out, y,

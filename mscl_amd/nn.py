@@ -223,7 +223,11 @@ MASK_FROM_Y_MIN = 1 << 24   # BN backward recomputes the ReLU mask from y on map
 
 
 def _wgrad(conv, x, dy):
-    """(weight gradients on a side stream, off the dgrad / BatchNorm-backward chain, were measured in rounds 1 and 2: -6 ... -13 %
+    """(Round 4 measured the narrowest form of all: only the 10-us slab sums of the window-resident weight gradients -- a leaf of
+    the chain, HBM-bound -- launched on the idle key stream behind an event, with persistent per-layer workspaces and the join
+    in sync_streams: 981-987 vs 1090-1095 clip-pairs/s in three alternating pairs.  Whatever forks off the RGB query chain during
+    backward costs more than it hides; the mechanism was removed again.)
+    (weight gradients on a side stream, off the dgrad / BatchNorm-backward chain, were measured in rounds 1 and 2: -6 ... -13 %
     on the step -- two MFMA-heavy kernels side by side do not pay -- and removed in round 3.  Round 3 re-measured the narrowest
     form: only the layer-1 / stem weight gradients of the RGB query trunk, issued AFTER their layer's input gradient on the idle
     key stream so that they would run beside the next BatchNorm-backward passes: 984-988 vs 1043-1048 clip-pairs/s; with layer 2 and
