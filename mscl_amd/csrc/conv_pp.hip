@@ -43,7 +43,7 @@ template <int N> struct IC { static constexpr int value = N; };
 // L sections, at the barrier behind them, in the M sections and at the barrier behind those (s_memtime; the stamps themselves cost
 // ~10 % of the wave cycles).  The values go to a buffer of their own and feed no output.
 #ifdef PP_STAMP
-__device__ unsigned long long g_pp_stamps[2048 * 2 * 4];
+__device__ unsigned long long g_pp_stamps[2048 * 2 * 8];
 extern "C" int mscl_debug_pp_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_stamps), (size_t)n * sizeof(unsigned long long));
 }
@@ -66,6 +66,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+#ifdef PP_STAMP
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,11 +125,9 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   };
   unsigned soff_n = 0, woff_n = 0; int tb_n = 0;
   const unsigned wstep = (unsigned)cs2;           // bytes from a (kt, kh, kw) weight tile to the (kt, kh, kw + 1) one
-  // ---- prologue, part 1: the first group's three weight tiles need no row state; they travel while the rows are set up ----
+  // ---- prologue, part 1: the first group's first weight tile needs no row state; it travels while the rows are set up ----
   group_soff(g_beg, soff_n, tb_n, woff_n);
   issue_b(0 * B_SLOT, woff_n);
-  issue_b(1 * B_SLOT, woff_n + wstep);
-  issue_b(2 * B_SLOT, woff_n + 2 * wstep);
   int row_voff[4], row_mask[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -185,11 +186,15 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   unsigned bq = 0;                                // ring slot (0..NB-1) of the current group's first weight tile
   unsigned a_cur = 0;                             // byte offset of the current group's position slot (0 / A_SLOT)
 
-  // ---- prologue, part 2: the first position tile; everything of group 0 has landed behind vmcnt(0) (the steady-state waits of
-  // the first group then find its later weight tiles already there) ----
+  // ---- prologue, part 2: the first position tile, then weight tiles 1 and 2 of the first group.  Only what phase 0 reads is waited
+  // for (the position tile and weight tile 0: 48 of the 80 KB); tiles 1 and 2 stay in flight exactly where the steady-state waits
+  // of Q0 / Q1 expect them (older than everything those phases issue).  Round 4: the stamps put this prologue at 5.5-7.4 k cycles
+  // of a block's 32-87 k. ----
   issue_a(0, 0, soff_n, tb_n);
   issue_a(1, 0, soff_n, tb_n);
-  PP_VMCNT(0);
+  issue_b(1 * B_SLOT, woff_n + wstep);
+  issue_b(2 * B_SLOT, woff_n + 2 * wstep);
+  PP_VMCNT(2 * UB);
   __builtin_amdgcn_s_barrier();
 
   u32x4_t fa[2][IM], fb[2][JN];
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   if (grp == 1) __builtin_amdgcn_s_barrier();
 #ifdef PP_STAMP
   unsigned long long tL = 0, tW1 = 0, tM = 0, tW2 = 0, ta, tb;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #define PP_PHASE(KW) ta = __builtin_amdgcn_s_memtime(); Lsec(IC<KW>{}); tb = __builtin_amdgcn_s_memtime(); tL += tb - ta; \
     __builtin_amdgcn_s_barrier(); ta = __builtin_amdgcn_s_memtime(); tW1 += ta - tb; Msec(); tb = __builtin_amdgcn_s_memtime(); tM += tb - ta; \
     __builtin_amdgcn_s_barrier(); ta = __builtin_amdgcn_s_memtime(); tW2 += ta - tb;
@@ -274,11 +279,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
 #undef PP_PHASE
   if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with the last barrier of waves 4-7
 #ifdef PP_STAMP
-  if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 2048) {
-    unsigned long long* o = g_pp_stamps + ((size_t)blockIdx.x * 2 + grp) * 4;
-    o[0] = tL; o[1] = tW1; o[2] = tM; o[3] = tW2;
-  }
-  (void)t_begin;
+  const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- epilogue (shared): rows back from padded-linear order; the halo rows and the padding columns are not stored ----
@@ -296,6 +297,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(
   }
   igemm_epilogue_rows<BM, BN, IM, JN, true>(g, acc, smem, tid, fr, fq, 0, n0, wm0, wn0, split, 0, orow, out, bias, addend, stat_sum,
                                             stat_sq, relu, partial);
+#ifdef PP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 2048) {
+    unsigned long long* o = g_pp_stamps + ((size_t)blockIdx.x * 2 + grp) * 8;
+    o[0] = tL; o[1] = tW1; o[2] = tM; o[3] = tW2; o[4] = t_loop - t_begin; o[5] = t_end - t_loop_end; o[6] = t_end - t_begin; o[7] = 0;
+  }
+#endif
 }
 
 // Round 4, measured and dropped: the same kernel with TWO blocks per CU (128-row blocks, three weight slots, 80 KB of LDS, 104

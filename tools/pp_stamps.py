@@ -36,15 +36,24 @@ def main():
         if blocks <= 128:
             ks = min(256 // blocks, ng // 2, 16)
         nblk = min(2048, blocks * ks)
-        buf = (ctypes.c_ulonglong * (nblk * 8))()
-        rc = h.mscl_debug_pp_stamps(buf, nblk * 8)
+        buf = (ctypes.c_ulonglong * (nblk * 16))()
+        rc = h.mscl_debug_pp_stamps(buf, nblk * 16)
         assert rc == 0, rc
-        t = torch.tensor(list(buf), dtype=torch.float64).view(nblk, 2, 4)
+        t = torch.tensor(list(buf), dtype=torch.float64).view(nblk, 2, 8)
         phases = 3.0 * ng / ks
         m = t.mean(0) / phases
         print(f'{name}: {nblk} blocks, {phases:.0f} phases per block; cycles per phase  L / wait / M / wait:  '
               f'waves 0-3 {m[0, 0]:.0f} / {m[0, 1]:.0f} / {m[0, 2]:.0f} / {m[0, 3]:.0f}   '
               f'waves 4-7 {m[1, 0]:.0f} / {m[1, 1]:.0f} / {m[1, 2]:.0f} / {m[1, 3]:.0f}   (M alone = 512 cycles of MFMA issue)', flush=True)
+        wm = t.mean(0)
+        print(f'    whole block, cycles (waves 0-3): prologue {wm[0, 4]:.0f}, loop {wm[0, 6] - wm[0, 4] - wm[0, 5]:.0f}, epilogue {wm[0, 5]:.0f}, '
+              f'total {wm[0, 6]:.0f};  block totals min / max over blocks {t[:, 0, 6].min():.0f} / {t[:, 0, 6].max():.0f}', flush=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            K.conv3d_fwd(x, w, d)
+        e1.record(); torch.cuda.synchronize()
+        print(f'    launch (stamp build, incl. split-K finalize where used): {e0.elapsed_time(e1) * 100:.1f} us', flush=True)
 
 
 if __name__ == '__main__':
