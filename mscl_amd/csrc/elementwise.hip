@@ -539,8 +539,9 @@ extern "C" int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner
 extern "C" int mscl_pool_parts(int outer, int inner, int C) {
   // row parts that bring a launch of few groups to about one block per CU, at least 64 rows each; 1 in deterministic mode (the
   // parts are combined by float atomics)
+  static MsclTune split{"MSCL_POOL_SPLIT"};
   const int chunks = C > 512 ? C / 512 : 1;
-  if (mscl_det() || (long)outer * chunks >= 192 || inner < 128) return 1;
+  if (mscl_det() || !split.get(1) || (long)outer * chunks >= 192 || inner < 128) return 1;
   int parts = 256 / (outer * chunks);
   if (parts > inner / 64) parts = inner / 64;
   return parts < 1 ? 1 : parts;
