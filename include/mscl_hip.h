@@ -56,6 +56,7 @@ int64_t mscl_debug_pp_launches(void);
 /* the same for the window-resident 1x3x3 kernel of the 16- / 32-channel maps (conv_thin.hip) */
 /* the same for the window-resident layer-1 kernels: forward / input gradient (conv_halo.hip), weight gradient (conv_wgrad_halo.hip) */
 int64_t mscl_debug_halo_launches(void);
+int64_t mscl_debug_stem_launches(void);   /* conv_stem.hip: the window-resident RGB-stem forward */
 int64_t mscl_debug_wgrad_halo_launches(void);
 int64_t mscl_debug_thin_launches(void);
 int64_t mscl_debug_thin_wgrad_launches(void);

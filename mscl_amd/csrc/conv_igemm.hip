@@ -621,6 +621,7 @@ static bool halo_enabled(const mscl_conv_desc* d) {
 
 int mscl_conv_thin(int planes, int H, int W, int C, int K, int flip, const bf16_t* x, const bf16_t* w, bf16_t* y, const float* bias,
                    const bf16_t* addend, int relu, float* ssum, float* ssq, int stat_groups, hipStream_t st);      // conv_thin.hip
+int mscl_conv_stem(const mscl_conv_desc* d, const bf16_t* x, const bf16_t* w, bf16_t* y, float* ssum, float* ssq, hipStream_t st);   // conv_stem.hip
 static bool thin_shape(const mscl_conv_desc* d) {
   return d->kT == 1 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 1 && d->pW == 1 &&
          (d->C == 16 || d->C == 32) && (d->K == 16 || d->K == 32);
@@ -651,6 +652,10 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
   if (thin_shape(d)) {             // 1x3x3 s1 between 16- / 32-channel maps: window-resident direct kernel (conv_thin.hip)
     const int h = mscl_conv_thin(d->N * d->T, d->H, d->W, d->C, d->K, 0, x, w, y, bias, addend, relu, ssum, ssq, stat_groups,
                                  (hipStream_t)stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
+  if (stat_groups == 1 && bias == nullptr && addend == nullptr && !relu) {  // W-paired RGB stem: window-resident kernel (conv_stem.hip)
+    const int h = mscl_conv_stem(d, x, w, y, ssum, ssq, (hipStream_t)stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
   if (stat_groups == 1 && bias == nullptr && !relu && halo_enabled(d)) {   // 3x3x3 s1 64->64: halo-resident kernel (conv_halo.hip)

@@ -408,6 +408,60 @@ def test_stem_w_paired_equals_plain_stem(W, dev):
     assert float(dw8[..., 6:].abs().max()) == 0.0          # (slot j = 3, p = 1 is kw = 7: real pixels, no kernel column -- dropped by the fold)
 
 
+# conv_stem.hip (window-resident forward of the W-paired RGB stems): the real planes of both configurations (default dispatch), an
+# odd width, a temporal stride, a plane smaller than one tile (forced), a tile tail behind the plane
+STEM_CASES = [
+    # name, N, T, H, W, kT, sT, pT, forced
+    ('r18_112', 2, 4, 112, 112, 3, 1, 1, False),
+    ('r50_224', 1, 3, 224, 224, 1, 1, 0, False),
+    ('edge_90', 1, 3, 90, 90, 3, 1, 1, False),
+    ('odd_w_70x57', 2, 3, 70, 57, 3, 1, 1, False),
+    ('stride_t2', 1, 5, 64, 64, 3, 2, 1, False),
+    ('small_20x24', 2, 4, 20, 24, 3, 1, 1, True),
+    ('small_kt1_22x23', 2, 2, 22, 23, 1, 1, 0, True),
+]
+
+
+@pytest.mark.parametrize('case', STEM_CASES, ids=[c[0] for c in STEM_CASES])
+def test_conv_stem_window_resident(case, dev):
+    """the stems of r3d.py:176-184 (3,7,7) and ResNet3dSlowOnly conv1 (1,7,7) through mscl_conv3d_fwd on W-paired input: the
+    window-resident kernel takes the launch (counter), equals CPU fp32 F.conv3d on the 3-channel clip, and repeats bit for bit"""
+    from mscl_amd import kernels as K_
+    from mscl_amd import lib
+    name, N, T, H, W, kT, sT, pT, forced = case
+    Co = 64
+    x3 = bf(rnd((N, T, H, W, 3), 1)); w = bf(rnd((Co, kT, 7, 7, 3), 2, scale=(2.0 / (3 * 49 * kT)) ** 0.5))
+    x8 = torch.zeros((N, T, H, W, 8), dtype=torch.bfloat16); x8[..., :3] = x3
+    yr = _conv_ref(x3.float(), w.float(), (sT, 2, 2), (pT, 3, 3))
+    xp = K_.pair_w(x8.to(dev))
+    w8 = torch.zeros((Co, kT, 7, 4, 8), dtype=torch.bfloat16, device=dev)
+    K_.pair_w_weight(w.to(dev), w8)
+    d = K_.conv_desc(tuple(xp.shape), Co, (kT, 7, 4), (sT, 2, 1), (pT, 3, 1))
+    if forced:
+        lib.tune(MSCL_STEM=1)
+    try:
+        n0 = lib.call_raw('mscl_debug_stem_launches')
+        st = torch.zeros((K_.STAT_SLOTS, 2, Co), device=dev)
+        y = K_.conv3d_fwd(xp, w8, d, stats=(st[0, 0], st[0, 1]))
+        assert lib.call_raw('mscl_debug_stem_launches') == n0 + 1, 'the window-resident stem kernel did not take the launch'
+        assert tuple(y.shape) == tuple(yr.shape)
+        close(y, yr, BF16_TOL, f'stem fwd {name}')
+        close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'stem bn sum')
+        close(st[:, 1].sum(0), (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'stem bn sumsq')
+        for _ in range(3):                                   # DMA ring / window reuse: repeated launches are bit-identical
+            assert torch.equal(K_.conv3d_fwd(xp, w8, d), y)
+        # epilogue variants the kernel does not cover stay with the implicit-GEMM kernel
+        b = rnd((Co,), 3)
+        y2 = K_.conv3d_fwd(xp, w8, d, bias=b.to(dev), relu=True)
+        assert lib.call_raw('mscl_debug_stem_launches') == n0 + 4
+        close(y2, F.relu(yr + b), BF16_TOL, 'stem fwd with bias + relu (implicit GEMM)')
+        lib.tune(MSCL_STEM=0)
+        close(K_.conv3d_fwd(xp, w8, d), y, 2.0 ** -7, 'window-resident stem vs implicit GEMM')
+        assert lib.call_raw('mscl_debug_stem_launches') == n0 + 4
+    finally:
+        lib.tune(MSCL_STEM=None)
+
+
 @pytest.mark.parametrize('C,relu,resmode', [(64, True, 'none'), (64, True, 'identity'), (128, True, 'bn'),
                                             (16, False, 'none'), (32, True, 'identity'), (512, True, 'bn')])
 def test_bn_act_fwd_bwd(C, relu, resmode, dev):
