@@ -514,20 +514,27 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
       for (int i = 0; i < IM; ++i)
         add4[j][i] = *reinterpret_cast<const uint2*>(addend + (orow[i] < 0 ? 0 : orow[i]) + j * 16 + fq * 4);
   }
+  // 16-byte stores: two channel tiles paired through v_permlane16_swap (igemm.h: an even lane row ends up with 8 consecutive
+  // channels of tile j, an odd one with 8 of tile j + 1; the partner row holds the same position)
+  auto quad = [&](int i, int j) -> uint2 {
+    float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+    if (addend != nullptr) {
+      const uint2 av = add4[j][i];
+      v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
+      v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
+    }
+    uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
+    return pv;
+  };
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
-    if (orow[i] < 0) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = j * 16 + fq * 4;
-      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      if (addend != nullptr) {
-        const uint2 av = add4[j][i];
-        v[0] += __uint_as_float(av.x << 16); v[1] += __uint_as_float(av.x & 0xFFFF0000u);
-        v[2] += __uint_as_float(av.y << 16); v[3] += __uint_as_float(av.y & 0xFFFF0000u);
-      }
-      uint2 pv; pv.x = pack2bf(v[0], v[1]); pv.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(out + orow[i] + n) = pv;
+    for (int j = 0; j < 4; j += 2) {
+      const uint2 q0 = quad(i, j), q1 = quad(i, j + 1);
+      const auto sx = __builtin_amdgcn_permlane16_swap(q0.x, q1.x, false, false);      // every lane takes part (no divergent branch around)
+      const auto sy = __builtin_amdgcn_permlane16_swap(q0.y, q1.y, false, false);
+      const int n = (j + (fq & 1)) * 16 + (fq & 2) * 4;
+      if (orow[i] >= 0) *reinterpret_cast<uint4*>(out + orow[i] + n) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     }
   }
 }

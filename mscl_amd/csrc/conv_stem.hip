@@ -13,7 +13,7 @@
 // written by the buffer unit's range check while the window is staged.
 //  * weights: two k steps (8 KB) per ring stage, gathered by LDS-DMA straight into MFMA fragment order (a lane's chunk sits at
 //    [k step][channel tile][lane]: reads are linear, no swizzle); an odd k-step count (21) is padded with a zero step;
-//  * half-step operand pipeline, one barrier per stage, two blocks per CU, epilogue (BatchNorm sums, bf16, 8-byte stores) as in
+//  * half-step operand pipeline, one barrier per stage, two blocks per CU, epilogue (BatchNorm sums, bf16, paired 16-byte stores) as in
 //    conv_halo.hip, whose structure this kernel follows.
 #include "common.h"
 
@@ -194,13 +194,15 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
       atomicAdd(tid < HC ? &stat_sum[so + tid] : &stat_sq[so + tid - HC], tsum);
     }
   }
+  // 16-byte stores: two channel tiles paired through v_permlane16_swap (igemm.h)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    if (orow[i] < 0) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint2 pv; pv.x = pack2bf(acc[j][i][0], acc[j][i][1]); pv.y = pack2bf(acc[j][i][2], acc[j][i][3]);
-      *reinterpret_cast<uint2*>(out + orow[i] + j * 16 + fq * 4) = pv;
+    for (int j = 0; j < 4; j += 2) {
+      const auto sx = __builtin_amdgcn_permlane16_swap(pack2bf(acc[j][i][0], acc[j][i][1]), pack2bf(acc[j + 1][i][0], acc[j + 1][i][1]), false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(pack2bf(acc[j][i][2], acc[j][i][3]), pack2bf(acc[j + 1][i][2], acc[j + 1][i][3]), false, false);
+      const int nn = (j + (fq & 1)) * 16 + (fq & 2) * 4;
+      if (orow[i] >= 0) *reinterpret_cast<uint4*>(out + orow[i] + nn) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     }
   }
 }
