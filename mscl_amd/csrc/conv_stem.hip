@@ -171,19 +171,21 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
   if (stat_sum != nullptr) {
     float* red = reinterpret_cast<float*>(smem);      // [NW][2][64]
     const int wv = tid >> 6;
+    // value 8 j + 4 sq + r = (channel tile j, sum / sum of squares, channel r of this lane row's quad): after the reduce-scatter
+    // quad q of a lane row holds the 8 totals of channel tile q
+    float sv[32];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[j][i][r]; s4[r] += v; q4[r] += v * v; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s4[r] = row16_sum(s4[r]); q4[r] = row16_sum(q4[r]); }
-      if (fr == 0) {
-        *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * HC + j * 16 + fq * 4]) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-        *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * HC + j * 16 + fq * 4]) = make_float4(q4[0], q4[1], q4[2], q4[3]);
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = acc[j][0][r], v1 = acc[j][1][r];
+        sv[j * 8 + r] = v0 + v1; sv[j * 8 + 4 + r] = v0 * v0 + v1 * v1;
       }
+    row16_reduce_scatter<32>(sv);
+    if ((fr & 3) == 0) {
+      const int jq = fr >> 2;
+      *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * HC + jq * 16 + fq * 4]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+      *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * HC + jq * 16 + fq * 4]) = make_float4(sv[4], sv[5], sv[6], sv[7]);
     }
     __syncthreads();
     if (tid < 2 * HC) {

@@ -79,6 +79,11 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IGemmGeom& g, f32x4_t 
     const int wrow = (wm0 / (IM * 16)) * NWN + wn0 / WCH;
     for (int pass = 0; pass < npass; ++pass) {
       __syncthreads();                                // the tiles (or the previous pass's rows) are dead
+      // value 8 j + 4 sq + r = (channel tile j, sum / sum of squares, channel r of this lane row's quad); the reduce-scatter
+      // (common.h) leaves quad q of a lane row with the totals of values [q * 2 JN, (q + 1) * 2 JN): half the DPP moves of one
+      // row sum per value, and the LDS stores spread over four lanes of a row
+      static_assert(JN == 1 || JN % 2 == 0, "a quad's share must be whole (j, sq) groups");
+      float sv[JN * 8];
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -89,12 +94,20 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IGemmGeom& g, f32x4_t 
           for (int r = 0; r < 4; ++r) { const float v = mine ? acc[j][i][r] : 0.f; s[r] += v; q[r] += v * v; }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]);
-        }
-        if (fr == 0) {
-          *reinterpret_cast<float4*>(&red[(wrow * 2 + 0) * WCH + j * 16 + fq * 4]) = make_float4(s[0], s[1], s[2], s[3]);
-          *reinterpret_cast<float4*>(&red[(wrow * 2 + 1) * WCH + j * 16 + fq * 4]) = make_float4(q[0], q[1], q[2], q[3]);
+        for (int r = 0; r < 4; ++r) { sv[j * 8 + r] = s[r]; sv[j * 8 + 4 + r] = q[r]; }
+      }
+      row16_reduce_scatter<JN * 8>(sv);
+      if ((fr & 3) == 0) {
+        const int v0 = (fr >> 2) * (2 * JN);           // first value of this quad
+#pragma unroll
+        for (int k = 0; k < 2 * JN; k += 4) {          // groups of 4 = the r of one (j, sq); JN = 1: two values (half a group) per quad
+          if constexpr (JN >= 2) {
+            const int v = v0 + k, j = v >> 3, sq = (v >> 2) & 1;
+            *reinterpret_cast<float4*>(&red[(wrow * 2 + sq) * WCH + j * 16 + fq * 4]) = make_float4(sv[k], sv[k + 1], sv[k + 2], sv[k + 3]);
+          } else {
+            const int sq = v0 >> 2, r0 = v0 & 3;
+            *reinterpret_cast<float2*>(&red[(wrow * 2 + sq) * WCH + fq * 4 + r0]) = make_float2(sv[0], sv[1]);
+          }
         }
       }
       __syncthreads();
