@@ -88,11 +88,14 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (stem_lds_ptr_t)(Ws + (u % RING) * 8192 + wave * 1024), 16, vo, so, 0, 0);
   };
 
-  // ---- prologue: the whole window, the first RING weight stages ----
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) issue_plane(kt);
+  // ---- prologue: plane 0 and the first RING weight stages, then the other planes: the loop starts when plane 0 and stage 0 have
+  // landed; the later planes are first read in stage 3 (k step 7), whose wait (at the end of stage 2) is for a weight stage issued
+  // AFTER them and so covers them, while the waits of stages 0 and 1 leave their pieces in flight ----
+  issue_plane(0);
 #pragma unroll
   for (int u = 0; u < RING; ++u) issue_weights(u);
+#pragma unroll
+  for (int kt = 1; kt < KT; ++kt) issue_plane(kt);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int wpl16 = __builtin_amdgcn_readfirstlane(g.WPL * 16);
@@ -127,8 +130,12 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], acc[j][i], 0, 0, 0);
   };
 #define ST_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
-  // window + stage 0 landed; the other RING - 1 stages stay in flight
-  if constexpr (RING == 4) ST_WAIT(3); else if constexpr (RING == 3) ST_WAIT(2); else ST_WAIT(1);
+  // plane 0 + stage 0 landed; the other planes and RING - 1 stages stay in flight
+  constexpr int LATE = (KT - 1) * NPS;                    // pieces of the later planes
+  static_assert(RING - 1 + LATE <= 8 && (KT == 1 || RING <= 3), "prologue wait");
+#define ST_WAIT_N(n) do { if ((n) >= 8) ST_WAIT(8); else if ((n) == 7) ST_WAIT(7); else if ((n) == 6) ST_WAIT(6); else if ((n) == 5) ST_WAIT(5); \
+    else if ((n) == 4) ST_WAIT(4); else if ((n) == 3) ST_WAIT(3); else if ((n) == 2) ST_WAIT(2); else if ((n) == 1) ST_WAIT(1); else ST_WAIT(0); } while (0)
+  ST_WAIT_N(RING - 1 + LATE);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   read_half(0, 0, 0);
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
     if (u + 1 < NU) {
       // stage u + 1 landed (the RING - 2 younger ones, fewer at the end, may stay in flight); this wave's reads of stage u retired;
       // the barrier publishes the one and frees the other
-      const int younger = (RING - 2) < (NU - 2 - u) ? (RING - 2) : (NU - 2 - u);
-      if (younger >= 2) ST_WAIT(2); else if (younger == 1) ST_WAIT(1); else ST_WAIT(0);
+      const int younger = ((RING - 2) < (NU - 2 - u) ? (RING - 2) : (NU - 2 - u)) + (u <= RING - 2 && u <= 1 ? LATE : 0);
+      ST_WAIT_N(younger);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (u + RING < NU) issue_weights(u + RING);
@@ -153,6 +160,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
     mma(1);
     __builtin_amdgcn_sched_barrier(0);
   }
+#undef ST_WAIT_N
 #undef ST_WAIT
   __syncthreads();                  // the epilogue reuses the window memory
 
