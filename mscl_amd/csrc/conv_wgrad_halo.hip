@@ -242,60 +242,64 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
 #undef WH_READ_B
 #undef WH_TR_READ
 
+  // Registers leave in REGISTER order: a lane's accumulator (tap t9, co tile i) is one float4 (co = 16 i + 4 (lane >> 4) + r, ci =
+  // 16 wq + (lane & 15)), and both the hand-over between the SIMD partners and the slab are laid out [wq][t9 * 4 + i][lane] float4 --
+  // 36 ds_write_b128 / ds_read_b128 and 36 global_store_dwordx4 per lane, every wave instruction 1 KB contiguous (the [tap][co][ci]
+  // order of rounds 3-4 took 144 dword instructions for each, the stores in 64-byte segments).  The reduce kernel undoes the order.
   if constexpr (NW == 8) {
     // ---- the k-step halves of a SIMD pair: waves 4-7 hand their 144 partial sums per lane over through LDS (4 x 36 KB, the
     // stages are dead), waves 0-3 add them in a fixed order ----
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);           // [ci tile][register][lane]
+    float4* red4 = reinterpret_cast<float4*>(smem);
     if (grp == 1) {
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) red[((wq * 144 + (t9 * 4 + i) * 4 + r) << 6) + lane] = acc[t9][i][r];
+          red4[((wq * 36 + t9 * 4 + i) << 6) + lane] = make_float4(acc[t9][i][0], acc[t9][i][1], acc[t9][i][2], acc[t9][i][3]);
     }
     __syncthreads();
     if (grp == 1) return;
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t9][i][r] += red[((wq * 144 + (t9 * 4 + i) * 4 + r) << 6) + lane];
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = red4[((wq * 36 + t9 * 4 + i) << 6) + lane];
+        acc[t9][i][0] += v.x; acc[t9][i][1] += v.y; acc[t9][i][2] += v.z; acc[t9][i][3] += v.w;
+      }
   }
-  // ---- slab store: [slot * nsub + sub][tap][co][ci], D row = co (16*i + (lane>>4)*4 + r), col = ci (16*wq + (lane & 15)) ----
-  float* slab = slabs + (long)lin * WH_SLAB;
+  float4* slab4 = reinterpret_cast<float4*>(slabs + (long)lin * WH_SLAB);
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = i * 16 + (lane >> 4) * 4 + r;
-        const int ci = wq * 16 + (lane & 15);
-        slab[(t9 * 64 + co) * 64 + ci] = acc[t9][i][r];
-      }
+      slab4[((wq * 36 + t9 * 4 + i) << 6) + lane] = make_float4(acc[t9][i][0], acc[t9][i][1], acc[t9][i][2], acc[t9][i][3]);
 }
 
-// dw[co][kt*9 + t9][ci] += sum over the gk slabs of (kt, channel slice), in slot order.  One thread per element of dw.
-__global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int gk, int nsub,
-                                                                  int ncs, int C, long total) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;     // e = (co * 27 + kt * 9 + t9) * C + ci
-  if (e >= total) return;
-  const int ci = (int)(e % C); const long r = e / C;
-  const int tap = (int)(r % 27), co = (int)(r / 27);
-  const int kt = tap / 9, t9 = tap - kt * 9;
-  const int sub = ((co >> 6) * ncs + (ci >> 6)) * 3 + kt;
-  const long rem = ((long)t9 * 64 + (co & 63)) * 64 + (ci & 63);
-  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight independent chains: the loop is a string of dependent-latency loads otherwise
+// dw[co][kt*9 + t9][ci] += sum over the gk slabs of (kt, channel slice), in a fixed order.  One thread per float4 of a slab (the four
+// co of one accumulator): 16-byte loads that a wave reads 1 KB at a time, four owned elements of dw updated by plain adds.
+__global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float4* __restrict__ slabs4, float* __restrict__ dw, int gk, int nsub,
+                                                                  int ncs, int C, long total4) {
+  constexpr int S4 = WH_SLAB / 4;                          // float4 per slab
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const int sub = (int)(t / S4), q = (int)(t - (long)sub * S4);      // q = (wq * 36 + t9 * 4 + i) * 64 + lane
+  const float4* p = slabs4 + (long)sub * S4 + q;
+  const long bstride = (long)nsub * S4;
+  float4 s4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // four independent load chains
   int b = 0;
-  for (; b + 8 <= gk; b += 8) {
+  for (; b + 4 <= gk; b += 4) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s8[u] += slabs[((long)(b + u) * nsub + sub) * WH_SLAB + rem];
+    for (int u = 0; u < 4; ++u) { const float4 v = p[(long)(b + u) * bstride]; s4[u].x += v.x; s4[u].y += v.y; s4[u].z += v.z; s4[u].w += v.w; }
   }
-  for (; b < gk; ++b) s8[b & 7] += slabs[((long)b * nsub + sub) * WH_SLAB + rem];
-  dw[e] += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));   // one owner per element: a plain add, the same bits every run
+  for (; b < gk; ++b) { const float4 v = p[(long)b * bstride]; s4[0].x += v.x; s4[0].y += v.y; s4[0].z += v.z; s4[0].w += v.w; }   // (<= 3 slabs)
+  const float r4[4] = {(s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y),
+                       (s4[0].z + s4[1].z) + (s4[2].z + s4[3].z), (s4[0].w + s4[1].w) + (s4[2].w + s4[3].w)};
+  const int lane = q & 63, u36 = q >> 6, wq = u36 / 36, v36 = u36 - wq * 36, t9 = v36 >> 2, i = v36 & 3;
+  const int kt = sub % 3, cs = sub / 3, cis = cs % ncs, cos = cs / ncs;
+  const int co0 = cos * 64 + i * 16 + (lane >> 4) * 4, ci = cis * 64 + wq * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dw[((long)(co0 + r) * 27 + kt * 9 + t9) * C + ci] += r4[r];     // one owner per element: plain adds, the same bits every run
 }
 
 static long g_wgrad_halo_launches = 0;
@@ -372,9 +376,9 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   if (t_nw.get(8) == 4 && g.nsub == 3) hipLaunchKernelGGL(wgrad_halo64_kernel<4>, dim3(blocks), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
   else hipLaunchKernelGGL(wgrad_halo64_kernel<8>, dim3(blocks), dim3(512), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
   MSCL_LAUNCH_CHECK();
-  const long total = (long)d->K * 27 * d->C;
-  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, gk, g.nsub,
-                     g.ncs, d->C, total);
+  const long total4 = (long)g.nsub * (WH_SLAB / 4);
+  hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, (const float4*)ws, dw, gk, g.nsub,
+                     g.ncs, d->C, total4);
   MSCL_LAUNCH_CHECK();
   ++g_wgrad_halo_launches;
   return 1;
