@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, (BM <= 128 ? 2 : 1)) void conv_halo64_kern
 //  * one barrier per tap as before (publishes the next tap's weight tile, frees this tap's ring stage), RING stages of 8 KB.
 // NW = 8: 32 positions x 64 channels per wave, 12 fragment reads per 16 MFMAs -- with two blocks on the CU the LDS then moves 110 KB per
 // tap and block against 512 MFMA-clocks: 84 % as busy as the matrix pipes.  NW = 4: 64 x 64 per wave, 16 reads per 32 MFMAs, 75 KB.
-template <int NW, int RING>
+template <int NW, int RING, int TPS = 1>
 __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                               const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
   constexpr int NPS = NHK / RPP;                           // 6 / 12 DMA pieces per thread per plane
   constexpr int WPOS = BM / NW, IM = WPOS / 16;            // 32 / 64 positions per wave, 2 / 4 position tiles
   constexpr int WP = 8 / NW;                               // DMA instructions per weight tile per wave
-  static_assert(RING >= 2 && RING <= 4 && (NW == 8 || NW == 4), "configuration");
+  static_assert(RING >= 2 && RING <= 4 && (NW == 8 || NW == 4) && (TPS == 1 || TPS == 2) && RING * TPS <= 4, "configuration");
   unsigned char* const Hs = smem;                          // [NHK][128 B] the one window slot, row j <-> q0 - Wp - 1 + j
-  unsigned char* const Ws = smem + PLANE;                  // [RING][64][128 B] weight ring
+  unsigned char* const Ws = smem + PLANE;                  // [RING][TPS taps][64][128 B] weight ring (a stage = TPS taps)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -381,17 +381,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
   const unsigned w_voff1 = w_voff0 + (unsigned)(32 * 27 * HC * 2);
   auto issue_weights = [&](int tap) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
-    unsigned char* dst = Ws + (tap % RING) * (64 * 128) + wave * 1024;
+    unsigned char* dst = Ws + (((tap / TPS) % RING) * TPS + tap % TPS) * (64 * 128) + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
     if constexpr (NW == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst + 4096), 16, w_voff1, so, 0, 0);
   };
   auto tap_plane = [&](int kt) { return mode ? 2 - kt : kt; };
   auto tap_shift = [&](int kh, int kw) { return mode ? (2 - kh) * g.Wp + (2 - kw) : kh * g.Wp + kw; };
 
-  // ---- prologue: first plane, the first RING weight tiles ----
+  // ---- prologue: first plane, the first RING weight stages ----
   issue_plane(tap_plane(0));
 #pragma unroll
-  for (int w0 = 0; w0 < RING; ++w0) issue_weights(w0);
+  for (int w0 = 0; w0 < RING * TPS; ++w0) issue_weights(w0);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int arow0 = wave * WPOS + fr;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
   bf16x8_t fa[2][IM], fb[2][4];                            // [set][fragment]: set s holds the operands of one half tap
   auto read_half = [&](int tap, int ks, int set) {
     const int kh = (tap % 9) / 3, kw = tap % 3;
-    const unsigned char* wb = Ws + (tap % RING) * (64 * 128) + b_addr[ks];
+    const unsigned char* wb = Ws + (((tap / TPS) % RING) * TPS + tap % TPS) * (64 * 128) + b_addr[ks];
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const bf16x8_t*>(wb + j * 2048);
     const int row = arow0 + tap_shift(kh, kw);
@@ -421,49 +421,114 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], acc[j][i], 0, 0, 0);
   };
 #define HB_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
-  // plane + tap-0 weights landed; the other RING - 1 weight tiles (WP instructions each) stay in flight
-  if constexpr (WP * (RING - 1) == 6) HB_WAIT(6); else if constexpr (WP * (RING - 1) == 4) HB_WAIT(4);
-  else if constexpr (WP * (RING - 1) == 3) HB_WAIT(3); else if constexpr (WP * (RING - 1) == 2) HB_WAIT(2); else HB_WAIT(1);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  read_half(0, 0, 0);
+#define HB_WAIT_N(n) do { if ((n) >= 8) HB_WAIT(8); else if ((n) == 7) HB_WAIT(7); else if ((n) == 6) HB_WAIT(6); else if ((n) == 5) HB_WAIT(5); \
+    else if ((n) == 4) HB_WAIT(4); else if ((n) == 3) HB_WAIT(3); else if ((n) == 2) HB_WAIT(2); else if ((n) == 1) HB_WAIT(1); else HB_WAIT(0); } while (0)
+  if constexpr (TPS == 1) {
+    // plane + tap-0 weights landed; the other RING - 1 weight tiles (WP instructions each) stay in flight
+    if constexpr (WP * (RING - 1) == 6) HB_WAIT(6); else if constexpr (WP * (RING - 1) == 4) HB_WAIT(4);
+    else if constexpr (WP * (RING - 1) == 3) HB_WAIT(3); else if constexpr (WP * (RING - 1) == 2) HB_WAIT(2); else HB_WAIT(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_half(0, 0, 0);
 
-#pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    read_half(tap, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (tap + 1 < 27) {
-      if ((tap + 1) % 9 == 0) {
-        // plane switch: every wave holds the last fragments of the old plane in registers
-        HB_WAIT(0);
+  #pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      read_half(tap, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 27) {
+        if ((tap + 1) % 9 == 0) {
+          // plane switch: every wave holds the last fragments of the old plane in registers
+          HB_WAIT(0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          issue_plane(tap_plane((tap + 1) / 9));
+          if (tap + RING < 27) issue_weights(tap + RING);    // (its ring stage was last read for this tap: free behind the barrier too)
+          __builtin_amdgcn_sched_barrier(0);
+          mma(1);                                            // the old tap's second k step runs under the DMA
+          __builtin_amdgcn_sched_barrier(0);
+          HB_WAIT(0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          read_half(tap + 1, 0, 0);
+          continue;
+        }
+        // wait for the weight tile of tap + 1 (everything issued after it may stay in flight: RING - 2 tiles, fewer at the end),
+        // retire this wave's reads of tap's stage; the barrier publishes the one and frees the other
+        const int younger = WP * ((RING - 2) < (25 - tap) ? (RING - 2) : (25 - tap > 0 ? 25 - tap : 0));
+        if (younger >= 4) HB_WAIT(4); else if (younger == 2) HB_WAIT(2); else if (younger == 1) HB_WAIT(1); else HB_WAIT(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue_plane(tap_plane((tap + 1) / 9));
-        if (tap + RING < 27) issue_weights(tap + RING);    // (its ring stage was last read for this tap: free behind the barrier too)
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);                                            // the old tap's second k step runs under the DMA
-        __builtin_amdgcn_sched_barrier(0);
-        HB_WAIT(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (tap + RING < 27) issue_weights(tap + RING);
         read_half(tap + 1, 0, 0);
-        continue;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // wait for the weight tile of tap + 1 (everything issued after it may stay in flight: RING - 2 tiles, fewer at the end),
-      // retire this wave's reads of tap's stage; the barrier publishes the one and frees the other
-      const int younger = WP * ((RING - 2) < (25 - tap) ? (RING - 2) : (25 - tap > 0 ? 25 - tap : 0));
-      if (younger >= 4) HB_WAIT(4); else if (younger == 2) HB_WAIT(2); else if (younger == 1) HB_WAIT(1); else HB_WAIT(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (tap + RING < 27) issue_weights(tap + RING);
-      read_half(tap + 1, 0, 0);
+      mma(1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    mma(1);
-    __builtin_amdgcn_sched_barrier(0);
+
+  } else {
+    // ---- a ring stage = TPS taps: one barrier per STAGE (it publishes the next stage and frees the one just used) instead of one per
+    // tap -- 17 barriers per block instead of 31; the DMA of a stage has a whole stage of MFMAs to land under ----
+    constexpr int NST = (27 + TPS - 1) / TPS;
+    auto taps_in = [](int st) { return st < 0 || st >= NST ? 0 : (27 - st * TPS < TPS ? 27 - st * TPS : TPS); };
+    auto issue_stage = [&](int st) {
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) if (st < NST && st * TPS + tt < 27) issue_weights(st * TPS + tt);
+    };
+    {   // plane + stage 0 landed; stages 1 .. RING - 1 stay in flight
+      int infl = 0;
+#pragma unroll
+      for (int st = 1; st < RING; ++st) infl += WP * taps_in(st);
+      HB_WAIT_N(infl);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_half(0, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      read_half(tap, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 27) {
+        const bool edge = (tap + 1) % TPS == 0;              // tap + 1 opens a new stage
+        const int st_e = tap / TPS;                          // the stage tap belongs to
+        if ((tap + 1) % 9 == 0) {
+          // plane switch: every wave holds the last fragments of the old plane in registers
+          HB_WAIT(0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          issue_plane(tap_plane((tap + 1) / 9));
+          if (edge) issue_stage(st_e + RING);                // (the stage just used is free behind the barrier too)
+          __builtin_amdgcn_sched_barrier(0);
+          mma(1);                                            // the old tap's second k step runs under the DMA
+          __builtin_amdgcn_sched_barrier(0);
+          HB_WAIT_N(edge ? WP * taps_in(st_e + RING) : 0);   // the plane has landed; the stage issued behind it may stay in flight
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          read_half(tap + 1, 0, 0);
+          continue;
+        }
+        if (edge) {
+          // stage st_e + 1 landed (the younger stages st_e + 2 .. st_e + RING - 1 may stay in flight); this wave's reads of stage st_e retired
+          int infl = 0;
+#pragma unroll
+          for (int st = st_e + 2; st <= st_e + RING - 1; ++st) infl += WP * taps_in(st);
+          HB_WAIT_N(infl);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          issue_stage(st_e + RING);
+        }
+        read_half(tap + 1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+#undef HB_WAIT_N
 #undef HB_WAIT
   __syncthreads();                  // the epilogue reuses the window memory
 
@@ -604,6 +669,15 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
     const int ring = t_ring.get(3);
     const size_t lds2 = (size_t)384 * 128 + (size_t)(ring < 2 ? 2 : (ring > 4 ? 4 : ring)) * 64 * 128;
     hipStream_t hs = (hipStream_t)stream;
+    // MSCL_HALO_TPS: 2 (default) = a ring of two 2-tap stages (80 KB per block), one barrier per STAGE: 17 barriers per block instead
+    // of 31; 1 = one tap per stage with MSCL_HALO_RING stages.  Measured in one process: forward 85.3 -> 83.3 us, input gradient 76.1 ->
+    // 75.1; step 1106-1112 -> 1112-1113 clip-pairs/s.
+    static MsclTune t_tps("MSCL_HALO_TPS");
+    if (t_tps.get(2) == 2) {
+      static bool attr3 = false;
+      if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
+      hipLaunchKernelGGL((conv_halo64b_kernel<8, 2, 2>), dim3(nblk), dim3(512), (size_t)384 * 128 + 4 * 64 * 128, hs, g, src, w, out, addend, ssum, ssq);
+    } else
     if (ring <= 2) hipLaunchKernelGGL((conv_halo64b_kernel<8, 2>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
     else if (ring == 3) hipLaunchKernelGGL((conv_halo64b_kernel<8, 3>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);
     else hipLaunchKernelGGL((conv_halo64b_kernel<8, 4>), dim3(nblk), dim3(512), lds2, hs, g, src, w, out, addend, ssum, ssq);

@@ -211,8 +211,8 @@ def test_conv_pp_forced(case, dev, monkeypatch):
 HALO2_CASES = [('h2_small', 2, 4, 12, 12), ('h2_plane56', 1, 3, 56, 56), ('h2_tail', 3, 5, 13, 11), ('h2_w61', 1, 2, 9, 61), ('h2_T1', 2, 1, 20, 20)]
 
 
-@pytest.mark.parametrize('blocks,waves,ring', [(2, 8, 3), (2, 8, 4), (2, 8, 2), (1, 8, 4)],
-                         ids=['b2r3', 'b2r4', 'b2r2', 'one_block'])
+@pytest.mark.parametrize('blocks,waves,ring', [(2, 8, 3), (2, 8, 4), (2, 8, 2), (1, 8, 4), (2, 8, 22)],
+                         ids=['b2r3', 'b2r4', 'b2r2', 'one_block', 'b2_two_tap_stages'])
 @pytest.mark.parametrize('case', HALO2_CASES, ids=[c[0] for c in HALO2_CASES])
 def test_conv_halo_two_blocks(case, blocks, waves, ring, dev, monkeypatch):
     """every form of the window-resident layer-1 conv: two blocks per CU (the default: ring of 3) with each ring depth, and the
@@ -223,7 +223,11 @@ def test_conv_halo_two_blocks(case, blocks, waves, ring, dev, monkeypatch):
     kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     monkeypatch.setenv('MSCL_HALO', '1')
     monkeypatch.setenv('MSCL_HALO_BLOCKS', str(blocks))
-    monkeypatch.setenv('MSCL_HALO_RING', str(ring))
+    if ring == 22:                                     # a ring of two 2-tap stages, one barrier per stage
+        monkeypatch.setenv('MSCL_HALO_TPS', '2')
+    else:
+        monkeypatch.setenv('MSCL_HALO_TPS', '1')
+        monkeypatch.setenv('MSCL_HALO_RING', str(ring))
     lib.tune()
     x = bf(rnd((N, T, H, W, C), 51)); w = bf(rnd((K, *kern, C), 52, scale=(2.0 / (C * 27)) ** 0.5))
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
