@@ -17,6 +17,7 @@ done
 cd $R
 { echo "# commit $H: per-kernel MFMA busy and HBM traffic of the whole step (three PMC passes, single stream, eager)"; python3 tools/pmc_step_summary.py $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE 11; } > $O/step_utilisation.md 2> $O/step_utilisation.err
 { echo "# commit $H: every conv stage alone (tools/bench_conv.py --iters 20, min of 3 rounds), TFLOP/s against the 2500 TFLOP/s dense bf16 peak"; python3 tools/bench_conv.py --iters 20 2>/dev/null | grep -v amdgpu; } > $O/conv_stage.log
+{ echo "# commit $H: SlowOnly-50 conv shapes one at a time (tools/bench_conv.py --r50 --iters 10, min of 3 rounds); GB/s = (input + output map bytes) / time"; python3 tools/bench_conv.py --r50 --iters 10 2>/dev/null | grep -v amdgpu; } > $O/conv_stage_r50.log
 { echo "# commit $H"; python3 tools/chain_times.py 2>/dev/null | grep -v amdgpu; } > $O/chain_times.txt
 python3 tools/bench_trunk.py > $O/trunk_r18.json 2>/dev/null
 python3 tools/bench_trunk.py --r50 > $O/trunk_r50.json 2>/dev/null
