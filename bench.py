@@ -360,7 +360,7 @@ def main():
                        'aug': 'stochastic flip+jitter+grayscale+blur (variant)' if args.stochastic_aug
                               else 'normalise only (BASELINE.json workload)'},
             'final_loss': loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64b_kernel<8,3> fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64b_kernel<8,2,2> fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                          'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': traffic,
                          'traffic_unit': f'HBM bytes per launch (rocprofv3 PMC, profiles/{tname})',

@@ -264,11 +264,6 @@ int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, int Ts, int H
 /* mean over the middle axis: x (outer, inner, C) bf16 -> out (outer, C) fp32.
  * AdaptiveAvgPool3d((1,1,1)) of necks/base.py:17-21 and ((None,1,1)) of heads/local_cl_head.py:23-24 */
 int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream);
-/* the same with the `inner` rows of every group cut into `parts` shares, one block each, that ADD their share of the mean into
- * `out` (zeroed by the caller; float atomics, so parts = 1 in deterministic mode); mscl_pool_parts gives the part count that brings
- * a launch of few groups (the 64-group pooling of the LMCL features) to about one block per CU */
-int mscl_pool_parts(int outer, int inner, int C);
-int mscl_pool_fwd_parts(const uint16_t* x, float* out, int outer, int inner, int C, int parts, void* stream);
 /* dx (outer, inner, C) bf16 = dout (outer, C) / inner, broadcast; accumulate into dx if accumulate */
 int mscl_pool_bwd(const float* dout, uint16_t* dx, int outer, int inner, int C, int accumulate, void* stream);
 

@@ -493,18 +493,12 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
 // block = 256 threads = G channel-granules x (256/G) row lanes; LDS reduce.
 // Maps wider than 512 channels (the Bottleneck trunks: up to 2048) are cut into 512-channel chunks along blockIdx.y:
 // `C` is the chunk width the thread layout sees, `ldc` the row pitch of the map in elements.
-// gridDim.z > 1 (mscl_pool_fwd_parts): block z sums rows [z * per, (z + 1) * per) of its group and ADDS its share of the mean into a
-// zeroed `out` -- the 64-group pooling of the LMCL features (12.8 MB) ran on 64 blocks, 200 KB each one after the other: 42 us on
-// the tail of the RGB query chain's forward
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner_all, int C, int ldc) {
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C, int ldc) {
   __shared__ float red[4 * 512];
   x += blockIdx.y * C; out += blockIdx.y * C;
   const int G = C >> 3;
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
-  const int per = (inner_all + gridDim.z - 1) / gridDim.z;
-  const int rbeg = blockIdx.z * per;
-  const int inner = min(per, inner_all - rbeg);
-  const long base = ((long)blockIdx.x * inner_all + rbeg) * ldc;
+  const long base = (long)blockIdx.x * inner * ldc;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // eight rows in flight per thread: with one, the 8-block launch over the layer-4 map (98 rows x 512 channels per clip, on
   // the way into the projection head of every chain) was 25 dependent round trips = 40 us for 0.8 MB
@@ -526,31 +520,15 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
   }
   block_channel_sum(s, red, G, C, 1, 0);
   __syncthreads();
-  const float inv = 1.f / (float)inner_all;
-  for (int i = threadIdx.x; i < C; i += 256) {
-    const float v = (red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]) * inv;
-    if (gridDim.z > 1) { if (inner > 0) atomicAdd(&out[(long)blockIdx.x * ldc + i], v); }
-    else out[(long)blockIdx.x * ldc + i] = v;
-  }
+  const float inv = 1.f / (float)inner;
+  for (int i = threadIdx.x; i < C; i += 256)
+    out[(long)blockIdx.x * ldc + i] = (red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]) * inv;
 }
 extern "C" int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream) {
-  return mscl_pool_fwd_parts(x, out, outer, inner, C, 1, stream);
-}
-extern "C" int mscl_pool_parts(int outer, int inner, int C) {
-  // row parts that bring a launch of few groups to about one block per CU, at least 64 rows each; 1 in deterministic mode (the
-  // parts are combined by float atomics)
-  static MsclTune split{"MSCL_POOL_SPLIT"};
-  const int chunks = C > 512 ? C / 512 : 1;
-  if (mscl_det() || !split.get(1) || (long)outer * chunks >= 192 || inner < 128) return 1;
-  int parts = 256 / (outer * chunks);
-  if (parts > inner / 64) parts = inner / 64;
-  return parts < 1 ? 1 : parts;
-}
-extern "C" int mscl_pool_fwd_parts(const uint16_t* x, float* out, int outer, int inner, int C, int parts, void* stream) {
-  if (!x || !out || outer <= 0 || inner <= 0 || C <= 0 || parts < 1 || parts > inner) return MSCL_E_ARG;
+  if (!x || !out || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
   if (C % 8 || ilog2_exact(C / 8) < 0 || C > 4096) return MSCL_E_SHAPE;
   const int Cc = C > 512 ? 512 : C;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer, C / Cc, parts), dim3(256), 0, (hipStream_t)stream, x, out, inner, Cc, C);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer, C / Cc), dim3(256), 0, (hipStream_t)stream, x, out, inner, Cc, C);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -383,19 +383,8 @@ def maxpool_hw_bwd(dout, win, x_shape):
     return dx
 
 
-_POOL_PARTS = {}
-
-
 def pool_fwd(x, outer, inner):
     C = x.shape[-1]
-    key = (outer, inner, C, lib.DET_GEN)
-    parts = _POOL_PARTS.get(key)
-    if parts is None:
-        parts = _POOL_PARTS[key] = lib.call_raw('mscl_pool_parts', outer, inner, C)
-    if parts > 1:           # few groups of many rows: row shares on their own blocks, added into a zeroed output
-        out = torch.zeros((outer, C), dtype=torch.float32, device=x.device)
-        call('mscl_pool_fwd_parts', ptr(x), ptr(out), outer, inner, C, parts, stream_ptr())
-        return out
     out = torch.empty((outer, C), dtype=torch.float32, device=x.device)
     call('mscl_pool_fwd', ptr(x), ptr(out), outer, inner, C, stream_ptr())
     return out

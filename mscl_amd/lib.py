@@ -70,8 +70,6 @@ _SIGS = {
     'mscl_upsample_add': [P, P] + [c_int] * 10 + [P],
     'mscl_upsample_bwd': [P, P] + [c_int] * 9 + [P],
     'mscl_pool_fwd': [P, P, c_int, c_int, c_int, P],
-    'mscl_pool_parts': [c_int, c_int, c_int],
-    'mscl_pool_fwd_parts': [P, P, c_int, c_int, c_int, c_int, P],
     'mscl_pool_bwd': [P, P, c_int, c_int, c_int, c_int, P],
     'mscl_maxpool_hw_fwd': [P, P, P, c_int, c_int, c_int, c_int, P],
     'mscl_maxpool_hw_bwd': [P, P, P, c_int, c_int, c_int, c_int, P],

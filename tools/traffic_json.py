@@ -45,7 +45,7 @@ def main():
     alg = 2 * 8 * 16 * 56 * 56 * 64 * 2 + 27 * 64 * 64 * 2          # map in + map out (bf16) + the kernel once
     out = {
         'commit': commit,
-        'kernel': 'conv_halo64b_kernel<8, 3> forward (two blocks per CU), 3x3x3 64->64 on (8,16,56,56,64) bf16',
+        'kernel': 'conv_halo64b_kernel forward (two blocks per CU), 3x3x3 64->64 on (8,16,56,56,64) bf16',
         'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/bench_conv.py --only l1_64_64 '
                    '--iters 3 --modes fwd (two separate passes; tools/evidence_r04.sh)',
         'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write, 'dispatches_per_pass': [nf, nw],
