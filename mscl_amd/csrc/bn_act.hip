@@ -20,24 +20,57 @@ __device__ __forceinline__ void bn_prepare(const BnDev& b, float* scale, float* 
     }
     return;
   }
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    for (int gi = 0; gi < groups; ++gi) {
-      const float* gs = b.sum + (long)gi * MSCL_STAT_SLOTS * 2 * C;
-      const float* gq = b.sumsq + (long)gi * MSCL_STAT_SLOTS * 2 * C;
-      float s1 = 0.f, s2 = 0.f;
-      for (int sl = 0; sl < nslots; ++sl) { s1 += gs[sl * 2 * C + c]; s2 += gq[sl * 2 * C + c]; }
-      const float mean = s1 * inv_n;
-      const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
-      const float inv = rsqrtf(var + eps);
-      const float sc = b.gamma[c] * inv;
-      scale[gi * C + c] = sc; shift[gi * C + c] = b.beta[c] - mean * sc;
-      if (writer) {
-        b.smean[gi * C + c] = mean; b.sinv[gi * C + c] = inv;
-        b.rmean[c] = (1.f - momentum) * b.rmean[c] + momentum * mean;
-        b.rvar[c] = (1.f - momentum) * b.rvar[c] + momentum * var * unbias;
+  // Every load of a channel -- the active statistics slots of every group, gamma / beta, the running statistics the writer block
+  // updates -- goes out BEFORE the first use, two channels per trip: as a loop over the slots with the loads inside, this section was
+  // 4 + 1 + 2 dependent memory round trips per channel trip (the compiler waits on each slot before it issues the next), i.e. most
+  // of the 7-8 us a pass over a small map took.
+  auto prep = [&](int cb) {
+    float a[2][2][MSCL_STAT_ACTIVE], q[2][2][MSCL_STAT_ACTIVE], gam[2], bet[2], rm[2], rv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = cb + k * (int)blockDim.x < C ? cb + k * (int)blockDim.x : cb;      // (the second channel of a short trip repeats the first)
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        if (gi >= groups) break;                           // (uniform: no load is waited for on the way)
+        const float* gs = b.sum + (long)gi * MSCL_STAT_SLOTS * 2 * C;
+        const float* gq = b.sumsq + (long)gi * MSCL_STAT_SLOTS * 2 * C;
+#pragma unroll
+        for (int sl = 0; sl < MSCL_STAT_ACTIVE; ++sl) {
+          const int si = sl < nslots ? sl : 0;             // a valid slot either way; what lies beyond nslots is dropped below
+          a[k][gi][sl] = gs[si * 2 * C + c]; q[k][gi][sl] = gq[si * 2 * C + c];
+        }
       }
+      gam[k] = b.gamma[c]; bet[k] = b.beta[c];
+      rm[k] = writer ? b.rmean[c] : 0.f; rv[k] = writer ? b.rvar[c] : 0.f;
     }
-  }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = cb + k * (int)blockDim.x;
+      if (c >= C) break;
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        if (gi >= groups) break;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < MSCL_STAT_ACTIVE; ++sl) if (sl < nslots) { s1 += a[k][gi][sl]; s2 += q[k][gi][sl]; }
+        const float mean = s1 * inv_n;
+        const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+        const float inv = rsqrtf(var + eps);
+        const float sc = gam[k] * inv;
+        scale[gi * C + c] = sc; shift[gi * C + c] = bet[k] - mean * sc;
+        if (writer) {
+          b.smean[gi * C + c] = mean; b.sinv[gi * C + c] = inv;
+          rm[k] = (1.f - momentum) * rm[k] + momentum * mean;
+          rv[k] = (1.f - momentum) * rv[k] + momentum * var * unbias;
+        }
+      }
+      if (writer) { b.rmean[c] = rm[k]; b.rvar[c] = rv[k]; }
+    }
+  };
+  // (maps of up to 512 channels -- every map of the R3D-18 step -- make ONE trip: written without the loop, whose header would
+  // wait for everything in flight, the caller's first data loads included)
+  if (C <= 2 * (int)blockDim.x) { if ((int)threadIdx.x < C) prep(threadIdx.x); }
+  else for (int cb = threadIdx.x; cb < C; cb += 2 * blockDim.x) prep(cb);
   if (writer && threadIdx.x == 0 && b.nbt) *b.nbt += groups;
 }
 
@@ -414,25 +447,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   };
   unsigned e0 = blockIdx.x * blockDim.x + threadIdx.x;
   load_trip(e0);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    for (int gq = 0; gq < groups; ++gq) {
-      const int k = gq * C + c, kg = gq * ldc + c;          // LDS index; index into the [group][ldc] arrays
-      const float* sc = scratch + (long)gq * MSCL_STAT_SLOTS * 4 * ldc;
-      gi[k] = gamma[c] * inv[kg]; mu[k] = mean[kg]; iv[k] = inv[kg];
-      msh[k] = mask_y ? beta[c] - mean[kg] * (gamma[c] * inv[kg]) : 0.f;
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-      for (int sl = 0; sl < nslots; ++sl) {
-        t0 += sc[sl * 4 * ldc + c]; t1 += sc[sl * 4 * ldc + ldc + c];
-        if (ry) t2 += sc[sl * 4 * ldc + 2 * ldc + c];
+  // Constants of this chunk's (at most 512) channels, two per thread, every load -- the reduce pass's slots, gamma, mean, invstd, beta,
+  // the residual's three -- issued before the first use (as a loop over the slots this was 4 + 1 dependent round trips per channel
+  // on top of the first data trip: half of what a small map's pass took; see bn_prepare)
+  {
+    float t[2][2][3][MSCL_STAT_ACTIVE], gm[2], bt[2], rg[2], mn[2][2], vi[2][2], rmn[2][2], rvi[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = (int)threadIdx.x + k * 256 < C ? (int)threadIdx.x + k * 256 : (int)threadIdx.x % C;
+      gm[k] = gamma[c]; bt[k] = mask_y ? beta[c] : 0.f; rg[k] = ry ? rgamma[c] : 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        if (gq >= groups) break;
+        const int kg = gq * ldc + c;
+        const float* sc = scratch + (long)gq * MSCL_STAT_SLOTS * 4 * ldc;
+        mn[k][gq] = mean[kg]; vi[k][gq] = inv[kg];
+        rmn[k][gq] = ry ? rmean[kg] : 0.f; rvi[k][gq] = ry ? rinv[kg] : 0.f;
+#pragma unroll
+        for (int sl = 0; sl < MSCL_STAT_ACTIVE; ++sl) {
+          const int si = sl < nslots ? sl : 0;             // a valid slot either way; what lies beyond nslots is dropped below
+          t[k][gq][0][sl] = sc[si * 4 * ldc + c]; t[k][gq][1][sl] = sc[si * 4 * ldc + ldc + c];
+          t[k][gq][2][sl] = ry ? sc[si * 4 * ldc + 2 * ldc + c] : 0.f;
+        }
       }
-      ca[k] = t0 * inv_n; cb[k] = t1 * inv_n;
-      if (ry) { rgi[k] = rgamma[c] * rinv[kg]; rmu[k] = rmean[kg]; riv[k] = rinv[kg]; rcb[k] = t2 * inv_n; }
-      p0 += t0; p1 += t1; p2 += t2;
     }
-    if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step, or once with two groups)
-      atomicAdd(&dgamma[c], p1); atomicAdd(&dbeta[c], p0);
-      if (ry) { atomicAdd(&rdgamma[c], p2); atomicAdd(&rdbeta[c], p0); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = (int)threadIdx.x + k * 256;
+      if (c >= C) break;
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        if (gq >= groups) break;
+        const int kk = gq * C + c;                           // LDS index
+        gi[kk] = gm[k] * vi[k][gq]; mu[kk] = mn[k][gq]; iv[kk] = vi[k][gq];
+        msh[kk] = mask_y ? bt[k] - mn[k][gq] * (gm[k] * vi[k][gq]) : 0.f;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < MSCL_STAT_ACTIVE; ++sl) if (sl < nslots) { t0 += t[k][gq][0][sl]; t1 += t[k][gq][1][sl]; t2 += t[k][gq][2][sl]; }
+        ca[kk] = t0 * inv_n; cb[kk] = t1 * inv_n;
+        if (ry) { rgi[kk] = rg[k] * rvi[k][gq]; rmu[kk] = rmn[k][gq]; riv[kk] = rvi[k][gq]; rcb[kk] = t2 * inv_n; }
+        p0 += t0; p1 += t1; p2 += t2;
+      }
+      if (blockIdx.x == 0) {      // parameter gradients (+=: the flow trunk is traversed twice per step, or once with two groups)
+        atomicAdd(&dgamma[c], p1); atomicAdd(&dbeta[c], p0);
+        if (ry) { atomicAdd(&rdgamma[c], p2); atomicAdd(&rdbeta[c], p0); }
+      }
     }
   }
   __syncthreads();
