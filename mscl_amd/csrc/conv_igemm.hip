@@ -410,18 +410,32 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
   for (long r = rbeg + (long)blockIdx.x * RP + tr; r < rend; r += (long)gridDim.x * RP) {
     const long o = r * C + c0;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int sl = 0; sl < nslab; ++sl) {
-      const float* pp = partial + (long)sl * rows * C + o;
-      const float4 a = *reinterpret_cast<const float4*>(pp), b = *reinterpret_cast<const float4*>(pp + 4);
-      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    // four slabs (and the addend) in flight per trip: with the loads inside a loop over the slabs every slab was its own memory
+    // round trip (the compiler waits at the bottom of the loop), 2-16 of them per row on a pass whose rows make one or two trips
+    uint4 av = make_uint4(0, 0, 0, 0);
+    if (addend) av = *reinterpret_cast<const uint4*>(addend + o);
+    const long sstride = rows * C;
+    for (int sl = 0; sl < nslab; sl += 4) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* pp = partial + (long)(sl + u < nslab ? sl + u : sl) * sstride + o;      // (a short trip repeats its first slab; dropped below)
+        a[u] = *reinterpret_cast<const float4*>(pp); b[u] = *reinterpret_cast<const float4*>(pp + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (sl + u < nslab) {
+          v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
     if (bias) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += bias[c0 + i];
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
-    if (addend) { float e[8]; unpack8(*reinterpret_cast<const uint4*>(addend + o), e);
+    if (addend) { float e[8]; unpack8(av, e);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += e[i]; }
     if (relu) {

@@ -263,7 +263,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long n, int nslab) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slab[(long)k * n + e];
+    for (int k = 0; k < nslab; k += 4) {          // four slabs in flight per trip (one per trip = one memory round trip per slab); order kept
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = slab[(long)(k + u < nslab ? k + u : k) * n + e];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (k + u < nslab) s += v[u];
+    }
     dw[e] += s;
   }
 }

@@ -7,7 +7,7 @@ timeout -k 10 600 python -u -m pytest tests/test_kernels_gpu.py -m gpu -x -q --t
 echo "== tests rc $rc"; [ $rc -eq 0 ] || exit 1
 for l in prev new prev new; do
   if [ $l = prev ]; then export MSCL_LIB=$R/mscl_amd/csrc/libmscl_hip_ab.so; else unset MSCL_LIB; fi
-  echo "== $l"; timeout -k 10 300 python -u tools/bench_nce.py 2>&1 | grep -v amdgpu | tee -a $O/nce_$l.log
+  echo "== $l"; timeout -k 10 300 python -u tools/bench_conv.py --modes fwd,dgrad --only l3_256_256,l4_512_512,l4_256_512_s2,neck_333_p1,neck_lat_l4 2>&1 | grep -v amdgpu | tee -a $O/conv_$l.log
 done
 for v in 1 2 3; do for l in prev new; do
   if [ $l = prev ]; then export MSCL_LIB=$R/mscl_amd/csrc/libmscl_hip_ab.so; else unset MSCL_LIB; fi
