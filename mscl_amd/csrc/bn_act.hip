@@ -173,9 +173,11 @@ extern "C" int mscl_bn_act_fwd_groups(const uint16_t* y, const mscl_bn_params* b
   // slots (bn_prepare), so blocks are not free, and a pass that fills every wave slot of the chip shuts the other chains of the
   // step out.  Measured (caps 512 / 512 / 512 for forward / reduce / apply against 2048 / 1024 / 2048, alternating in one call):
   // step 951.6 vs 926.5-928.8 clip-pairs/s, R3D-18 trunk alone 1750 vs 1701 clips/s, SlowOnly-50 trunk at 8 x 32 x 224^2 424.7 vs
-  // 400.4 clips/s; 256 and 384 measured like 512 on the step, 768-1024 in between.  MSCL_BN_FWD_CAP / _RED_CAP / _APPLY_CAP override.
+  // 400.4 clips/s; 256 and 384 measured like 512 on the step, 768-1024 in between.
   constexpr long fwd_cap = 512;                // (round 4, re-swept inside the step with the two-block layer-1 kernels: 256 / 512 / 1024 for each
-                                               // of the three passes within +-0.5 % of one another; 512 stays)
+                                               // of the three passes within +-0.5 % of one another; again after the constants' loads
+                                               // went out together: 512 / 512 / 512 1127, forward 1024 / 2048 1124 / 1117, apply 1024 /
+                                               // 2048 1121 / 1120, reduce 1024 1119, all 1024 1115 clip-pairs/s; 512 stays)
   constexpr long gpt = 1;                      // granules per thread (swept 1 / 2 / 4 inside the step: no gain)
   long blocks = (total + 256 * gpt - 1) / (256 * gpt); if (blocks > fwd_cap) blocks = fwd_cap;
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * groups * C * sizeof(float),
