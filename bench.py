@@ -121,6 +121,20 @@ def cpu_baseline(cpu_batch):
                        f'(mean {mean:.2f} s on {threads} threads)')
 
 
+def chain_fire_times(profiles=None):
+    """(fire times [ms into backward] of the six gradient buckets, backward length, source) from the newest
+    profiles/r0N_chain_times.txt that carries a 'bucket fire times' line (tools/chain_times.py); the round-3 constants otherwise"""
+    import glob
+    import re
+    profiles = profiles or os.path.join(ROOT, 'profiles')
+    for path in sorted(glob.glob(os.path.join(profiles, 'r[0-9][0-9]_chain_times.txt')), reverse=True):
+        for ln in open(path):
+            m = re.match(r'bucket fire times into backward \(ms\) \[[^\]]*\]: ([0-9. ]+); backward ([0-9.]+)', ln)
+            if m:
+                return [float(v) for v in m.group(1).split()], float(m.group(2)), os.path.basename(path)
+    return [0.9, 1.25, 1.8, 3.78, 0.5, 1.7], 3.78, 'constants of profiles/r03_chain_times.txt'
+
+
 def rccl_probe(dev, world, model):
     """What RCCL saw, so that a driver can verify an N-rank line from the line itself (world size > 1, or a one-rank group with
     MSCL_FORCE_DIST=1): backend, world size, the ranks an all-gather returned, the bus bandwidth of one 100-MB fp32 all-reduce
@@ -148,8 +162,9 @@ def rccl_probe(dev, world, model):
         out['grad_buckets_MB'] = [round(n / 1e6, 1) for n in nbytes]
         out['grad_collective'], out['grad_transport'] = red.collective, red.transport
         # fire times into backward (ms) of [layer 4, layer 3, layer 2, stem + layer 1, neck + heads, flow] and the backward's length,
-        # measured on one GPU (profiles/r03_chain_times.txt)
-        fire, bwd = [0.9, 1.25, 1.8, 3.78, 0.5, 1.7], 3.78
+        # measured on one GPU by tools/chain_times.py: read from the newest committed profiles/r0N_chain_times.txt
+        fire, bwd, src = chain_fire_times()
+        out['fire_times_source'] = src
         if len(nbytes) == len(fire):
             out['exposed_wire_ms_model'] = round(parallel.exposed_wire_ms(nbytes, fire, bwd, max(world, 2)), 4)
     return out

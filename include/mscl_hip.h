@@ -121,7 +121,12 @@ int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_
  * (the flow encoder is traversed twice, recognizers/mscl.py:239-240).  dbias (K floats, optional)
  * += sum over positions of dy.  Replaces autograd's conv3d weight/bias gradient.  ws (optional, ws_floats fp32):
  * scratch for the window-resident layer-1 kernel (3x3x3 s1 p1, 64 -> 64), which stores per-block partial slabs and
- * reduces them in a second pass; 256 * 36864 floats cover every shape; NULL selects the general kernel. */
+ * reduces them in a second pass; 256 * 36864 floats cover every shape; NULL selects the general kernel.
+ * INVARIANT (one stream per parameter): where a layer's positions form a single split, and in the slab-reducing kernels, dw is
+ * updated by plain read-modify-write adds, not atomics -- two mscl_conv3d_wgrad calls for the SAME dw must not overlap, i.e. every
+ * launch that writes one parameter's gradient is issued on one stream (or ordered by events).  The MSCL step keeps it: both
+ * traversals of the shared flow trunk run on the flow stream.  The transposed kernels of mscl_weight_transpose[_batched] obey the
+ * same rule with respect to the input-gradient launches that read them. */
 int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
                       float* dbias, float* ws, int64_t ws_floats, void* stream);
 

@@ -94,8 +94,8 @@ class SyncMoCoAugmentV5:
             return x
         return K.color_aug(x.contiguous(), params, self.blur_ksize)
 
-    def pack_rgb(self, x, flip=None):
-        return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, flip=flip)
+    def pack_rgb(self, x, flip=None, out=None):
+        return K.pack_input(x.contiguous(), IMAGENET_MEAN, IMAGENET_STD, flip=flip, out=out)
 
     def pack_flow(self, x, t_off, T, flip=None, out=None):
         if x.shape[1] == 2:                     # raw (u, v): FlowVisualizer fused into the packing pass
@@ -122,8 +122,8 @@ class IdentityAug:
     def __call__(self, clips):
         return clips
 
-    def pack_rgb(self, x, flip=None):
-        return K.pack_input(x.contiguous(), flip=flip)
+    def pack_rgb(self, x, flip=None, out=None):
+        return K.pack_input(x.contiguous(), flip=flip, out=out)
 
     def pack_flow(self, x, t_off, T, flip=None, out=None):
         if x.shape[1] == 2:

@@ -505,8 +505,7 @@ static int launch_cfg(IGemmGeom g, const bf16_t* src, const bf16_t* wgt, bf16_t*
       const long nblk = blocks * g.ksplit;
       // one LDS stage for one-step layers into <= 64 channels (measured on the SlowOnly-50 shapes, A/B in one process: 64 -> 64 1x1x1
       // forward 32.9 -> 29.7 us, its input gradient 26.7 -> 23.8; the write-heavy 64 -> 256 lost 4 %, so wide outputs keep two stages)
-      static MsclTune t_one("MSCL_ONE_STAGE");              // 0: two LDS stages everywhere (A/B)
-      if (nk == 1 && g.ksplit == 1 && g.Cr <= 64 && t_one.get(1) != 0) {
+      if (nk == 1 && g.ksplit == 1 && g.Cr <= 64) {       // (round 4 A/B: 29.7 vs 32.9 us on the SlowOnly-50 64 -> 64 1x1x1 conv; wider outputs lose)
         auto kern1 = conv_igemm_fast_kernel<BM, BN, WAVES_M, WAVES_N, 1>;
         hipLaunchKernelGGL(kern1, dim3((unsigned)nblk), dim3(64 * WAVES_M * WAVES_N), (size_t)(BM + BN) * BK * 2, st, g, src, wgt, out, bias,
                            addend, ssum, ssq, relu, partial);

@@ -359,8 +359,6 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   long target = (CO + NCOL) > 128 ? 512 : 768;            // blocks overall: 2 per CU with the 68-KB 128 x 128 tile, ~3 otherwise
   if (g.C <= 8) target = 2048;                            // stems: 16-byte gathers per position, the DMA latency wants more waves (95 -> 81 us)
   long want = (CO + NCOL) > 128 ? (target / tiles > 0 ? target / tiles : 1) : (target + tiles - 1) / tiles;
-  static MsclTune t_one("MSCL_WGRAD_ONE_SPLIT");          // layers with at least this many tiles run ONE split (plain adds, no atomics)
-  if (tiles >= t_one.get(1 << 30)) want = 1;
   long maxs = (g.M + 255) / 256;                          // at least 4 steps per block
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;

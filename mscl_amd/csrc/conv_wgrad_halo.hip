@@ -59,22 +59,22 @@ typedef __attribute__((address_space(3))) void* wh_lds_t;
 typedef __attribute__((ext_vector_type(4))) short wh_s16x4;
 typedef __attribute__((ext_vector_type(8))) short wh_s16x8;
 
-// NW = waves per block: 8 = two per SIMD that split the k steps of every item (see the header); 4 = one per SIMD, the round-3
-// form, kept as the A/B arm (MSCL_WGRAD_HALO_WAVES=4; 64 -> 64 only)
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g, const bf16_t* __restrict__ x,
+// NW = waves per block: two per SIMD that split the k steps of every item (see the header; the one-wave-per-SIMD form of round 3
+// measured 128 vs 98 us on layer 1 and was deleted in round 5 with its switch MSCL_WGRAD_HALO_WAVES)
+constexpr int WH_NW = 8;
+__global__ __launch_bounds__(64 * WH_NW, 1) void wgrad_halo64_kernel(const WHGeom g, const bf16_t* __restrict__ x,
                                                                   const bf16_t* __restrict__ dy, float* __restrict__ slabs) {
+  constexpr int NW = WH_NW;
   constexpr int NG = NW / 4;                               // wave groups splitting the 8 k steps of an item
   constexpr int RPP = 8 * NW;                              // rows per DMA pass (64 * NW threads x 16 B)
   constexpr int XP = (WH_XROWS + RPP - 1) / RPP, DP = 256 / RPP, NP = XP + DP;      // passes: 12 + 8 / 6 + 4
   constexpr int TRIPS = 4 / NG;                            // trips of two k steps per item and group
-  static_assert(NW == 4 || NW == 8, "waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave & 3, grp = wave >> 2;                // ci tile of the wave; k-step group
   // the three kt blocks of a slot: consecutive logical ids = one XCD (its L2 then serves two of the three reads of every tile)
-  const int lin = NW == 8 ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int sub = lin % g.nsub, slot = lin / g.nsub;       // sub = (co slice * ncs + ci slice) * 3 + kt
   const int kt = sub % 3, cs = (sub / 3) % g.ncs, kslice = sub / (3 * g.ncs);
   const int c2 = g.C * 2, k2 = g.K * 2;                    // row pitch of x / dy in bytes
@@ -91,11 +91,11 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t9][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // items of this block.  NW = 4: plane tiles slot, slot + gk, ... (plane-major).  NW = 8: a contiguous range of the TILE-MAJOR
-  // order (item i = tile i / planes of plane i % planes), the same range for the three kt blocks of the slot.
-  const int i_end = NW == 8 ? (int)((long)(slot + 1) * g.total / g.gk) : g.total;
-  const int i_step = NW == 8 ? 1 : g.gk;
-  auto item_plane = [&](int it) { return NW == 8 ? it - fdiv(it, g.dPlanes) * g.planes : fdiv(it, g.dTiles); };
+  // items of this block: a contiguous range of the TILE-MAJOR order (item i = tile i / planes of plane i % planes), the same range
+  // for the three kt blocks of the slot
+  const int i_end = (int)((long)(slot + 1) * g.total / g.gk);
+  constexpr int i_step = 1;
+  auto item_plane = [&](int it) { return it - fdiv(it, g.dPlanes) * g.planes; };
   auto next_valid = [&](int it) {
     while (it < i_end) {
       const int plane = item_plane(it);
@@ -113,9 +113,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
   int x_q = 0, d_q = 0;                                    // padded-linear position of the row of the NEXT piece of each kind
   unsigned xs = 0, ds = 0;
   auto prepare = [&](int it) {
-    int plane, tile;
-    if constexpr (NW == 8) { tile = fdiv(it, g.dPlanes); plane = it - tile * g.planes; }
-    else { plane = fdiv(it, g.dTiles); tile = it - plane * g.tiles; }
+    const int tile = fdiv(it, g.dPlanes), plane = it - tile * g.planes;
     const int q0 = g.Wp + tile * 256;
     x_q = q0 - g.Wp - 1 + prow;                            // >= -1
     d_q = q0 + prow;
@@ -140,7 +138,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
     }
   };
 
-  int pt = next_valid(NW == 8 ? (int)((long)slot * g.total / g.gk) : slot);
+  int pt = next_valid((int)((long)slot * g.total / g.gk));
   int cur = 0;
   if (pt < i_end) {
     prepare(pt);
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
     __syncthreads();                                       // ... for every wave; the other stage is no longer being read
     const bool has_next = nxt < i_end;
     if (has_next) prepare(nxt);
-    // 72 steps (8 k steps x 9 taps) as trips of 18 (4 per wave at NW = 4, 2 at NW = 8): static register slots (A double buffer
+    // 72 steps (8 k steps x 9 taps) as trips of 18 (2 per wave): static register slots (A double buffer
     // by k-step parity, B ring of 3), the trip's k base lives in the address registers, the k step inside a trip in the
     // immediate offset.  Operands are fetched two steps ahead; the last trip's look-ahead reads fall beyond the wave's k steps
     // (harmless, never used) so that the hand-counted waits stay the same on every trip.
@@ -205,10 +203,9 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
 #undef WH_CASE
           default: break;
         }
-        // next item's tiles.  NW = 4: 20 DMA pieces on the odd steps of the first trips, so the last one is >= 1.5 trips old
-        // when the item ends.  NW = 8: 10 pieces per wave, all in the first of its two trips (odd steps and step 16): a whole trip
+        // next item's tiles: 10 pieces per wave, all in the first of its two trips (odd steps and step 16): a whole trip
         // (>= 1150 cycles of MFMA work) lies between the last issue and the next item's wait.
-        const bool islot = NW == 4 ? ((ls & 1) != 0) : (trip == 0 && ((ls & 1) != 0 || ls == 16));
+        const bool islot = trip == 0 && ((ls & 1) != 0 || ls == 16);
         if (has_next && islot && piece < NP) { issue_piece(piece, cur ^ 1); ++piece; }
         // this step's operands were issued two steps ago: everything younger may stay in flight
         const int y1 = ((ls + 1) % 9 == 0) ? 10 : 2;       // reads issued by the previous step
@@ -246,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_halo64_kernel(const WHGeom g
   // 16 wq + (lane & 15)), and both the hand-over between the SIMD partners and the slab are laid out [wq][t9 * 4 + i][lane] float4 --
   // 36 ds_write_b128 / ds_read_b128 and 36 global_store_dwordx4 per lane, every wave instruction 1 KB contiguous (the [tap][co][ci]
   // order of rounds 3-4 took 144 dword instructions for each, the stores in 64-byte segments).  The reduce kernel undoes the order.
-  if constexpr (NW == 8) {
+  {
     // ---- the k-step halves of a SIMD pair: waves 4-7 hand their 144 partial sums per lane over through LDS (4 x 36 KB, the
     // stages are dead), waves 0-3 add them in a fixed order ----
     __syncthreads();
@@ -325,9 +322,6 @@ static bool wh_shape(const mscl_conv_desc* d) {
   if ((long)d->N * d->T * d->H * d->W * d->C * 2 >= (1L << 31) || (long)d->N * d->T * d->H * d->W * d->K * 2 >= (1L << 31)) return false;
   static MsclTune t_min("MSCL_WGRAD_HALO_MIN");
   if ((long)d->H * Wp < t_min.get(200)) return false;
-  static MsclTune t_ch("MSCL_WGRAD_HALO_MAXC");             // widest layer that takes it (A/B: 64 = layer 1 only, the round-3 scope)
-  const int maxc = t_ch.get(512);
-  if (d->C > maxc || d->K > maxc) return false;
   const int nsub = 3 * (d->C / 64) * (d->K / 64);
   if (nsub > wh_cus()) return false;
   // enough plane tiles for every block to walk a few: a block that stages one or two items pays its prologue, its pair reduction
@@ -361,8 +355,7 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   g.total = d->N * d->T * g.tiles;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   int gk = wh_slots(d);
@@ -371,10 +364,8 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   g.gk = gk;
   g.planes = d->N * d->T;
   g.dWp = make_fastdiv(g.Wp); g.dTiles = make_fastdiv(g.tiles); g.dT = make_fastdiv(d->T); g.dPlanes = make_fastdiv(g.planes);
-  static MsclTune t_nw("MSCL_WGRAD_HALO_WAVES");            // 8 (default): two waves per SIMD; 4: the round-3 form (64 -> 64 only)
   const unsigned blocks = (unsigned)(g.nsub * gk);
-  if (t_nw.get(8) == 4 && g.nsub == 3) hipLaunchKernelGGL(wgrad_halo64_kernel<4>, dim3(blocks), dim3(256), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
-  else hipLaunchKernelGGL(wgrad_halo64_kernel<8>, dim3(blocks), dim3(512), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
+  hipLaunchKernelGGL(wgrad_halo64_kernel, dim3(blocks), dim3(64 * WH_NW), (size_t)2 * WH_STAGE, st, g, x, dy, ws);
   MSCL_LAUNCH_CHECK();
   const long total4 = (long)g.nsub * (WH_SLAB / 4);
   hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, (const float4*)ws, dw, gk, g.nsub,

@@ -298,15 +298,21 @@ class ClipPairLoader:
             return
         stop, th, q = st
         stop.set()
-        if th.is_alive():
-            for slot in self._slots:
-                slot.free.set()                                      # wake a filler waiting for a slot
-            while th.is_alive():
-                try:
-                    q.get_nowait()                                   # make room for a filler blocked in q.put
-                except queue.Empty:
-                    pass
-                th.join(timeout=0.01)
+        # The slots belong to the epoch that is running now (self._active): only that epoch's retirement -- or the loader's own,
+        # st = None -- may touch them.  The reset is gated on OWNERSHIP, not on the filler being alive: a filler that has
+        # finished can leave [last batch, None] in the queue, and a consumer that walks away before those batches reach
+        # _to_device leaves their slots with `free` cleared -- the next epoch's filler would wait on them for ever.
+        owner = (not mine) or getattr(self, '_active', None) is st
+        if owner:
+            if th.is_alive():
+                for slot in self._slots:
+                    slot.free.set()                                  # wake a filler waiting for a slot
+                while th.is_alive():
+                    try:
+                        q.get_nowait()                               # make room for a filler blocked in q.put
+                    except queue.Empty:
+                        pass
+                    th.join(timeout=0.01)
             for slot in self._slots:                                 # uploads already queued must finish before a slot is refilled
                 if slot.event is not None:
                     slot.event.synchronize()

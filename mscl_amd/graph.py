@@ -93,9 +93,9 @@ class GraphedStep:
                 self._ptr_cpu[i] = t.data_ptr()
             self._ptr_ring.push(self._ptr_cpu)
             self._live = (self._live[-2:] if hasattr(self, '_live') else []) + [srcs]      # the clips of the last replays stay referenced
-            for k, v in self.static.items():        # whatever else the batch carries still travels through its static buffer
-                if k != m.im_key and k not in m.flow_key and k in batch:
-                    for dst, src in zip(v, batch[k]):
+            for k in ('flip_mask', 'aug_params'):   # what else the captured step READS travels through its static buffer; nothing
+                if k in self.static and k in batch:  # else does ('label' would cost B scalar copy launches per replay for no reader)
+                    for dst, src in zip(self.static[k], batch[k]):
                         if torch.is_tensor(dst) and dst.data_ptr() != src.data_ptr():
                             dst.copy_(src, non_blocking=True)
         else:

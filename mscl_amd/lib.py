@@ -183,9 +183,12 @@ def tune(**switches):
         else:
             os.environ[k] = str(v)
     call('mscl_tuning_reload')
+    global DET_GEN
+    DET_GEN += 1              # scratch sizes depend on the switches too (MSCL_WGRAD_HALO_*, MSCL_THIN): cached plans must not outlive them
 
 
-DET_GEN = 0
+DET_GEN = 0              # generation of everything a cached per-(module, shape) plan depends on: the deterministic flag AND the tuning
+# switches.  Bumped by set_deterministic() and tune(); code that flips either through lib.call() directly must bump it itself.
 DET = False              # mirror of the library's flag for the per-launch Python paths (scratch sizing)
 
 

@@ -74,14 +74,19 @@ class Conv3dHip(nn.Module):
         """the transposed bf16 kernel the input-gradient kernels read, refreshed first if an optimizer step has left it behind the
         masters (TransposeState: the refresh is deferred off the step's serial tail, so EVERY reader comes through here)"""
         st = self._rt.get('wt_state')
-        if st is not None and st.stale:
-            st.refresh()
+        if st is not None:
+            if st.stale:
+                st.refresh()
+            elif st.event is not None:
+                st.sync_reader()
         return self._rt['wT']
 
     def dgrad(self, dy, x_shape, addend=None):
         return K.conv3d_dgrad(dy, self.wT(), self.desc(x_shape), addend=addend)
 
     def wgrad(self, x, dy):
+        """dw += ...: plain adds where one block owns an element (include/mscl_hip.h, mscl_conv3d_wgrad INVARIANT): every
+        application of one conv module runs its weight gradient on ONE stream (the step keeps each trunk / neck on one chain)"""
         rt = self._rt
         d = self.desc(x.shape)
         key = ('w', tuple(x.shape), lib.DET_GEN)
@@ -103,10 +108,28 @@ class TransposeState:
 
     def __init__(self, table):
         self.table, self.stale = table, False
+        self.event, self.stream, self.waited = None, None, set()
 
     def refresh(self):
+        """one launch on the CURRENT stream.  The copies are shared by every stream that runs input gradients, so the refresh
+        leaves an event behind and a reader on another stream waits for it once (sync_reader) -- a custom multi-stream step
+        whose first input gradient triggered the lazy refresh on one stream must not read half-written copies on another.
+        (Under graph capture the step's own fork / join orders the refresh; no event is kept.)"""
         K.weight_transpose_batched(*self.table)
         self.stale = False
+        self.stream = lib.stream_ptr()
+        self.waited = {self.stream}
+        if torch.cuda.is_current_stream_capturing():
+            self.event = None
+        else:
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def sync_reader(self):
+        sp = lib.stream_ptr()
+        if sp not in self.waited:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.waited.add(sp)
 
 
 class BatchNorm3dHip(nn.Module):

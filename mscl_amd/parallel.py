@@ -232,8 +232,13 @@ class GradReducer:
         # measurement aid (bench.py, "exposed_wire_ms_measured"): buckets are not sent at all -- the replicas then drift apart,
         # so only ever for a few timed steps at the very end of a run
         self.skip = False
+        # measurement aid (tools/chain_times.py): called with the bucket index whenever a trigger completes a bucket, also at
+        # world size 1 -- where in backward each bucket's all-reduce would start
+        self.on_fire = None
 
     def bucket_done(self, i, force=False):
+        if self.on_fire is not None and not force:
+            self.on_fire(i)
         if single() or i in self.launched:
             return
         self.hits[i] += 1

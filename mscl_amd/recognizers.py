@@ -356,11 +356,19 @@ class KeyGraph:
         rec.momentum_update(m_dev)
         return rec.encode_k(x)[0]
 
+    def input_slot(self, shape):
+        """the graph's own input buffer when the next run() of a packed clip of this shape will be a replay: the caller packs
+        straight into it and run() skips its copy (a 26-MB device copy per key branch and eager step otherwise); else None"""
+        if self.graph is not None and self.shape == tuple(shape) and not torch.cuda.is_current_stream_capturing():
+            return self.static_in
+        return None
+
     def run(self, rec, x, m_dev):
         if torch.cuda.is_current_stream_capturing():        # inside a whole-step capture: stay part of that graph
             return self._body(rec, x, m_dev)
         if self.graph is not None and self.shape == tuple(x.shape):
-            self.static_in.copy_(x)
+            if x.data_ptr() != self.static_in.data_ptr():
+                self.static_in.copy_(x)
             self.graph.replay()
             return self.out
         self.calls += 1
@@ -395,7 +403,8 @@ class _ReplayFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, holder):
-        holder.static_x.copy_(x)
+        if x.data_ptr() != holder.static_x.data_ptr():      # (the caller may have packed straight into the graph's input: input_slot)
+            holder.static_x.copy_(x)
         holder.fwd.replay()
         ctx.holder = holder
         return holder.q.detach(), holder.p.detach()
@@ -452,6 +461,13 @@ class QueryGraph:
             nn_hip.HOLD_BUCKETS[0] = False
         self.q, self.p, self.fwd, self.bwd, self.shape = q.detach(), p.detach(), fwd, bwd, tuple(x.shape)
 
+    def input_slot(self, shape):
+        """as KeyGraph.input_slot: the forward graph's input buffer when the next run() of this shape will be a replay"""
+        if (self.fwd is not None and self.shape == tuple(shape) and not self.failed and torch.is_grad_enabled()
+                and not torch.cuda.is_current_stream_capturing()):
+            return self.static_x
+        return None
+
     def run(self, body, x, trigger, anchor):
         """body(x) -> (q, pooled map, map shape) is the eager formulation; returns the same triple"""
         usable = not (self.failed or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled())
@@ -468,6 +484,32 @@ class QueryGraph:
             return body(x)
         q, p = _ReplayFn.apply(x, anchor, self)
         return q, p, self.map_shape
+
+
+class _Split2Fn(torch.autograd.Function):
+    """x -> (x[:n], x[n:]) along axis 0, whose backward hands the two gradients back as ONE tensor without arithmetic when they
+    are neighbours in one buffer (the loss node lays its input gradients out that way, kernels.loss_unpack): autograd's own
+    slicing would answer each half with a zero-filled full tensor and add the two -- six small launches on the step's serial
+    path per split (profiles/r04_glue_launches.txt: 4 slice_backward + their adds)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.rows = n, x.shape[0]
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, rows = ctx.n, ctx.rows
+        if (ga is not None and gb is not None and ga.is_contiguous() and gb.is_contiguous() and ga.dtype == gb.dtype
+                and ga.untyped_storage().data_ptr() == gb.untyped_storage().data_ptr()
+                and ga.storage_offset() + ga.numel() == gb.storage_offset()):
+            return torch.as_strided(ga, (rows,) + tuple(ga.shape[1:]), ga.stride(), ga.storage_offset()), None
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        ga = ga if ga is not None else ref.new_zeros((n,) + tuple(ref.shape[1:]))
+        gb = gb if gb is not None else ref.new_zeros((rows - n,) + tuple(ref.shape[1:]))
+        return torch.cat([ga, gb], 0), None
 
 
 class _MSCLLossFn(torch.autograd.Function):
@@ -749,6 +791,8 @@ class MSCLWithAug(nn.Module):
 
     @torch.no_grad()
     def refresh_after_optimizer(self):
+        if self._wt is None:                # before materialize(): no shadows or transposed copies exist yet (sync_shadows builds them)
+            return
         for rec in (self.recognizer, self.recognizer_flow):
             for fn in rec._q_refresh:
                 fn()
@@ -959,6 +1003,13 @@ class MSCLWithAug(nn.Module):
         rec.momentum_update(m_dev)
         return rec.encode_k(x)[0]
 
+    def _key_slot(self, slot, shape):
+        """where the packed key clip of call site `slot` goes: the key sub-graph's own input buffer when that graph is about to be
+        replayed (no copy into it then), else a fresh tensor (None)"""
+        if self.key_graphs and self.training:
+            return self._key_graph[slot].input_slot(shape)
+        return None
+
     def active_query_graphs(self):
         """the QueryGraph holders the step uses: one (base || rotated in one pass) with flow_batch, else one per pass"""
         return self._query_graph[:1] if self.flow_batch else self._query_graph
@@ -1052,31 +1103,36 @@ class MSCLWithAug(nn.Module):
         with torch.cuda.stream(s_fq):
             if self.flow_batch:
                 Bq = flow_q.shape[0]
-                xq = torch.empty((2 * Bq, Th, flow_q.shape[3], flow_q.shape[4], 8), dtype=torch.bfloat16, device=flow_q.device)
+                xshape = (2 * Bq, Th, flow_q.shape[3], flow_q.shape[4], 8)
+                xq = self._query_graph[0].input_slot(xshape) if (self.query_graphs and self.training) else None
+                if xq is None:
+                    xq = torch.empty(xshape, dtype=torch.bfloat16, device=flow_q.device)
                 aug.pack_flow(flow_q, 0, Th, flip_q, out=xq[:Bq])
                 aug.pack_flow(flow_q, Th, Th, flip_q, out=xq[Bq:])
                 q_f, p_f, fs = self._flow_query(2, xq)
                 tq = fs[1]
-                q_fb, q_fa = q_f[:Bq], q_f[Bq:]
-                p_fb, p_fa = p_f[:Bq * tq], p_f[Bq * tq:]
+                q_fb, q_fa = _Split2Fn.apply(q_f, Bq)
+                p_fb, p_fa = _Split2Fn.apply(p_f, Bq * tq)
                 fmap_shape = (Bq,) + tuple(fs[1:])
             else:
                 q_fb, p_fb, fmap_shape = self._flow_query(0, aug.pack_flow(flow_q, 0, Th, flip_q))
                 q_fa, p_fa, _ = self._flow_query(1, aug.pack_flow(flow_q, Th, Th, flip_q))
         with torch.cuda.stream(s_fk):
             # two EMA updates, two BN-statistics passes (App. E-5)
+            kshape = (flow_k.shape[0], Th, flow_k.shape[3], flow_k.shape[4], 8)
             if dp:
-                k_fb = self._encode_key(1, recf, aug.pack_flow(fk_b, 0, Th, flip_k1), sc[1:2])
-                k_fa = self._encode_key(2, recf, aug.pack_flow(fk_a, 0, Th, flip_k2), sc[2:3])
+                k_fb = self._encode_key(1, recf, aug.pack_flow(fk_b, 0, Th, flip_k1, out=self._key_slot(1, kshape)), sc[1:2])
+                k_fa = self._encode_key(2, recf, aug.pack_flow(fk_a, 0, Th, flip_k2, out=self._key_slot(2, kshape)), sc[2:3])
             else:
-                k_fb = self._encode_key(1, recf, aug.pack_flow(flow_k, 0, Th, flip_k), sc[1:2])
-                k_fa = self._encode_key(2, recf, aug.pack_flow(flow_k, Th, Th, flip_k), sc[2:3])
+                k_fb = self._encode_key(1, recf, aug.pack_flow(flow_k, 0, Th, flip_k, out=self._key_slot(1, kshape)), sc[1:2])
+                k_fa = self._encode_key(2, recf, aug.pack_flow(flow_k, Th, Th, flip_k, out=self._key_slot(2, kshape)), sc[2:3])
         # -- RGB key branch (no gradient): a third stream, it only meets the query branch in the loss
         with torch.cuda.stream(side_k):
+            rshape = (im_k.shape[0], im_k.shape[2], im_k.shape[3], im_k.shape[4], 8)
             if dp:
-                x_k = aug.pack_rgb(im_k_x, flip_k0)
+                x_k = aug.pack_rgb(im_k_x, flip_k0, out=self._key_slot(0, rshape))
             else:
-                x_k = aug.pack_rgb(aug.color(im_k, color_k, 1), flip_k)
+                x_k = aug.pack_rgb(aug.color(im_k, color_k, 1), flip_k, out=self._key_slot(0, rshape))
             k_rgb = self._encode_key(0, rec, x_k, sc[0:1])
         if not q_first:
             q_rgb, maps_rgb = issue_query()

@@ -207,3 +207,37 @@ def test_loader_old_epoch_finalised_after_a_new_one_started(dev, tmp_path):
         for _ in range(len(loader) + 1):
             next(old2)
     it3.close()
+
+
+@pytest.mark.timeout(180)
+def test_loader_walks_away_after_the_filler_has_finished(dev, tmp_path):
+    """(round-4 advisor) default ring of 3 slots (queue of 2): the filler can finish and leave [last batch, None] queued.  A
+    consumer that breaks on the penultimate batch then drains a batch whose slot never reached _to_device -- its `free` flag stays
+    cleared -- so the slot reset must follow OWNERSHIP of the epoch, not whether the filler thread is still alive: the next epoch
+    yields every batch instead of waiting on that slot for ever."""
+    from mscl_amd import Config
+    from mscl_amd.data import ClipPairLoader, MSCLPipeline
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/recognition/moco/mscl_r18_cosm_lr2e-2.py'))
+    T, B, hw, fhw = 4, 2, (40, 52), (20, 26)
+    store, vids = _make_store(str(tmp_path / 'store'), 8, 120, hw, fhw, seed=6)
+    steps = [dict(s) for s in cfg.train_pipeline]
+    for s in steps:
+        if s['type'] == 'TemporalShiftChosenSampleFrames':
+            s.update(clip_len=T, frame_interval=2)
+        if s['type'] == 'MoCoResize':
+            s.update(scale=(32, 32))
+    pipe = MSCLPipeline.from_cfg(steps)
+    loader = ClipPairLoader(store, pipe, B, dev, seed=3, shuffle=False, slots=3)
+    n = len(loader)
+    assert n == 4
+    for i, batch in enumerate(loader):
+        if i == n - 2:                              # the penultimate batch: wait until the filler has queued the rest and returned
+            th = loader._active[1]
+            th.join(timeout=30)
+            assert not th.is_alive()
+            break
+    assert all(s.free.is_set() for s in loader._slots)      # the drained batch's slot was handed back
+    full = list(loader)
+    assert [len(b['label']) for b in full] == [B] * n
+    assert loader._active is None

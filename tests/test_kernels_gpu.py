@@ -203,7 +203,7 @@ def test_conv_pp_forced(case, dev, monkeypatch):
         assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
 
 
-# conv_halo64b_kernel (conv_halo.hip: two blocks per CU, one window slot, half-tap operand pipeline) with every weight-ring depth:
+# conv_halo64b_kernel (conv_halo.hip: two blocks per CU, one window slot, half-tap operand pipeline, ring of two 2-tap weight stages):
 # planes smaller than a tile and of several tiles with a ragged last one, the widest plane the window takes (W = 61), T = 1 / 2 (a
 # missing neighbour plane on one or both sides: a zero window), forward with statistics and with an addend, input gradient with and
 # without addend, and the same launch many times over (a race between the window / ring DMA and the fragment reads shows as a
@@ -211,23 +211,15 @@ def test_conv_pp_forced(case, dev, monkeypatch):
 HALO2_CASES = [('h2_small', 2, 4, 12, 12), ('h2_plane56', 1, 3, 56, 56), ('h2_tail', 3, 5, 13, 11), ('h2_w61', 1, 2, 9, 61), ('h2_T1', 2, 1, 20, 20)]
 
 
-@pytest.mark.parametrize('blocks,waves,ring', [(2, 8, 3), (2, 8, 4), (2, 8, 2), (1, 8, 4), (2, 8, 22)],
-                         ids=['b2r3', 'b2r4', 'b2r2', 'one_block', 'b2_two_tap_stages'])
 @pytest.mark.parametrize('case', HALO2_CASES, ids=[c[0] for c in HALO2_CASES])
-def test_conv_halo_two_blocks(case, blocks, waves, ring, dev, monkeypatch):
-    """every form of the window-resident layer-1 conv: two blocks per CU (the default: ring of 3) with each ring depth, and the
-    one-block-per-CU form of rounds 1-3 (the A/B arm)"""
+def test_conv_halo_two_blocks(case, dev, monkeypatch):
+    """the window-resident layer-1 conv (the A/B arms of round 4 -- one block per CU, one-tap ring stages of depth 2 / 3 / 4 -- were
+    deleted in round 5 with their switches)"""
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W = case
     C = K = 64
     kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     monkeypatch.setenv('MSCL_HALO', '1')
-    monkeypatch.setenv('MSCL_HALO_BLOCKS', str(blocks))
-    if ring == 22:                                     # a ring of two 2-tap stages, one barrier per stage
-        monkeypatch.setenv('MSCL_HALO_TPS', '2')
-    else:
-        monkeypatch.setenv('MSCL_HALO_TPS', '1')
-        monkeypatch.setenv('MSCL_HALO_RING', str(ring))
     lib.tune()
     x = bf(rnd((N, T, H, W, C), 51)); w = bf(rnd((K, *kern, C), 52, scale=(2.0 / (C * 27)) ** 0.5))
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
@@ -263,8 +255,7 @@ def test_conv_halo_two_blocks(case, blocks, waves, ring, dev, monkeypatch):
 # plane smaller than one 256-position tile is a tile of mostly zero rows): one and several channel slices each way, more blocks
 # than slots and fewer, several items per block (tile-major ranges that cross sample and tile boundaries), T = 1 / 2 (planes
 # without a neighbour on one or both sides: every item of kt = 0 / 2 skipped), a plane of several tiles with a ragged last one,
-# accumulation into a non-zero dw with a bias gradient, and the same bits on every run (slot-ordered slab sums).  The round-3
-# form (one wave per SIMD) stays covered as the A/B arm on the 64 -> 64 cases.
+# accumulation into a non-zero dw with a bias gradient, and the same bits on every run (slot-ordered slab sums).
 WGRAD_HALO_CASES = [
     ('wh_64_64', 2, 4, 12, 12, 64, 64),
     ('wh_64_64_T1', 3, 1, 10, 9, 64, 64),
@@ -278,17 +269,13 @@ WGRAD_HALO_CASES = [
 ]
 
 
-@pytest.mark.parametrize('waves', [8, 4])
 @pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=[c[0] for c in WGRAD_HALO_CASES])
-def test_conv_wgrad_halo_forced(case, waves, dev, monkeypatch):
+def test_conv_wgrad_halo_forced(case, dev, monkeypatch):
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K = case
-    if waves == 4 and (C, K) != (64, 64):
-        pytest.skip('the one-wave-per-SIMD arm covers 64 -> 64 only')
     kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     monkeypatch.setenv('MSCL_WGRAD_HALO_MIN', '1')            # planes of any size
     monkeypatch.setenv('MSCL_WGRAD_HALO_ITEMS', '0')          # ... and any number of them
-    monkeypatch.setenv('MSCL_WGRAD_HALO_WAVES', str(waves))
     lib.tune()
     x = bf(rnd((N, T, H, W, C), 41)); w = rnd((K, *kern, C), 42)
     d = K_.conv_desc(x.shape, K, kern, stride, pad)

@@ -89,6 +89,33 @@ def main():
         out[name + ' fwd'] = timed(qg.fwd.replay, a.iters)
         out[name + ' bwd'] = timed(qg.bwd.replay, a.iters)
 
+    # where in backward each gradient bucket's all-reduce would start (GradReducer.on_fire): events in two eager three-stream steps,
+    # as fractions of that backward, scaled to the graph-replayed RGB backward above (eager launches are host-paced).
+    # bench.py's ring model (rccl.exposed_wire_ms_model) reads this line from the newest profiles/r0N_chain_times.txt.
+    fired = {}
+    def on_fire(i):
+        if i not in fired:
+            e = torch.cuda.Event(enable_timing=True); e.record(); fired[i] = e
+    fracs = None
+    for rep in range(2):
+        fired.clear()
+        o = model.train_step(batch, sync_logs=False)
+        opt.zero_grad()
+        model.reducer.on_fire = on_fire
+        model.reducer.hits = [0] * len(model.reducer.ranges)
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        o['loss'].backward()
+        model.sync_streams()
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        model.reducer.on_fire = None
+        opt.step()
+        torch.cuda.synchronize()
+        total = e0.elapsed_time(e1)
+        fracs = [e0.elapsed_time(fired[i]) / total if i in fired else 1.0 for i in range(len(model.reducer.ranges))]
+    bwd_ms = out['rgb query bwd']
+    fire_line = 'bucket fire times into backward (ms) [layer4, layer3, layer2, stem+layer1, neck+heads, flow]: ' + \
+        ' '.join('%.3f' % (f * bwd_ms) for f in fracs) + '; backward %.3f' % bwd_ms
+
     # optimizer + EMA-free tail
     def tail():
         opt.zero_grad()
@@ -103,6 +130,7 @@ def main():
             out[f'whole step, graph, {streams} stream(s)'] = timed(lambda: gs.step(batch), a.iters)
     for k, v in out.items():
         print(f'{k:55s} {v:8.3f} ms', flush=True)
+    print(fire_line, flush=True)
     f = out
     print('sum of chains (rgb q f+b, rgb k, 2 flow q f+b, 2 flow k): %.3f ms' % (
         f['rgb query fwd'] + f['rgb query bwd'] + f['rgb key (EMA+fwd)'] + 2 * (f['flow query, one pass fwd'] + f['flow query, one pass bwd'])
