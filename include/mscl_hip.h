@@ -295,7 +295,8 @@ int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* 
  * queue is the reference buffer (dim, K) fp32, count (K) int64.  For each of R query rows
  * (q: R x dim fp32, pos_logit: R floats = q.k_pos, *not yet* divided by T) computes over the aged
  * snapshot W = queue * 0.99999^count without materialising it:
- *   part[blk][r] = {max, sum exp(l-max), #negatives with logit > pos logit}   (pass 1, one K chunk per block)
+ *   part[blk][r] = {max, sum exp(l-max), #negatives with logit > pos logit}   (pass 1, one chunk of 128 queue columns per block:
+ *   nblk = ceil(K / 128); K must be even -- a lane reads two columns of a queue row as one 8-byte piece)
  *   then mscl_nce_finish: lse, loss_r = lse - pos/T, rank_r, and probabilities' normaliser.
  * Pass 2 (mscl_nce_bwd) re-streams the queue and accumulates dq[r] = (1/T) sum_k softmax_k * W[:,k]
  * (the positive-key term is added by the caller's tiny kernel mscl_nce_pos_bwd); ws = scratch for the per-block

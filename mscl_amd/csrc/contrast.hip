@@ -5,8 +5,8 @@
 // (dim, K) buffer; query rows are wave-uniform and come through the scalar cache.
 #include "common.h"
 
-#define NCE_COLS 64           // queue columns per block; 4 waves split the feature dimension
-#define NCE_WAVES 4
+#define NCE_BCOLS 128         // queue columns per block, TWO per lane: a wave-instruction reads 512 B of one queue row
+#define NCE_WAVES 4           // the 4 waves split the feature dimension
 
 // "Virtual enqueue": the snapshot the reference takes AFTER _dequeue_and_enqueue(keys) (moco.py:423-440) -- every age +1, the
 // n_new columns from *ptr on replaced by the new keys at age 1 -- read straight from the queue as it stands BEFORE that write
@@ -19,79 +19,152 @@ __device__ __forceinline__ bool nce_in_new(const NceVirt& v, int k, int& j) {
   j = k - (int)*v.ptr;
   return j >= 0 && j < v.n_new;
 }
-__device__ __forceinline__ float nce_age(const NceVirt& v, const int64_t* count, int k) {
-  int j;
-  if (v.keys == nullptr) return (float)count[k];
-  return nce_in_new(v, k, j) ? 1.f : (float)(count[k] + 1);
-}
 
-// Each block owns 64 queue columns; wave w accumulates channels [w*dim/4, (w+1)*dim/4) of the dot products
-// (4x the loads in flight of a column-per-thread loop: the pass is latency-bound otherwise), partials are
-// summed through LDS.  lg[r] = logit of (row r, this lane's column) is returned to wave 0's lanes.
-// query rows staged once per block as qs[c][RT] (channel-major): the rows of one channel are then a few broadcast
-// ds_read_b128; fetching them through the scalar cache (RT s_loads per channel, each waited for) kept the pass at
-// 0.5 TB/s of queue reads
+// Round 5: wider pieces, two blocks per CU.  Rounds 1-4 gave a block 64 columns, one per lane: a wave-instruction read 256 bytes of
+// a queue row, the next row's piece lay 256 KB further on, and a wave held 32 such loads: 28.6 / 38.2 us per pass over the 33.5-MB
+// queue (1.1 TB/s, 0.14 of the HBM peak) on the step's serial loss phase.  Measured on the way here: 256 columns per block, four per
+// lane (1-KB pieces, one 110-KB block per CU) 17.0 / 34.9 us -- with ONE wave per SIMD the 3072 multiply-adds of a lane (24 rows),
+// the load round trips and the LDS exchange follow one another instead of overlapping.  Kept: 128 columns per block, two per lane
+// (512-byte pieces), every load of the lane's 32 channels in flight before the first use, and LDS small enough for TWO blocks per CU
+// (two waves per SIMD: one block's arithmetic runs under the other's loads).
+// Wave w takes channels [w dim/4, (w + 1) dim/4) of the dot products; the four partial sums of a (row, column) meet through LDS.
+// Query rows are staged once per block as qs[c][RT] (channel-major): the rows of one channel are then a few broadcast
+// ds_read_b128; fetching them through the scalar cache (RT s_loads per channel, each waited for) kept the pass at 0.5 TB/s.
+// (qs always holds 128 channel rows: the waves take fixed 32-channel shares of a 128-channel space, channels >= dim are zeros --
+// loops over a runtime channel count sent the load buffer to scratch and put a wait behind every load)
 template <int RT>
-__device__ __forceinline__ void nce_stage_q(const float* __restrict__ q, float* __restrict__ qs, int R, int dim) {
-  for (int i = threadIdx.x; i < dim * RT; i += blockDim.x) {
-    const int c = i / RT, r = i - c * RT;
-    qs[i] = r < R ? q[r * dim + c] : 0.f;
+__device__ __forceinline__ void nce_q_load(const float* __restrict__ q, float (&qr)[RT / 2], int R, int dim) {
+#pragma unroll
+  for (int n = 0; n < RT / 2; ++n) {          // 128 RT elements over 256 threads; issued AHEAD of the queue loads, stored behind them
+    const int i = threadIdx.x + 256 * n, c = i / RT, r = i - c * RT;
+    const bool ok = r < R && c < dim;
+    const float v = q[ok ? r * dim + c : 0];
+    qr[n] = ok ? v : 0.f;
   }
 }
-
 template <int RT>
-__device__ __forceinline__ void nce_partial(const float* __restrict__ queue, const float* __restrict__ qs, int k, int dim,
-                                            int K, int wave, float* acc, const NceVirt& vt) {
-  const int cq = dim / NCE_WAVES, c0 = wave * cq;
+__device__ __forceinline__ void nce_q_store(const float (&qr)[RT / 2], float* __restrict__ qs) {
 #pragma unroll
-  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-  // every queue load of this lane's column slice is issued before the first use (dim <= 128: at most 32 per wave): the pass
-  // is one round of blocks, so its time is the number of dependent memory round trips, not bandwidth
-  float wv[32];
-  int jn = 0;
-  const bool isnew = nce_in_new(vt, k, jn);
+  for (int n = 0; n < RT / 2; ++n) qs[threadIdx.x + 256 * n] = qr[n];
+}
+
+// the lane's columns: first column (clamped for a lane past the end: K is even, so a lane is live or dead as a whole), which of
+// them the virtual enqueue replaces, their age decay.  In two steps: the positions need no memory and the queue loads go out on
+// them; the ages (two dependent round trips: the queue pointer, then the counts) are fetched BEHIND those loads and turned into
+// decays after the arithmetic -- at the head of the kernel they held the queue loads back by their full latency.
+struct NceCols { int k0; bool live; int newmask; int jn[2]; float decay[2]; };
+__device__ __forceinline__ NceCols nce_cols(int blk, int lane, int K, const NceVirt& vt) {
+  NceCols c;
+  const int k = blk * NCE_BCOLS + lane * 2;
+  c.live = k < K;
+  c.k0 = c.live ? k : K - 2;
+  c.newmask = 0;
+  c.jn[0] = c.jn[1] = 0; c.decay[0] = c.decay[1] = 0.f;
+  if (vt.keys != nullptr) {                    // (wave-uniform; the plain passes skip the pointer load)
 #pragma unroll
-  for (int i = 0; i < 32; ++i) wv[i] = i < cq ? (isnew ? vt.keys[(long)jn * dim + c0 + i] : queue[(long)(c0 + i) * K + k]) : 0.f;
+    for (int j = 0; j < 2; ++j)
+      if (nce_in_new(vt, c.k0 + j, c.jn[j])) c.newmask |= 1 << j;
+  }
+  return c;
+}
+__device__ __forceinline__ void nce_decay(NceCols& c, const int64_t* __restrict__ count, const NceVirt& vt) {
+  const long a0 = count[c.k0], a1 = count[c.k0 + 1];
+  const float age0 = vt.keys == nullptr ? (float)a0 : ((c.newmask & 1) ? 1.f : (float)(a0 + 1));
+  const float age1 = vt.keys == nullptr ? (float)a1 : ((c.newmask & 2) ? 1.f : (float)(a1 + 1));
+  c.decay[0] = powf(0.99999f, age0); c.decay[1] = powf(0.99999f, age1);      // recognizers/moco.py:484
+}
+
+// wv[i] = the lane's two columns of queue row c0 + i in the snapshot `vt` describes, every load issued before the first use; the rare
+// lanes whose columns the virtual enqueue replaces patch the components in
+__device__ __forceinline__ void nce_load_cols(const float* __restrict__ queue, float2 (&wv)[32], int c0, int dim, int K,
+                                              const NceCols& cl, const NceVirt& vt) {
+  // unconditional loads from clamped rows, zeroed afterwards by a select: a load under a condition becomes a branch with a wait
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
-    if (i >= cq) break;
-    const int c = c0 + i;
-    const float w = wv[i];
-    const float4* qv = reinterpret_cast<const float4*>(qs + c * RT);
+    const int c = c0 + i < dim ? c0 + i : dim - 1;
+    wv[i] = *reinterpret_cast<const float2*>(queue + (long)c * K + cl.k0);
+  }
+  if (cl.newmask) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int c = c0 + i < dim ? c0 + i : dim - 1;
+      if (cl.newmask & 1) wv[i].x = vt.keys[(long)cl.jn[0] * dim + c];
+      if (cl.newmask & 2) wv[i].y = vt.keys[(long)cl.jn[1] * dim + c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i)
+    if (c0 + i >= dim) wv[i] = make_float2(0.f, 0.f);
+}
+
+// acc[r] (a float2: the lane's two columns) = sum over this wave's channels of q[r][c] * W[c][k0 .. k0 + 1]
+template <int RT>
+__device__ __forceinline__ void nce_partial(const float* __restrict__ qs, const float2 (&wv)[32], int c0, float2 (&acc)[RT]) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float2 w = wv[i];
+    const float4* qv = reinterpret_cast<const float4*>(qs + (c0 + i) * RT);
 #pragma unroll
     for (int r4 = 0; r4 < RT / 4; ++r4) {
       const float4 v = qv[r4];
-      acc[4 * r4 + 0] = fmaf(v.x, w, acc[4 * r4 + 0]); acc[4 * r4 + 1] = fmaf(v.y, w, acc[4 * r4 + 1]);
-      acc[4 * r4 + 2] = fmaf(v.z, w, acc[4 * r4 + 2]); acc[4 * r4 + 3] = fmaf(v.w, w, acc[4 * r4 + 3]);
+      const float qr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float2& a = acc[4 * r4 + u];
+        a.x = fmaf(qr[u], w.x, a.x); a.y = fmaf(qr[u], w.y, a.y);
+      }
     }
+    // left alone, the scheduler hoists the (independent) query-row reads of ALL channels above the arithmetic: hundreds of registers, spills
+    if (i & 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// part[(blk*R + r)*3 + {0: max, 1: sum exp(l - max), 2: #(l > pos)}]
+// part[(blk*R + r)*3 + {0: max, 1: sum exp(l - max), 2: #(l > pos)}], one block per 128 columns
 template <int RT>
-__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
-                                                      const float* __restrict__ q, const float* __restrict__ pos,
-                                                      float* __restrict__ part, int R, int dim, int K, float inv_T, const NceVirt vt) {
-  __shared__ float red[NCE_WAVES][RT][NCE_COLS];
-  __shared__ __attribute__((aligned(16))) float qs[128 * RT];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = blockIdx.x * NCE_COLS + lane;
-  const bool live = k < K;
-  nce_stage_q<RT>(q, qs, R, dim);
+__global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                         const float* __restrict__ q, const float* __restrict__ pos,
+                                                         float* __restrict__ part, int R, int dim, int K, float inv_T, const NceVirt vt) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // qs[dim][RT] | red[4][RT][64 lanes] float2
+  float* qs = sm; float2* red = reinterpret_cast<float2*>(qs + 128 * RT);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: row bases in SGPRs)
+  const int c0 = wave * 32;
+  NceCols cl = nce_cols(blockIdx.x, lane, K, vt);
+  float qr[RT / 2];
+  nce_q_load<RT>(q, qr, R, dim);
+  float2 wv[32];
+  nce_load_cols(queue, wv, c0, dim, K, cl, vt);              // (the loads travel while the query rows are staged)
+  nce_decay(cl, count, vt);
+  nce_q_store<RT>(qr, qs);
   __syncthreads();
-  float acc[RT];
-  nce_partial<RT>(queue, qs, live ? k : K - 1, dim, K, wave, acc, vt);
+  {
+    float2 acc[RT];
+    nce_partial<RT>(qs, wv, c0, acc);
 #pragma unroll
-  for (int r = 0; r < RT; ++r) red[wave][r][lane] = acc[r];
+    for (int r = 0; r < RT; ++r) red[(wave * RT + r) * 64 + lane] = acc[r];
+  }
+  // (the tile stays "in use" to here, as it does in the backward kernel, which compiles to 138 registers: without a later use hipcc
+  // turns this kernel's channel loop inside out -- query-row reads of nine channels ahead of the first multiply -- and spills 209)
+#pragma unroll
+  for (int i = 0; i < 32; ++i) asm volatile("" :: "v"(wv[i].x), "v"(wv[i].y));
   __syncthreads();
   // wave w finishes rows r = w, w+4, ...
-  const float decay = powf(0.99999f, nce_age(vt, count, live ? k : K - 1));      // recognizers/moco.py:484
+#pragma unroll 1
   for (int r = wave; r < R; r += NCE_WAVES) {
-    const float dot = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
-    const float l = live ? dot * decay * inv_T : -INFINITY;
-    const float m = wave_max(l);
-    const float s = wave_sum(live ? __expf(l - m) : 0.f);
-    const float c = wave_sum((live && l > pos[r] * inv_T) ? 1.f : 0.f);
+    const float2 d0 = red[(0 * RT + r) * 64 + lane], d1 = red[(1 * RT + r) * 64 + lane], d2 = red[(2 * RT + r) * 64 + lane],
+                 d3 = red[(3 * RT + r) * 64 + lane];
+    const float dot[2] = {d0.x + d1.x + d2.x + d3.x, d0.y + d1.y + d2.y + d3.y};
+    const float pr = pos[r] * inv_T;
+    float l[2], cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      l[j] = cl.live ? dot[j] * cl.decay[j] * inv_T : -INFINITY;
+      cnt += (cl.live && l[j] > pr) ? 1.f : 0.f;
+    }
+    const float m = wave_max(fmaxf(l[0], l[1]));
+    const float s = wave_sum(cl.live ? __expf(l[0] - m) + __expf(l[1] - m) : 0.f);
+    const float c = wave_sum(cnt);
     if (lane == 0) { float* o = part + ((long)blockIdx.x * R + r) * 3; o[0] = m; o[1] = s; o[2] = c; }
   }
 }
@@ -138,88 +211,89 @@ __global__ __launch_bounds__(256) void nce_finish_kernel(const float* __restrict
 }
 
 // dq[r][c] += inv_T * row_scale[r] * sum_k softmax_k * decay_k * queue[c][k]
-// A block walks NCE_BWD_CHUNKS chunks of 64 columns and keeps its dq contribution in registers; the per-block results go
-// to a slab ([block][RT][dim], plain stores) summed by nce_bwd_reduce_kernel.  (One atomicAdd per element per 64-column
-// block meant 3 M float atomics on the same 12 KB: contention-bound at 67 us for a 33.5 MB read.)
-#define NCE_BWD_CHUNKS 2
-#define NCE_WPAD 68          // Wt row pitch in floats: 16-byte aligned rows, conflict-free b128 reads down a column of threads
+// A block owns 128 columns.  Phase 1 = the forward's logits (partial sums through LDS) -> the softmax coefficients gc[r][column].
+// Phase 2 = the block's share of dq as a [RT x 128] x [128 x dim] product on the vector units: the queue tile is still in the
+// registers that loaded it and is laid out by channel, Wt[channel][128 columns], over the dead reduction image; a thread owns FOUR
+// channels x RT / 8 rows, so a 4-column step costs 4 + RT / 8 sixteen-byte LDS reads for 2 RT multiply-adds (one channel x RT / 2
+// rows, the round-1 form, cost 1 + RT / 2: the phase was LDS-bound).
+// The per-block results go to a slab ([block][RT][dim], plain stores) summed by nce_bwd_reduce_kernel.  (One atomicAdd per
+// element per block meant millions of float atomics on the same 12 KB: contention-bound at 67 us for a 33.5-MB read.)
+#define NCE_WPAD 132         // Wt row pitch in floats: 16-byte aligned rows, conflict-free b128 reads down 16 consecutive channels
 template <int RT>
-__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
-                                                      const float* __restrict__ q, const float* __restrict__ lse,
-                                                      const float* __restrict__ row_scale, float* __restrict__ slab,
-                                                      int R, int dim, int K, float inv_T, const NceVirt vt) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // qs[dim][RT], Wt[dim][NCE_WPAD], red[4][RT][NCE_COLS] (reused as gcoef[RT][NCE_COLS])
-  float* qs = sm; float* Wt = qs + dim * RT; float* red = Wt + dim * NCE_WPAD;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cq = dim / NCE_WAVES, c0 = wave * cq;
-  nce_stage_q<RT>(q, qs, R, dim);
-  // phase-2 ownership: thread -> (channel c2, half of the rows)
-  const int c2 = threadIdx.x % 128, half = threadIdx.x / 128;
-  constexpr int RH = RT / 2;
-  float a2[RH];
+__global__ __launch_bounds__(256, 2) void nce_bwd_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                         const float* __restrict__ q, const float* __restrict__ lse,
+                                                         const float* __restrict__ row_scale, float* __restrict__ slab,
+                                                         int R, int dim, int K, float inv_T, const NceVirt vt) {
+  // LDS: [ qs[dim][RT], later gc[RT][128] ] [ red[4][RT][64] float2, later Wt[dim][NCE_WPAD] ] -- the coefficients are written when
+  // the last reader of the query rows has passed the barrier behind phase 1
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* qs = sm; float* gc = sm;
+  float2* red = reinterpret_cast<float2*>(sm + RT * NCE_BCOLS);
+  float* Wt = reinterpret_cast<float*>(red);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: row bases in SGPRs)
+  const int c0 = wave * 32;
+  NceCols cl = nce_cols(blockIdx.x, lane, K, vt);
+  float qr[RT / 2];
+  nce_q_load<RT>(q, qr, R, dim);
+  float2 wv[32];
+  nce_load_cols(queue, wv, c0, dim, K, cl, vt);
+  nce_decay(cl, count, vt);
+  nce_q_store<RT>(qr, qs);
+  __syncthreads();
+  {
+    float2 acc[RT];
+    nce_partial<RT>(qs, wv, c0, acc);
 #pragma unroll
-  for (int r = 0; r < RH; ++r) a2[r] = 0.f;
-  for (int ch = 0; ch < NCE_BWD_CHUNKS; ++ch) {
-    const int k = (blockIdx.x * NCE_BWD_CHUNKS + ch) * NCE_COLS + lane;
-    const bool live = k < K;
-    const int kk = live ? k : K - 1;
-    __syncthreads();                            // qs staged / previous chunk's Wt, gcoef consumed
-    float acc[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-    float wv[32];                               // all loads of the slice in flight at once (see nce_partial)
-    int jn = 0;
-    const bool isnew = nce_in_new(vt, kk, jn);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) wv[i] = i < cq ? (isnew ? vt.keys[(long)jn * dim + c0 + i] : queue[(long)(c0 + i) * K + kk]) : 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      if (i >= cq) break;
-      const int c = c0 + i;
-      const float w = wv[i];
-      Wt[c * NCE_WPAD + lane] = live ? w : 0.f;
-      const float4* qv = reinterpret_cast<const float4*>(qs + c * RT);
-#pragma unroll
-      for (int r4 = 0; r4 < RT / 4; ++r4) {
-        const float4 v = qv[r4];
-        acc[4 * r4 + 0] = fmaf(v.x, w, acc[4 * r4 + 0]); acc[4 * r4 + 1] = fmaf(v.y, w, acc[4 * r4 + 1]);
-        acc[4 * r4 + 2] = fmaf(v.z, w, acc[4 * r4 + 2]); acc[4 * r4 + 3] = fmaf(v.w, w, acc[4 * r4 + 3]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RT; ++r) red[(wave * RT + r) * NCE_COLS + lane] = acc[r];
-    __syncthreads();
-    const float decay = powf(0.99999f, nce_age(vt, count, kk));
-    float coef[RT / NCE_WAVES + 1];
-    int nc = 0;
-    for (int r = wave; r < RT; r += NCE_WAVES, ++nc) {
-      float dot = 0.f;
-#pragma unroll
-      for (int w = 0; w < NCE_WAVES; ++w) dot += red[(w * RT + r) * NCE_COLS + lane];
-      const float l = dot * decay * inv_T;
-      coef[nc] = (live && r < R) ? __expf(l - lse[r < R ? r : 0]) * decay * inv_T * row_scale[r < R ? r : 0] : 0.f;
-    }
-    __syncthreads();
-    float* gc = red;                              // [RT][NCE_COLS]
-    nc = 0;
-    for (int r = wave; r < RT; r += NCE_WAVES, ++nc) gc[r * NCE_COLS + lane] = coef[nc];
-    __syncthreads();
-    if (c2 < dim) {
-      for (int j = 0; j < NCE_COLS; j += 4) {     // 16-byte LDS reads: 13 per 48 FMAs (gc rows are broadcast reads)
-        const float4 w = *reinterpret_cast<const float4*>(Wt + c2 * NCE_WPAD + j);
-#pragma unroll
-        for (int r = 0; r < RH; ++r) {
-          const float4 gv = *reinterpret_cast<const float4*>(gc + (half * RH + r) * NCE_COLS + j);
-          a2[r] = fmaf(gv.x, w.x, fmaf(gv.y, w.y, fmaf(gv.z, w.z, fmaf(gv.w, w.w, a2[r]))));
-        }
-      }
-    }
+    for (int r = 0; r < RT; ++r) red[(wave * RT + r) * 64 + lane] = acc[r];
   }
-  if (c2 < dim) {
-    float* o = slab + (long)blockIdx.x * RT * dim;
+  __syncthreads();
+  float2 cf[RT / NCE_WAVES];
 #pragma unroll
-    for (int r = 0; r < RH; ++r) o[(half * RH + r) * dim + c2] = a2[r];
+  for (int n = 0; n < RT / NCE_WAVES; ++n) {
+    const int r = wave + n * NCE_WAVES;
+    const float2 d0 = red[(0 * RT + r) * 64 + lane], d1 = red[(1 * RT + r) * 64 + lane], d2 = red[(2 * RT + r) * 64 + lane],
+                 d3 = red[(3 * RT + r) * 64 + lane];
+    const float dot[2] = {d0.x + d1.x + d2.x + d3.x, d0.y + d1.y + d2.y + d3.y};
+    const bool rl = cl.live && r < R;
+    const float ls = lse[r < R ? r : 0], sc = inv_T * row_scale[r < R ? r : 0];
+    cf[n].x = rl ? __expf(dot[0] * cl.decay[0] * inv_T - ls) * cl.decay[0] * sc : 0.f;
+    cf[n].y = rl ? __expf(dot[1] * cl.decay[1] * inv_T - ls) * cl.decay[1] * sc : 0.f;
   }
+  __syncthreads();                                // every wave has read red (and qs long before): both regions change hands
+#pragma unroll
+  for (int n = 0; n < RT / NCE_WAVES; ++n)
+    *reinterpret_cast<float2*>(gc + (wave + n * NCE_WAVES) * NCE_BCOLS + lane * 2) = cf[n];
+#pragma unroll
+  for (int i = 0; i < 32; ++i)                    // (all 128 rows: channels >= dim hold zeros)
+    *reinterpret_cast<float2*>(Wt + (c0 + i) * NCE_WPAD + lane * 2) = cl.live ? wv[i] : make_float2(0.f, 0.f);
+  __syncthreads();
+  // phase 2: thread -> channels cg + 32 u (u < 4), rows RG rg .. RG rg + RG - 1
+  constexpr int RG = RT / 8;
+  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  float a2[RG][4];
+#pragma unroll
+  for (int r = 0; r < RG; ++r)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a2[r][u] = 0.f;
+#pragma unroll 2
+  for (int j = 0; j < NCE_BCOLS; j += 4) {
+    float4 w[4], gv[RG];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(Wt + (cg + 32 * u) * NCE_WPAD + j);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) gv[r] = *reinterpret_cast<const float4*>(gc + (rg * RG + r) * NCE_BCOLS + j);
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        a2[r][u] = fmaf(gv[r].x, w[u].x, fmaf(gv[r].y, w[u].y, fmaf(gv[r].z, w[u].z, fmaf(gv[r].w, w[u].w, a2[r][u]))));
+  }
+  float* o = slab + (long)blockIdx.x * RT * dim;
+#pragma unroll
+  for (int r = 0; r < RG; ++r)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (cg + 32 * u < dim) o[(rg * RG + r) * dim + cg + 32 * u] = a2[r][u];
 }
 
 // dq[r][c] += sum over blocks of slab[b][r][c]  (rows r < R); blockIdx.y takes every gridDim.y-th slab
@@ -268,18 +342,28 @@ extern "C" int mscl_nce_fwd_virt(const float* queue, const int64_t* count, const
   if (!queue || !count || !q || !pos_logit || !part || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
   if (new_keys && (!queue_ptr || n_new <= 0 || n_new > K)) return MSCL_E_ARG;
   const NceVirt vt{new_keys, queue_ptr, new_keys ? n_new : 0};
-  if (dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
+  if (dim > 128 || dim % NCE_WAVES || K % 2) return MSCL_E_SHAPE;       // (K % 2: a lane reads two columns as one 8-byte piece)
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (K + NCE_COLS - 1) / NCE_COLS;
+  const int nblk = (K + NCE_BCOLS - 1) / NCE_BCOLS;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_fwd_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
   for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {
     const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
+    const int rt = Rt <= 8 ? 8 : (Rt <= 16 ? 16 : (Rt <= 24 ? 24 : 32));
+    const size_t lds = ((size_t)128 * rt + (size_t)NCE_WAVES * rt * NCE_BCOLS) * sizeof(float);        // 61 KB at 24 rows: two blocks per CU
     const float* qt = q + (size_t)r0 * dim; const float* pt = pos_logit + r0;
     float* part_t = part + (size_t)nblk * r0 * 3;
     NCE_DISPATCH(Rt,
-      hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
-      hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
-      hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
-      hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt))
+      hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_fwd_kernel<24>, dim3(nblk), dim3(256), lds, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
+      hipLaunchKernelGGL(nce_fwd_kernel<32>, dim3(nblk), dim3(256), lds, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt))
     MSCL_LAUNCH_CHECK();
   }
   return 0;
@@ -305,11 +389,12 @@ extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const
   if (!queue || !count || !q || !lse || !row_scale || !dq || !ws || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
   if (new_keys && (!queue_ptr || n_new <= 0 || n_new > K)) return MSCL_E_ARG;
   const NceVirt vt{new_keys, queue_ptr, new_keys ? n_new : 0};
-  if (dim > 128 || dim % NCE_WAVES) return MSCL_E_SHAPE;
+  if (dim > 128 || dim % NCE_WAVES || K % 2) return MSCL_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (K + NCE_COLS * NCE_BWD_CHUNKS - 1) / (NCE_COLS * NCE_BWD_CHUNKS);
+  const int nblk = (K + NCE_BCOLS - 1) / NCE_BCOLS;
   static bool attr = false;
   if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -319,7 +404,8 @@ extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const
     const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
     const int rt = Rt <= 8 ? 8 : (Rt <= 16 ? 16 : (Rt <= 24 ? 24 : 32));
     if ((int64_t)nblk * rt * dim > ws_floats) return MSCL_E_ARG;
-    const size_t lds = ((size_t)dim * rt + (size_t)dim * NCE_WPAD + (size_t)NCE_WAVES * rt * NCE_COLS) * sizeof(float);
+    const size_t red_f = (size_t)NCE_WAVES * rt * NCE_BCOLS, wt_f = (size_t)128 * NCE_WPAD;      // Wt lies over the dead reduction image
+    const size_t lds = ((size_t)rt * NCE_BCOLS + (red_f > wt_f ? red_f : wt_f)) * sizeof(float);          // (dim <= 128 = NCE_BCOLS: gc covers qs); 79 KB at 24 rows
     const float* qt = q + (size_t)r0 * dim; const float* lt = lse + r0; const float* st_ = row_scale + r0;
     NCE_DISPATCH(Rt,
       hipLaunchKernelGGL(nce_bwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, qt, lt, st_, ws, Rt, dim, K, inv_T, vt),

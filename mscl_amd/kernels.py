@@ -434,7 +434,7 @@ def l2norm_bwd(y, norms, dy):
     return dx
 
 
-NCE_COLS = 64
+NCE_COLS = 128           # queue columns per block of the InfoNCE passes (NCE_BCOLS in csrc/contrast.hip): nblk = ceil(K / 128)
 
 
 def nce_forward(queue, count, q, pos, inv_T, virt=None):

@@ -25,14 +25,27 @@ for R in (8, 24):
         return K.nce_backward(queue, count, q, lse, ones, 1 / 0.07)
 
     for name, fn in (('fwd', fwd), ('bwd', bwd)):
+        # device time: 20 calls captured into ONE HIP graph and replayed (eager calls are host-paced: two launches and four
+        # allocations per call cost the host more than the kernels take)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g):
+                for _ in range(20):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
-            fn()
+        for _ in range(5):
+            g.replay()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        print(f'R={R:2d} {name}: {us:7.1f} us   {dim * Kq * 4 / us / 1e3:7.1f} GB/s of queue reads')
+        us = e0.elapsed_time(e1) / 100 * 1e3
+        print(f'R={R:2d} {name}: {us:7.1f} us   {dim * Kq * 4 / us / 1e3:7.1f} GB/s of queue reads (graph replay, incl. the finish / slab-sum launch)')
