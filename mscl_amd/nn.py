@@ -254,7 +254,14 @@ def _wgrad(conv, x, dy):
     on the step -- two MFMA-heavy kernels side by side do not pay -- and removed in round 3.  Round 3 re-measured the narrowest
     form: only the layer-1 / stem weight gradients of the RGB query trunk, issued AFTER their layer's input gradient on the idle
     key stream so that they would run beside the next BatchNorm-backward passes: 984-988 vs 1043-1048 clip-pairs/s; with layer 2 and
-    the flow trunk's as well 922-937.)"""
+    the flow trunk's as well 922-937.
+    Round 5 measured the opposite selection: only the weight gradients of the SMALL maps (<= 16384 / <= 8192 output positions:
+    layers 3-4, their entries and shortcuts, the pyramid levels, the flow trunk's last layer -- latency-bound kernels at 6 % MFMA
+    busy, ~0.5 ms of the RGB query chain) on ONE extra stream, in issue order, joined once before the optimizer: 1040 / 1042 vs 1129
+    clip-pairs/s (two captured graphs replayed alternately in one process, tools/ab_step.py).  Not the kernels but the fork costs:
+    every cross-stream edge inside the captured step is a barrier packet and a signal between hardware queues, ~30 of them per step
+    here, and each delays the chain it leaves.  Concurrency for small launches has to come from ONE launch (a grouped kernel), not
+    from more streams.)"""
     conv.wgrad(x, dy)
 
 
