@@ -43,7 +43,9 @@ def stage_table(events):
              (128, 256, 14): 'layer3.0.conv1 128->256 s2', (256, 256, 14): 'layer3 256->256 @4x14x14',
              (256, 512, 7): 'layer4.0.conv1 256->512 s2', (512, 512, 7): 'layer4 512->512 @2x7x7'}
     acc = {}
-    for mode, d, e0, e1 in events:
+    for ev in events:
+        mode, d, e0, e1 = ev[:4]
+        share = ev[4] if len(ev) > 4 else 1.0          # a grouped launch (nn.WGradQueue): its time split over the layers by FLOPs
         N, T, H, W, C, To, Ho, Wo, K, kT, kH, kW, sT, sH, sW = d
         if C == 8:                                  # 3-channel stems, padded (and W-paired: kW 4 stands for 7 taps)
             name, cin, taps = ('stem rgb' if kT == 3 else 'stem flow'), 3, kT * kH * 7
@@ -53,7 +55,7 @@ def stage_table(events):
             name, cin, taps = ('flow trunk' if C <= 64 and kT == 1 else 'neck / shortcuts (1x1x1, 1x3x3, small 3x3x3)'), C, kT * kH * kW
         gf = 2.0 * N * To * Ho * Wo * K * taps * cin * 1e-9
         a = acc.setdefault(name, {}).setdefault(mode, [0.0, 0.0, 0])
-        a[0] += gf; a[1] += e0.elapsed_time(e1); a[2] += 1
+        a[0] += gf; a[1] += e0.elapsed_time(e1) * share; a[2] += 1
     out = {}
     for name, modes in acc.items():
         out[name] = {m: {'launches': v[2], 'gflop': round(v[0], 2), 'ms': round(v[1], 4),
@@ -338,15 +340,15 @@ def main():
         raise SystemExit('loss is NaN')
 
     if rank == 0:
-        ms = [a.elapsed_time(b) for mode, d, a, b in prof['events']
-              if mode == 'fwd' and (d[4], d[8], d[9], d[2]) == (64, 64, 3, SIDE // 2)]          # layer-1 3x3x3 64->64 forward launches
+        ms = [ev[2].elapsed_time(ev[3]) for ev in prof['events']
+              if ev[0] == 'fwd' and (ev[1][4], ev[1][8], ev[1][9], ev[1][2]) == (64, 64, 3, SIDE // 2)]          # layer-1 3x3x3 64->64 forward launches
         avg_ms = sum(ms) / max(1, len(ms))
         flops = 2.0 * BATCH * T_FRAMES * (SIDE // 2) ** 2 * 64 * 27 * 64       # 88.8 GFLOP per launch
         achieved = flops / (avg_ms * 1e-3) / 1e12 if ms else 0.0
         # second kernel by total time: conv_pp_kernel<128> (layers 2-4, SEPC, FPN); priced on its largest shape, the 128 -> 128
         # 3x3x3 conv on (8,8,28,28,128) = 44.4 GFLOP per launch, forward launches by the same event pairs
-        ms2 = [a.elapsed_time(b) for mode, d, a, b in prof['events']
-               if mode == 'fwd' and (d[4], d[8], d[9], d[2]) == (128, 128, 3, SIDE // 4)]
+        ms2 = [ev[2].elapsed_time(ev[3]) for ev in prof['events']
+               if ev[0] == 'fwd' and (ev[1][4], ev[1][8], ev[1][9], ev[1][2]) == (128, 128, 3, SIDE // 4)]
         avg2 = sum(ms2) / max(1, len(ms2))
         flops2 = 2.0 * BATCH * (T_FRAMES // 2) * (SIDE // 4) ** 2 * 128 * 27 * 128
         ach2 = flops2 / (avg2 * 1e-3) / 1e12 if ms2 else 0.0

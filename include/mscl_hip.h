@@ -130,6 +130,21 @@ int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_
 int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
                       float* dbias, float* ws, int64_t ws_floats, void* stream);
 
+/* Grouped form for the small layers (round 5).  On the small maps -- layers 3-4, their entries and 1x1x1 shortcuts, the pyramid
+ * levels of necks/fpn.py:188-203 and necks/sepc.py:118-135 -- the weight gradient is a launch-latency-bound leaf of the backward
+ * chain (8-41 us at 6 % MFMA busy, ~30 launches per step).  mscl_conv3d_wgrad_group computes the weight gradients of n <=
+ * MSCL_WGRAD_GROUP_MAX layers in ONE launch (and the bias gradients of those with dbias[i] != NULL in one more): the caller defers
+ * the layers' launches, keeps x[i] / dy[i] alive, and hands them over together.  descs: n descriptors; x, dy, dw, dbias: host arrays
+ * of n device pointers (dbias may be NULL, or hold NULLs).  Every layer must be groupable: mscl_conv3d_wgrad_groupable(d) == 1, i.e.
+ * mscl_conv3d_wgrad would take it on its general 64 x 64-tile kernel with no workspace (not in deterministic mode, whose per-split
+ * slab sums run per layer).  Layers of one group that share a dw (a module applied to several pyramid levels) add with float
+ * atomics; the one-stream-per-parameter INVARIANT above holds for the group as for a single call. */
+#define MSCL_WGRAD_GROUP_MAX 16
+int mscl_conv3d_wgrad_groupable(const mscl_conv_desc* d);
+int mscl_conv3d_wgrad_group(int n, const mscl_conv_desc* descs, const uint16_t* const* x, const uint16_t* const* dy,
+                            float* const* dw, float* const* dbias, void* stream);
+int64_t mscl_debug_wgrad_group_launches(void);   /* test aid, as the other launch counters */
+
 /* [Cout][taps][Cin] bf16 -> [Cin][taps][Cout] bf16 */
 int mscl_weight_transpose(const uint16_t* w, uint16_t* wT, int Cout, int taps, int Cin, void* stream);
 /* the same for every conv kernel of a model in ONE launch: `table` is a device array of n entries

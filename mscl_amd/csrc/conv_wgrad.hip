@@ -53,10 +53,13 @@ __device__ __forceinline__ auto wg_rsrc(const void* p, unsigned bytes) {
 
 // WCO = waves along the output-channel axis (1: the 4 waves split the columns and every wave reads the whole dy tile;
 // 2: a 2 x 2 arrangement, used with the 128 x 128 tile where each wave then owns 64 x 64 and one LDS byte feeds 2.5x the MFMAs)
+// `g` may live in the kernarg segment of a single launch or in the item table of a grouped one (conv_wgrad_group_kernel); `bidx` /
+// `nblk`: this block's index among the layer's blocks and their number; `atomic`: dw is shared with another launch item (a conv
+// module applied to several pyramid levels) or with other position splits -> float atomics, else the block owns its elements
 template <int CO, int NCOL, int WCO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ dy, float* __restrict__ dw,
-                                                         float* __restrict__ slab) {
+__device__ __forceinline__ void conv_wgrad_body(const WGeom& g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                float* __restrict__ dw, float* __restrict__ slab, const int bidx, const int nblk,
+                                                const bool atomic) {
   constexpr int PB = 64;                        // positions per step
   constexpr int GA = CO / 8, GB = NCOL / 8;     // granules per tile row
   constexpr int NA = (PB * GA + 255) / 256;     // dy DMA passes (one 1-KiB chunk per wave per pass)
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
   // block order: all column tiles (taps) of ONE position slice are consecutive logical ids and the ids are
   // remapped so that an XCD gets a contiguous run: the slice's x / dy rows are then served 27x from that
   // XCD's L2 instead of the Infinity Cache (layer 1 re-reads 2.8 GB per launch otherwise)
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = xcd_remap(bidx, nblk);
   const int colt = bid % g.col_tiles; bid /= g.col_tiles;
   const int split = bid % g.splits; const int cot = bid / g.splits;
   const int co0 = cot * CO, n0 = colt * NCOL;
@@ -253,10 +256,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf
           // deterministic mode: this split's tile goes to its own slab with plain stores; wgrad_slab_reduce_kernel adds the
           // slabs to dw in split order
           if (slab != nullptr) slab[((long)split * g.K + co) * g.ncols + col] = acc[i][j][r];
-          else if (g.splits == 1) dw[(long)co * g.ncols + col] += acc[i][j][r];       // one owner per element: no atomic needed
+          else if (!atomic) dw[(long)co * g.ncols + col] += acc[i][j][r];             // one owner per element: no atomic needed
           else atomicAdd(&dw[(long)co * g.ncols + col], acc[i][j][r]);
         }
       }
+}
+
+template <int CO, int NCOL, int WCO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGeom g, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                         float* __restrict__ slab) {
+  conv_wgrad_body<CO, NCOL, WCO>(g, x, dy, dw, slab, (int)blockIdx.x, (int)gridDim.x, g.splits > 1);
+}
+
+// ---- grouped launch (round 5): the weight gradients (and bias gradients) of up to MSCL_WGRAD_GROUP_MAX layers in ONE launch --------
+// A weight gradient is a leaf of the backward chain, and on the small maps (layers 3-4, their entries and shortcuts, the pyramid
+// levels) conv_wgrad_kernel<64,64,1> is latency-bound: 8-41 us per launch at 6 % MFMA busy, 30 launches and 0.77 ms of kernel time
+// per step, most of it on the RGB query chain with the chip nearly idle.  Streams do not help -- every fork edge inside the
+// captured step costs more than it hides (profiles/r05_ab_sweeps.md) -- so the concurrency comes from the grid: the host defers
+// these launches, keeps (x, dy) alive, and hands a bucket's worth of them over at once; block b finds its item by a scan of
+// first[] (wave-uniform) and runs the unchanged body on that item's geometry.  Items that share a dw (the SEPC convs are applied to
+// several pyramid levels) add with float atomics.
+#define MSCL_WGRAD_GROUP_MAX 16
+struct WGroupItem { WGeom g; const bf16_t* x; const bf16_t* dy; float* dw; int atomic; int pad_; };
+struct WGroup { int n; int first[MSCL_WGRAD_GROUP_MAX + 1]; WGroupItem it[MSCL_WGRAD_GROUP_MAX]; };
+
+__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WGroup grp) {
+  int i = 0;
+#pragma unroll 1
+  for (int k = 1; k < grp.n; ++k) if ((int)blockIdx.x >= grp.first[k]) i = k;
+  const WGroupItem& it = grp.it[i];
+  conv_wgrad_body<64, 64, 1>(it.g, it.x, it.dy, it.dw, nullptr, (int)blockIdx.x - grp.first[i], grp.first[i + 1] - grp.first[i],
+                             it.atomic != 0);
+}
+
+// bias gradients of the same group: column sums of every item's dy in one launch (colsum_kernel's loop; blockIdx.y = item)
+struct CGroupItem { const bf16_t* dy; float* dbias; long rows; int C; int blocks; };
+struct CGroup { int n; CGroupItem it[MSCL_WGRAD_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void colsum_group_kernel(const CGroup grp) {
+  const CGroupItem& it = grp.it[blockIdx.y];
+  if ((int)blockIdx.x >= it.blocks) return;
+  const int C = it.C, G = C / 8;
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int UNR = 4;
+  const long stride = (long)it.blocks * RP;
+  for (long r0 = (long)blockIdx.x * RP + tr; r0 < it.rows; r0 += stride * UNR) {
+    uint4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long r = r0 + u * stride;
+      v[u] = *reinterpret_cast<const uint4*>(it.dy + (r < it.rows ? r : r0) * C + tg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (r0 + u * stride >= it.rows) break;
+      float f[8]; unpack8(v[u], f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += f[k];
+    }
+  }
+  __shared__ float red[4 * 512];
+  block_channel_sum(s, red, G, C, 1, 0);
+  __syncthreads();
+  for (int k = threadIdx.x; k < C; k += 256) atomicAdd(&it.dbias[k], red[k] + red[C + k] + red[2 * C + k] + red[3 * C + k]);
 }
 
 // dw[e] += slab[0][e] + slab[1][e] + ... in split order (deterministic mode)
@@ -351,8 +414,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]);
 }
 
-template <int CO, int NCOL, int WCO = 1>
-static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipStream_t st, float* det_ws = nullptr, long det_floats = 0) {
+// tiles and position splits of one layer; returns the number of blocks
+template <int CO, int NCOL>
+static long plan_w(WGeom& g) {
   g.co_tiles = (g.K + CO - 1) / CO;
   g.col_tiles = (g.ncols + NCOL - 1) / NCOL;
   const long tiles = (long)g.co_tiles * g.col_tiles;
@@ -365,6 +429,14 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   long per = ((g.M + want - 1) / want + 63) / 64 * 64;
   g.per_split = (int)per;
   g.splits = (int)((g.M + per - 1) / per);
+  return tiles * g.splits;
+}
+
+template <int CO, int NCOL, int WCO = 1>
+static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipStream_t st, float* det_ws = nullptr, long det_floats = 0) {
+  plan_w<CO, NCOL>(g);
+  const long tiles = (long)g.co_tiles * g.col_tiles;
+  long per;
   float* slab = nullptr;
   const long dwn = (long)g.K * g.ncols;
   if (mscl_det() && g.splits > 1) {                       // one fp32 slab per split, added to dw in split order afterwards
@@ -394,6 +466,9 @@ static int launch_w(WGeom g, const bf16_t* x, const bf16_t* dy, float* dw, hipSt
   return 0;
 }
 
+static long g_wgrad_group_launches = 0;
+extern "C" int64_t mscl_debug_wgrad_group_launches(void) { return g_wgrad_group_launches; }      // tests: the grouped launch ran
+
 int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                       hipStream_t st);           // conv_wgrad_halo.hip
 int mscl_wgrad_thin(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
@@ -411,13 +486,10 @@ static bool big_tile(const mscl_conv_desc* d) {
   return M >= 16384 && (long)d->kT * d->kH * d->kW * d->C >= 1728;
 }
 
-extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
-                                 float* dbias, float* ws, int64_t ws_floats, void* stream) {
-  if (!d || !x || !dy || !dw) return MSCL_E_ARG;
+static int wgeom_of(const mscl_conv_desc* d, WGeom& g) {
   if (d->C % 8 || d->K % 8) return MSCL_E_SHAPE;
   if (ilog2_exact(d->K / 8) < 0 || d->K / 8 > 256 || ilog2_exact(d->C / 8) < 0) return MSCL_E_SHAPE;
   if (d->kT > 8 || d->kH > 8 || d->kW > 8) return MSCL_E_SHAPE;
-  WGeom g{};
   g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.C = d->C;
   g.To = d->To; g.Ho = d->Ho; g.Wo = d->Wo; g.K = d->K;
   g.kT = d->kT; g.kH = d->kH; g.kW = d->kW; g.sT = d->sT; g.sH = d->sH; g.sW = d->sW;
@@ -426,6 +498,75 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
   if (M * d->K >= (1L << 30) || (long)d->N * d->T * d->H * d->W * d->C >= (1L << 30)) return MSCL_E_SHAPE;   // 32-bit byte offsets
   g.M = (int)M; g.ntaps = d->kT * d->kH * d->kW; g.cgs = ilog2_exact(d->C / 8); g.ncols = g.ntaps * d->C;
   g.dWo = make_fastdiv(d->Wo); g.dHo = make_fastdiv(d->Ho); g.dTo = make_fastdiv(d->To);
+  return 0;
+}
+
+extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias);
+// 1: mscl_conv3d_wgrad would run this layer on conv_wgrad_kernel<64,64,1> with no workspace -- the layers a grouped launch takes
+extern "C" int mscl_conv3d_wgrad_groupable(const mscl_conv_desc* d) {
+  if (!d || mscl_det()) return 0;                 // deterministic mode sums per-split slabs in a pass of its own: one launch per layer
+  WGeom g{};
+  if (wgeom_of(d, g) != 0) return 0;
+  if (d->K < 64 || big_tile(d)) return 0;
+  return mscl_conv3d_wgrad_ws(d, 0) == 0 ? 1 : 0;  // (> 0: a window-resident kernel takes the layer)
+}
+
+// The weight (and, where dbias[i] != NULL, bias) gradients of n <= MSCL_WGRAD_GROUP_MAX groupable layers in one launch each.
+// descs: n descriptors; x / dy / dw / dbias: n device pointers each (host arrays).
+extern "C" int mscl_conv3d_wgrad_group(int n, const mscl_conv_desc* descs, const uint16_t* const* x, const uint16_t* const* dy,
+                                       float* const* dw, float* const* dbias, void* stream) {
+  if (n <= 0 || n > MSCL_WGRAD_GROUP_MAX || !descs || !x || !dy || !dw) return MSCL_E_ARG;
+  WGroup grp{};
+  CGroup cg{};
+  grp.n = n;
+  long total = 0, cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!x[i] || !dy[i] || !dw[i]) return MSCL_E_ARG;
+    if (!mscl_conv3d_wgrad_groupable(&descs[i])) return MSCL_E_SHAPE;
+    WGroupItem& it = grp.it[i];
+    const int ge = wgeom_of(&descs[i], it.g); if (ge) return ge;
+    const long nb = plan_w<64, 64>(it.g);
+    it.x = x[i]; it.dy = dy[i]; it.dw = dw[i];
+    it.atomic = it.g.splits > 1;
+    for (int k = 0; k < i; ++k) if (dw[k] == dw[i]) { it.atomic = 1; grp.it[k].atomic = 1; }     // one module, several applications
+    grp.first[i] = (int)total;
+    total += nb;
+    if (total >= (1L << 30)) return MSCL_E_SHAPE;
+    if (dbias && dbias[i]) {
+      const mscl_conv_desc* d = &descs[i];
+      if (d->K > 512) return MSCL_E_SHAPE;
+      CGroupItem& c = cg.it[cg.n++];
+      c.dy = dy[i]; c.dbias = dbias[i]; c.rows = it.g.M; c.C = d->K;
+      const int RPc = 256 / (d->K / 8);
+      long b = (c.rows + RPc * 4 - 1) / (RPc * 4); if (b > 256) b = 256; if (b < 1) b = 1;
+      c.blocks = (int)b;
+      if (b > cmax) cmax = b;
+    }
+  }
+  grp.first[n] = (int)total;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * 64 * (64 + 64) * 2 + (size_t)8 * 64 * sizeof(int2);
+  hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3((unsigned)total), dim3(256), lds, st, grp);
+  MSCL_LAUNCH_CHECK();
+  if (cg.n > 0) {
+    hipLaunchKernelGGL(colsum_group_kernel, dim3((unsigned)cmax, cg.n), dim3(256), 0, st, cg);
+    MSCL_LAUNCH_CHECK();
+  }
+  ++g_wgrad_group_launches;
+  return 0;
+}
+
+extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
+                                 float* dbias, float* ws, int64_t ws_floats, void* stream) {
+  if (!d || !x || !dy || !dw) return MSCL_E_ARG;
+  WGeom g{};
+  { const int ge = wgeom_of(d, g); if (ge) return ge; }
+  const long M = g.M;
   hipStream_t st = (hipStream_t)stream;
   int e;
   // 3x3x3 / 1 / 1 layers whose planes fill 256-position tiles: window-resident kernel on 64 x 64 channel slices (its slabs are

@@ -50,6 +50,9 @@ _SIGS = {
     'mscl_conv_halo64': [POINTER(ConvDesc), c_int, P, P, P, P, P, P, P],
     'mscl_conv3d_dgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
     'mscl_conv3d_wgrad': [POINTER(ConvDesc), P, P, P, P, P, c_int64, P],
+    'mscl_conv3d_wgrad_groupable': [POINTER(ConvDesc)],
+    'mscl_conv3d_wgrad_group': [c_int, POINTER(ConvDesc), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), P],
+    'mscl_debug_wgrad_group_launches': [],
     'mscl_weight_transpose': [P, P, c_int, c_int, c_int, P],
     'mscl_weight_transpose_batched': [P, c_int, c_int, P],
     'mscl_bn_act_fwd': [P, POINTER(BnParams), P, POINTER(BnParams), P, c_int64, c_int, c_float, c_float, c_int, P],
@@ -96,7 +99,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_wgrad_halo_ws', 'mscl_debug_halo_launches', 'mscl_debug_stem_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
+_INT64_RESULT = ('mscl_debug_wgrad_group_launches', 'mscl_wgrad_halo_ws', 'mscl_debug_halo_launches', 'mscl_debug_stem_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
 EXPORTS = tuple(_SIGS)
 
 _lib = None
@@ -187,6 +190,7 @@ def tune(**switches):
     DET_GEN += 1              # scratch sizes depend on the switches too (MSCL_WGRAD_HALO_*, MSCL_THIN): cached plans must not outlive them
 
 
+WGRAD_GROUP_MAX = 16     # = MSCL_WGRAD_GROUP_MAX (include/mscl_hip.h)
 DET_GEN = 0              # generation of everything a cached per-(module, shape) plan depends on: the deterministic flag AND the tuning
 # switches.  Bumped by set_deterministic() and tune(); code that flips either through lib.call() directly must bump it itself.
 DET = False              # mirror of the library's flag for the per-launch Python paths (scratch sizing)

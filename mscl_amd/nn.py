@@ -245,6 +245,82 @@ PAIR_STEM = True            # RGB stem on W-paired input (kernels.pair_w): K 117
 MASK_FROM_Y_MIN = 1 << 24   # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
 
 
+class WGradQueue:
+    """Deferred weight gradients of the small layers, launched as ONE grouped kernel (mscl_conv3d_wgrad_group, csrc/conv_wgrad.hip).
+
+    A weight gradient is a leaf of the backward chain.  On the small maps (layers 3-4, their entries and shortcuts, the pyramid
+    levels) it is a launch-latency-bound kernel -- 8-41 us at 6 % MFMA busy, ~30 of them and as many bias column sums per step,
+    most on the RGB query chain with the chip nearly idle -- and streams cannot hide it (every fork edge inside the captured step
+    costs more than it hides: profiles/r05_ab_sweeps.md).  So the launches are deferred instead: _wgrad() queues (conv, x, dy), which
+    keeps the operands alive, and the queue of a stream goes out on that stream as one grouped launch (+ one for the bias
+    gradients) when it is full, when a gradient bucket is about to be reduced, and -- through the autograd engine's
+    end-of-backward callback -- before .backward() returns.  One queue per stream: the flow trunk's backward runs on the flow stream."""
+
+    def __init__(self):
+        self.queues = {}            # raw stream handle -> (torch stream, [(conv, x, dy, desc)])
+        self.armed = False          # an end-of-backward callback is registered for the running backward pass
+
+    def add(self, conv, x, dy, d):
+        sp = lib.stream_ptr()
+        q = self.queues.get(sp)
+        if q is None:
+            q = self.queues[sp] = (torch.cuda.current_stream(), [])
+        q[1].append((conv, x, dy, d))
+        if not self.armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush_all)
+                self.armed = True
+            except RuntimeError:            # not inside a backward pass (a kernel-level caller): nothing would flush the queue later
+                self._flush(q[1])
+                return
+        if len(q[1]) >= lib.WGRAD_GROUP_MAX:
+            self._flush(q[1])
+
+    def flush(self):
+        """the current stream's queue, now (before a gradient bucket's all-reduce)"""
+        q = self.queues.get(lib.stream_ptr())
+        if q is not None and q[1]:
+            self._flush(q[1])
+
+    def flush_all(self):
+        """every stream's queue, each on its own stream (the end of a backward pass; the step's sync_streams joins the streams)"""
+        self.armed = False
+        for st, items in self.queues.values():
+            if items:
+                with torch.cuda.stream(st):
+                    self._flush(items)
+
+    @staticmethod
+    def _flush(items):
+        n = len(items)
+        descs = (lib.ConvDesc * n)()
+        xs, dys, dws, dbs = ((ctypes.c_void_p * n)() for _ in range(4))
+        gf = []
+        for i, (conv, x, dy, d) in enumerate(items):
+            ctypes.memmove(ctypes.byref(descs[i]), ctypes.byref(d), ctypes.sizeof(lib.ConvDesc))
+            rt = conv._rt
+            xs[i], dys[i], dws[i] = x.data_ptr(), dy.data_ptr(), rt['dw'].data_ptr()
+            dbs[i] = rt['dbias'].data_ptr() if rt['dbias'] is not None else None
+            rt['slot_w'].touched = True
+            if rt['slot_b'] is not None:
+                rt['slot_b'].touched = True
+            gf.append(2.0 * d.N * d.To * d.Ho * d.Wo * d.K * d.kT * d.kH * d.kW * d.C)
+        e0 = K.prof_begin()
+        lib.call('mscl_conv3d_wgrad_group', n, descs, xs, dys, dws, dbs, lib.stream_ptr())
+        if e0 is not None:          # bench.py's stage table: the group's time split over its layers by their FLOPs
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            tot = sum(gf)
+            for (conv, x, dy, d), f in zip(items, gf):
+                K.PROFILE['events'].append(('wgrad', tuple(getattr(d, k) for k in K._DESC_FIELDS), e0, e1, f / tot))
+        del items[:]                # (drops the references that kept x / dy alive)
+
+
+WGRADS = WGradQueue()
+GROUP_MAX_ROWS = 16384              # output positions up to which a layer's weight gradient is deferred into a grouped launch
+GROUP_WGRADS = [True]               # False: every weight gradient is launched where it arises (A/B, tools/ab_step.py)
+
+
 def _wgrad(conv, x, dy):
     """(Round 4 measured the narrowest form of all: only the 10-us slab sums of the window-resident weight gradients -- a leaf of
     the chain, HBM-bound -- launched on the idle key stream behind an event, with persistent per-layer workspaces and the join
@@ -261,7 +337,18 @@ def _wgrad(conv, x, dy):
     clip-pairs/s (two captured graphs replayed alternately in one process, tools/ab_step.py).  Not the kernels but the fork costs:
     every cross-stream edge inside the captured step is a barrier packet and a signal between hardware queues, ~30 of them per step
     here, and each delays the chain it leaves.  Concurrency for small launches has to come from ONE launch (a grouped kernel), not
-    from more streams.)"""
+    from more streams: WGradQueue.)"""
+    if GROUP_WGRADS[0]:
+        key = ('wg', tuple(x.shape), lib.DET_GEN)
+        ok = conv._plans.get(key)
+        d = conv.desc(x.shape)
+        if ok is None:
+            # small maps only: a large map's weight gradient fills the chip by itself, and deferring it would keep its dy alive
+            ok = conv._plans[key] = (d.N * d.To * d.Ho * d.Wo <= GROUP_MAX_ROWS and conv._rt.get('dw8_flush') is None
+                                     and bool(lib.call_raw('mscl_conv3d_wgrad_groupable', ctypes.byref(d))))
+        if ok:
+            WGRADS.add(conv, x, dy, d)
+            return
     conv.wgrad(x, dy)
 
 
@@ -270,9 +357,11 @@ HOLD_BUCKETS = [False]          # True while a branch's backward is being captur
 
 def _bucket_done(mod):
     """data-parallel hook: this module's backward completes a gradient bucket -> start its all-reduce now"""
+    buckets = getattr(mod, '_grad_buckets', ())
+    if buckets and (HOLD_BUCKETS[0] or not parallel.single()):
+        WGRADS.flush()          # the bucket's deferred weight gradients go out before its all-reduce (and inside a sub-graph capture)
     if HOLD_BUCKETS[0]:
         return                  # nothing executes during capture; the replaying node fires the trigger itself
-    buckets = getattr(mod, '_grad_buckets', ())
     for red, i in buckets:
         red.bucket_done(i)
 
@@ -297,6 +386,8 @@ class BucketCounter:
     def bwd(self):
         self.pending -= 1
         if self.pending == 0 and not HOLD_BUCKETS[0]:
+            if not parallel.single():
+                WGRADS.flush()
             self.red.bucket_done(self.idx)
 
 
@@ -709,7 +800,7 @@ class _ConvBiasFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, out = ctx.saved_tensors
         dz = K.relu_bwd(dout.contiguous(), out) if ctx.relu else dout.contiguous()
-        ctx.conv.wgrad(x, dz)
+        _wgrad(ctx.conv, x, dz)
         if ctx.counted:
             ctx.conv._bucket_counter.bwd()           # data-parallel: the last application of the bucket starts its all-reduce
         dx = ctx.conv.dgrad(dz, x.shape) if ctx.needs_input_grad[0] else None

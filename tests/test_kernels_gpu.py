@@ -1028,3 +1028,62 @@ def _virt_vs_real(K_, dev, dim, Kq, R, n):
         dq_r = K_.nce_backward(queue, count, q, lse_r, scale, 1 / 0.07)
         assert torch.equal(lse_v, lse_r) and torch.equal(loss_v, loss_r) and torch.equal(rank_v, rank_r)
         assert torch.equal(dq_v, dq_r)
+
+
+def test_conv_wgrad_group(dev):
+    """mscl_conv3d_wgrad_group (round 5): the weight and bias gradients of several small layers in one launch each -- 3x3x3, 1x3x3,
+    1x1x1 and strided layers of different maps, one module applied to two maps (shared dw: atomics), accumulation into non-zero
+    buffers -- against CPU fp32 autograd and against the per-layer entry point; window-resident / big-tile shapes are refused."""
+    import ctypes
+    from mscl_amd import kernels as K_, lib
+    specs = [  # N,T,H,W, C, K, kernel, stride, pad, shares dw with
+        (2, 2, 7, 7, 512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), None),
+        (2, 4, 14, 14, 256, 512, (3, 3, 3), (2, 2, 2), (1, 1, 1), None),
+        (2, 4, 14, 14, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), None),
+        (2, 2, 7, 7, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2),        # the same module on a second pyramid level
+        (2, 4, 14, 14, 256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), None),
+        (2, 4, 14, 14, 128, 256, (1, 1, 1), (2, 2, 2), (0, 0, 0), None),
+        (1, 2, 7, 7, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), None),
+    ]
+    n = len(specs)
+    descs = (lib.ConvDesc * n)()
+    xs, dys, dws, dbs, refs, keep = [], [], [], [], [], []
+    for i, (N, T, H, W, C, Kc, kern, st, pad, share) in enumerate(specs):
+        x = bf(rnd((N, T, H, W, C), 100 + i)); w = rnd((Kc, *kern, C), 200 + i).requires_grad_(True)
+        d = K_.conv_desc(x.shape, Kc, kern, st, pad)
+        assert lib.call_raw('mscl_conv3d_wgrad_groupable', ctypes.byref(d)) == 1, specs[i]
+        y = _conv_ref(x.float(), w, st, pad)
+        dy = bf(rnd(tuple(y.shape), 300 + i))
+        y.backward(dy.float())
+        ctypes.memmove(ctypes.byref(descs[i]), ctypes.byref(d), ctypes.sizeof(lib.ConvDesc))
+        xs.append(x.to(dev)); dys.append(dy.to(dev))
+        if share is None:
+            dws.append(torch.full((Kc, *kern, C), 0.5, device=dev)); dbs.append(torch.full((Kc,), -1.0, device=dev))
+            refs.append([w.grad.clone(), dy.float().sum(dim=(0, 1, 2, 3))])
+        else:
+            dws.append(dws[share]); dbs.append(dbs[share])
+            refs[share][0] += w.grad; refs[share][1] += dy.float().sum(dim=(0, 1, 2, 3))
+            refs.append(None)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    n0 = lib.call_raw('mscl_debug_wgrad_group_launches')
+    lib.call('mscl_conv3d_wgrad_group', n, descs, arr(xs), arr(dys), arr(dws), arr(dbs), lib.stream_ptr())
+    assert lib.call_raw('mscl_debug_wgrad_group_launches') == n0 + 1
+    for i, r in enumerate(refs):
+        if r is not None:
+            close(dws[i] - 0.5, r[0], F32_TOL, f'grouped wgrad {i}')
+            close(dbs[i] + 1.0, r[1], F32_TOL, f'grouped dbias {i}')
+    # the per-layer entry point on the same operands (fp32 sums in another order)
+    for i, (N, T, H, W, C, Kc, kern, st, pad, share) in enumerate(specs):
+        if share is None and i != 2:
+            dw1 = torch.zeros((Kc, *kern, C), device=dev)
+            K_.conv3d_wgrad(xs[i], dys[i], K_.conv_desc(xs[i].shape, Kc, kern, st, pad), dw1)
+            close(dws[i] - 0.5, dw1, F32_TOL, f'grouped vs single {i}')
+    # shapes the window-resident kernels / the 128 x 128 tile take are not groupable, and the call refuses them
+    for shp in [((8, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)), ((8, 8, 28, 28, 128), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+                ((8, 16, 56, 56, 64), 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)), ((2, 4, 14, 14, 16), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))]:
+        d = K_.conv_desc(*shp)
+        assert lib.call_raw('mscl_conv3d_wgrad_groupable', ctypes.byref(d)) == 0, shp
+    d1 = (lib.ConvDesc * 1)()
+    ctypes.memmove(ctypes.byref(d1[0]), ctypes.byref(K_.conv_desc((8, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1))), ctypes.sizeof(lib.ConvDesc))
+    one = (ctypes.c_void_p * 1)(xs[0].data_ptr())
+    assert lib.call_raw('mscl_conv3d_wgrad_group', 1, d1, one, one, one, None, lib.stream_ptr()) == -2
