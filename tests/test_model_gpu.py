@@ -1381,3 +1381,58 @@ def test_training_learns(dev):
     assert last['loss_pos'] < 0.1 * first['loss_pos'], (first['loss_pos'], last['loss_pos'])
     assert last['loss'] < first['loss'] - 5.0, (first['loss'], last['loss'])
     assert float(opt.grad_norm()) < 40.0
+
+
+def test_grouped_weight_gradients_equal_per_layer_launches(dev):
+    """(round 5) nn.WGradQueue defers the weight / bias gradients of the small maps and launches them grouped
+    (mscl_conv3d_wgrad_group; the arithmetic itself is checked per layer in test_kernels_gpu.py::test_conv_wgrad_group).  At the
+    model level the gradient arena after one step's backward must sit as close to the per-layer launches' as those sit to one
+    another (float atomics reorder between runs and the batch-2 BatchNorm amplifies that -- the yardstick of
+    test_graphed_step_matches_eager), the grouped launch must have run, and nothing may be left queued when backward() returns."""
+    from mscl_amd import lib, nn as nn_hip
+    from mscl_amd.synthetic import synthetic_batch
+    B, T, H, Kq = 2, 8, 64, 64
+    batch = synthetic_batch(B, T, H, H, 0, 3, device=dev)
+    grads = []
+    for on in (False, False, False, True):
+        nn_hip.GROUP_WGRADS[0] = on
+        try:
+            model, cfg = build(T, Kq, dev)
+            n0 = lib.call_raw('mscl_debug_wgrad_group_launches')
+            out = model.train_step(batch, sync_logs=False)
+            model.zero_grad()
+            out['loss'].backward()
+            assert all(not q[1] for q in nn_hip.WGRADS.queues.values()) and not nn_hip.WGRADS.armed
+            model.sync_streams(); torch.cuda.synchronize()
+            launched = lib.call_raw('mscl_debug_wgrad_group_launches') - n0
+            assert (launched >= 2) if on else (launched == 0), launched     # RGB chain (two groups: > 16 layers) + flow chain
+            grads.append(model.arena.G.clone())
+        finally:
+            nn_hip.GROUP_WGRADS[0] = True
+    a0, a1, a2, g = grads
+    assert torch.isfinite(g).all()
+    dist = lambda x, y: float((x - y).norm() / a0.norm())
+    noise = max(dist(a0, a1), dist(a0, a2), dist(a1, a2))
+    rel = min(dist(g, a0), dist(g, a1), dist(g, a2))
+    assert rel <= 3.0 * noise + 1e-3, (rel, noise)
+
+
+def test_split2_backward_hands_back_one_tensor(dev):
+    """recognizers._Split2Fn: halves of one tensor whose gradients come back as neighbours in one buffer are returned as ONE view (no
+    zero-fill + add launches); gradients that are not neighbours, or a missing one, fall back to a concatenation"""
+    from mscl_amd.recognizers import _Split2Fn
+    x = torch.randn(6, 5, device=dev, requires_grad=True)
+    a, b = _Split2Fn.apply(x, 2)
+    assert torch.equal(a, x[:2]) and torch.equal(b, x[2:])
+    flat = torch.arange(30, dtype=torch.float32, device=dev)
+    torch.autograd.backward([a, b], [flat[:10].view(2, 5), flat[10:].view(4, 5)])
+    assert torch.equal(x.grad, flat.view(6, 5)) and x.grad.data_ptr() == flat.data_ptr()
+    x.grad = None
+    a, b = _Split2Fn.apply(x, 2)
+    ga, gb = torch.ones(2, 5, device=dev), torch.full((4, 5), 2.0, device=dev)
+    torch.autograd.backward([a, b], [ga, gb])
+    assert torch.equal(x.grad, torch.cat([ga, gb]))
+    x.grad = None
+    a, b = _Split2Fn.apply(x, 2)
+    a.sum().backward()
+    assert torch.equal(x.grad, torch.cat([torch.ones(2, 5, device=dev), torch.zeros(4, 5, device=dev)]))
