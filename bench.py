@@ -354,7 +354,7 @@ def main():
         ach2 = flops2 / (avg2 * 1e-3) / 1e12 if ms2 else 0.0
         traffic = None
         tname = None
-        for tname in ('r04_traffic_layer1.json', 'r03_traffic_layer1.json', 'r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
+        for tname in ('r05_traffic_layer1.json', 'r04_traffic_layer1.json', 'r03_traffic_layer1.json', 'r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
             tp = os.path.join(ROOT, 'profiles', tname)
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
@@ -377,7 +377,7 @@ def main():
                        'aug': 'stochastic flip+jitter+grayscale+blur (variant)' if args.stochastic_aug
                               else 'normalise only (BASELINE.json workload)'},
             'final_loss': loss,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64b_kernel<8,2,2> fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_halo64b_kernel fwd (+BN statistics), 3x3x3 64->64 on (8,16,56,56,64)',
                          'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS,
                          'launches_timed': len(ms), 'avg_launch_ms': avg_ms, 'traffic': traffic,
                          'traffic_unit': f'HBM bytes per launch (rocprofv3 PMC, profiles/{tname})',
