@@ -24,12 +24,14 @@ def main():
     step = rows[beg + 1:end + 1]
     t0 = step[0][0]
     print(f'step span {(step[-1][1] - t0) / 1e3:.1f} us, {len(step)} kernels')
-    # loss phase: from the first nce / rowdot / l2norm kernel to the last nce_bwd / lmcl / linear_bwd kernel
-    keys = ('nce_', 'rowdot', 'l2norm', 'lmcl', 'linear_', 'loss_pack', 'loss_unpack', 'enqueue', 'step_logs', 'pool_')
-    idx = [i for i, r in enumerate(step) if r[2].startswith(keys)]
-    a, b = idx[0], idx[-1]
+    # loss phase: from the loss_pack launch to the loss_unpack launch (the tracer serialises the streams of the captured step, so the
+    # offsets are those of the serialised order; the durations are the kernels' own)
+    keys = ('nce_', 'rowdot', 'lmcl', 'loss_pack', 'loss_unpack', 'enqueue', 'step_logs', 'linear_')
+    a = max(i for i, r in enumerate(step) if r[2].startswith('loss_pack'))
+    b = max(i for i, r in enumerate(step) if r[2].startswith('loss_unpack'))
     lo = step[a][0]
-    print(f'loss-phase kernels span {(step[b][1] - lo) / 1e3:.1f} us (from {(lo - t0) / 1e3:.1f} us into the step)')
+    print(f'loss-phase kernels span {(step[b][1] - lo) / 1e3:.1f} us (from {(lo - t0) / 1e3:.1f} us into the step); '
+          f'sum of their durations {sum(e - s for s, e, n, q in step[a:b + 1]) / 1e3:.1f} us over {b + 1 - a} launches')
     for s, e, n, q in step[a:b + 1]:
         mark = '*' if n.startswith(keys) else ' '
         print(f'{mark} q{q:>3} +{(s - lo) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  {n}')
