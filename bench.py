@@ -30,8 +30,9 @@ T_FRAMES, SIDE, BATCH = 16, 112, 8
 #   reference step (section 8d): 3302 = (RGB trunk 651.14 + neck 145.28 + flow trunk 2 x 14.51) x (3 on the query side + 1 on the
 #   key side).  What this build EXECUTES is less: no stem input gradients (22.66 + 2 x 0.94), the key branch's pyramid is
 #   skipped (145.28: k_mlvl has no reader), and levels 1-2 of the last PConv3D are not computed (13.18 forward; they never had
-#   a backward: their gradient is None in the reference too).  step_frac prices the executed work only.
-_TRUNK, _NECK, _NECK_DEAD, _FLOW, _STEM_DG, _FSTEM_DG = 651.14, 145.28, 13.18, 14.51, 22.659, 0.944
+#   a backward: their gradient is None in the reference too), nor, since round 5, level 2 of the first PConv3D, which only those
+#   fed (1.39 forward: P1 on the 7 x 7 level + the strided P2 into it).  step_frac prices the executed work only.
+_TRUNK, _NECK, _NECK_DEAD, _FLOW, _STEM_DG, _FSTEM_DG = 651.14, 145.28, 13.18 + 1.387, 14.51, 22.659, 0.944
 STEP_GFLOP_REFERENCE = 4 * (_TRUNK + _NECK + 2 * _FLOW)
 STEP_GFLOP_EXECUTED = (3 * _TRUNK - _STEM_DG) + 3 * (_NECK - _NECK_DEAD) + 2 * (3 * _FLOW - _FSTEM_DG) + 2 * _FLOW + _TRUNK
 

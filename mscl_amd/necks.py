@@ -40,16 +40,16 @@ class FPNHip(nn.Module):
         self.lateral_convs = nn.ModuleList(_ConvModule(c, out_channels, 1, 0) for c in in_channels)
         self.fpn_convs = nn.ModuleList(_ConvModule(out_channels, out_channels, kernel, pad) for _ in in_channels)
 
-    def forward(self, feats):
+    def forward(self, feats, levels=None):
         """top-down: lat[i-1] += nearest_up(lat[i]) (fpn.py:193-203); the add rides the lateral conv's
-        epilogue instead of a separate pass."""
+        epilogue instead of a separate pass.  `levels`: the outputs somebody reads (None = all); the others are None."""
         n = len(feats)
         lat = [None] * n
         lat[n - 1] = conv_bias(self.lateral_convs[n - 1].conv, feats[n - 1])
         for i in range(n - 2, -1, -1):
             up = upsample(lat[i + 1], feats[i].shape[1:4], trilinear=False)
             lat[i] = conv_bias(self.lateral_convs[i].conv, feats[i], addend=up)
-        return [conv_bias(self.fpn_convs[i].conv, lat[i]) for i in range(n)]
+        return [conv_bias(self.fpn_convs[i].conv, lat[i]) if levels is None or i in levels else None for i in range(n)]
 
 
 class PConv3DHip(nn.Module):
@@ -95,9 +95,24 @@ class SEPCHip(nn.Module):
         earlier one feeds its successor (sepc.py:118-135).  The skipped outputs are the ones that receive no gradient in the
         reference (`Pconvs.1.Pconv.2` has grad None), so parameter gradients are unchanged."""
         assert len(xs) == len(self.in_channels)
+        wanted = self.wanted(levels)
         for i, p in enumerate(self.Pconvs):
-            xs = p(xs, levels=levels if i == len(self.Pconvs) - 1 else None)
+            xs = p(xs, levels=wanted[i + 1])
         return xs
+
+    def wanted(self, levels):
+        """[the input levels read, the levels PConv3D 0 has to produce, ..., the levels the last one has to produce] (None = all)"""
+        L, n = len(self.in_channels), len(self.Pconvs)
+        # what each PConv3D has to produce: the last one the caller's levels; an earlier one every level its successor READS -- output
+        # l of a PConv3D reads inputs l (P1), l + 1 (P0) and l - 1 (P2).  (Round 5: the first of the two used to compute all three
+        # levels although the second, asked for level 0 alone, reads levels 0 and 1: two convs per step whose result nothing read
+        # and whose backward never ran.)
+        wanted = [None] * (n + 1)
+        wanted[n] = None if levels is None else tuple(sorted(levels))
+        for i in range(n - 1, -1, -1):
+            nxt = wanted[i + 1]
+            wanted[i] = None if nxt is None else tuple(sorted({m for l in nxt for m in (l - 1, l, l + 1) if 0 <= m < L}))
+        return wanted
 
 
 class TPNSingleHip(nn.Module):
@@ -121,10 +136,10 @@ class TPNSingleHip(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, feats, levels=None):
-        outs = self.fpn(list(feats[-self.num_tpn_stages:]))
+        feats = list(feats[-self.num_tpn_stages:])
         if self.sepc is not None:
-            return self.sepc(outs, levels=levels)
-        return outs if levels is None else [o if i in levels else None for i, o in enumerate(outs)]
+            return self.sepc(self.fpn(feats, levels=self.sepc.wanted(levels)[0]), levels=levels)
+        return self.fpn(feats, levels=levels)
 
 
 @NECKS.register_module()

@@ -245,6 +245,33 @@ PAIR_STEM = True            # RGB stem on W-paired input (kernels.pair_w): K 117
 MASK_FROM_Y_MIN = 1 << 24   # BN backward recomputes the ReLU mask from y on maps this large (72 vs 78 us on layer 1; smaller maps lose)
 
 
+class _BackwardEnd:
+    """Hooks that run once when the running backward pass ends (the deferred weight gradients), through the autograd engine's
+    callback queue.  A hook that raises does not keep the others from running -- the first error is raised after the last.
+    The engine callback is queued on every add (it is per pass and dropped with a pass that dies; a flag kept here would go stale
+    and the next pass's hooks would never run): the first one to fire runs the hooks, the rest find none."""
+    hooks = []
+
+    @staticmethod
+    def add(fn):
+        """RuntimeError when no backward pass is running (the engine refuses the callback)"""
+        torch.autograd.Variable._execution_engine.queue_callback(_BackwardEnd.run)
+        if fn not in _BackwardEnd.hooks:
+            _BackwardEnd.hooks.append(fn)
+
+    @staticmethod
+    def run():
+        hooks, err = list(_BackwardEnd.hooks), None
+        del _BackwardEnd.hooks[:]
+        for fn in hooks:
+            try:
+                fn()
+            except Exception as e:          # noqa: BLE001 -- re-raised below
+                err = err or e
+        if err is not None:
+            raise err
+
+
 class WGradQueue:
     """Deferred weight gradients of the small layers, launched as ONE grouped kernel (mscl_conv3d_wgrad_group, csrc/conv_wgrad.hip).
 
@@ -258,7 +285,6 @@ class WGradQueue:
 
     def __init__(self):
         self.queues = {}            # raw stream handle -> (torch stream, [(conv, x, dy, desc)])
-        self.armed = False          # an end-of-backward callback is registered for the running backward pass
 
     def add(self, conv, x, dy, d):
         sp = lib.stream_ptr()
@@ -266,13 +292,11 @@ class WGradQueue:
         if q is None:
             q = self.queues[sp] = (torch.cuda.current_stream(), [])
         q[1].append((conv, x, dy, d))
-        if not self.armed:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(self.flush_all)
-                self.armed = True
-            except RuntimeError:            # not inside a backward pass (a kernel-level caller): nothing would flush the queue later
-                self._flush(q[1])
-                return
+        try:
+            _BackwardEnd.add(self.flush_all)
+        except RuntimeError:                # not inside a backward pass (a kernel-level caller): nothing would flush the queue later
+            self._flush(q[1])
+            return
         if len(q[1]) >= lib.WGRAD_GROUP_MAX:
             self._flush(q[1])
 
@@ -284,7 +308,6 @@ class WGradQueue:
 
     def flush_all(self):
         """every stream's queue, each on its own stream (the end of a backward pass; the step's sync_streams joins the streams)"""
-        self.armed = False
         for st, items in self.queues.values():
             if items:
                 with torch.cuda.stream(st):

@@ -1402,7 +1402,7 @@ def test_grouped_weight_gradients_equal_per_layer_launches(dev):
             out = model.train_step(batch, sync_logs=False)
             model.zero_grad()
             out['loss'].backward()
-            assert all(not q[1] for q in nn_hip.WGRADS.queues.values()) and not nn_hip.WGRADS.armed
+            assert all(not q[1] for q in nn_hip.WGRADS.queues.values()) and not nn_hip._BackwardEnd.hooks
             model.sync_streams(); torch.cuda.synchronize()
             launched = lib.call_raw('mscl_debug_wgrad_group_launches') - n0
             assert (launched >= 2) if on else (launched == 0), launched     # RGB chain (two groups: > 16 layers) + flow chain
@@ -1436,3 +1436,4 @@ def test_split2_backward_hands_back_one_tensor(dev):
     a, b = _Split2Fn.apply(x, 2)
     a.sum().backward()
     assert torch.equal(x.grad, torch.cat([torch.ones(2, 5, device=dev), torch.zeros(4, 5, device=dev)]))
+
