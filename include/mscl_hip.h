@@ -325,9 +325,13 @@ int mscl_l2norm_bwd(const float* y, const float* norms, const float* dy, float* 
  * the plain forms. */
 int mscl_nce_fwd_virt(const float* queue, const int64_t* count, const float* q, const float* pos_logit, float* part,
                       int R, int dim, int K, float inv_T, const float* new_keys, int n_new, const int64_t* queue_ptr, void* stream);
+/* mscl_nce_bwd_virt, kpos / pos_logit (both or neither; NULL in the plain form): the positive pair's term
+ * dq[r] += row_scale[r] * inv_T * (softmax_pos[r] - 1) * kpos[r] is added in the same launch that sums the per-block partial
+ * sums (the arithmetic of mscl_nce_pos_bwd; one launch less per pass on the step's serial loss phase). */
 int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
                       float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T,
-                      const float* new_keys, int n_new, const int64_t* queue_ptr, void* stream);
+                      const float* new_keys, int n_new, const int64_t* queue_ptr, const float* kpos, const float* pos_logit,
+                      void* stream);
 int mscl_nce_fwd(const float* queue, const int64_t* count, const float* q, const float* pos_logit,
                  float* part, int R, int dim, int K, float inv_T, void* stream);
 int mscl_nce_finish(const float* part, const float* pos_logit, float* lse, float* loss_rows, int32_t* rank,
@@ -354,14 +358,18 @@ int mscl_nce_pos_bwd(const float* kpos, const float* pos, const float* lse, cons
  * query / key rows of the RGB-queue pass (A) and the post-enqueue flow-queue pass (C), their row scales and the LMCL flow frames
  * into one workspace  QA[n B D] KA[n B D] QC[n B D] KC[n B D] sA[n B] sC[n B] ones[B] flow[B 2t Cf]  (n = 3 with use_aug, else 2);
  * unpack: out = dq_rgb[B D] dq_fb[B D] dq_fa[B D] dp_rgb[B t C] dp_fb[B t Cf] dp_fa[B t Cf] from the passes' query gradients. */
+/* pos (NULL: not wanted): the positive logits <query row, key row> of every row of the three passes, [n B] of pass A, [B] of the
+ * pre-enqueue flow-queue pass B (q_fb . k_fb), [n B] of pass C -- the arithmetic of mscl_rowdot, in the pack launch. */
 int mscl_loss_pack(const float* q_rgb, const float* q_fb, const float* q_fa, const float* k_rgb, const float* k_fb,
-                   const float* k_fa, const float* p_fb, const float* p_fa, float* ws, int B, int D, int t, int Cf,
+                   const float* k_fa, const float* p_fb, const float* p_fa, float* ws, float* pos, int B, int D, int t, int Cf,
                    int use_aug, float w_intra, void* stream);
 int mscl_loss_unpack(const float* dA, const float* dB, const float* dC, const float* dpr, const float* dpf, float* out,
                      int B, int D, int t, int C, int Cf, int use_aug, void* stream);
 
 /* queue bookkeeping, bit-exact int64: count += 1; queue[:, ptr:ptr+n] = keys^T; count[ptr:ptr+n] = 1;
- * ptr = (ptr+n) % K.   recognizers/moco.py:423-440.  keys: (n, dim) fp32, ptr: int64[1] on device. */
+ * ptr = (ptr+n) % K.   recognizers/moco.py:423-440.  keys: (n, dim) fp32, ptr: int64[1] on device.
+ * One launch (the block that finishes last moves the pointer, through a library-owned ticket): calls on DIFFERENT streams must
+ * not overlap in time -- the step orders its enqueues on one stream, as the reference orders them. */
 int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, const float* keys, int n, int dim, int K, void* stream);
 
 /* ---- LMCL (heads/local_cl_head.py:57-73,41-55) ------------------------------------------------

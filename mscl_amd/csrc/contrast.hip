@@ -296,13 +296,23 @@ __global__ __launch_bounds__(256, 2) void nce_bwd_kernel(const float* __restrict
       if (cg + 32 * u < dim) o[(rg * RG + r) * dim + cg + 32 * u] = a2[r][u];
 }
 
-// dq[r][c] += sum over blocks of slab[b][r][c]  (rows r < R); blockIdx.y takes every gridDim.y-th slab
+// dq[r][c] += sum over blocks of slab[b][r][c]  (rows r < R); blockIdx.y takes every gridDim.y-th slab.
+// kpos != NULL: the positive pair's term rides along (one launch less per pass on the step's serial loss phase) --
+// dq[r][:] += row_scale[r] * inv_T * (softmax_pos[r] - 1) * kpos[r][:], added by the blocks of slab column 0 as one more addend
+// BEHIND the slab sum: the arithmetic of nce_pos_bwd_kernel, and in deterministic mode still one add per element.
 __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dq, int nslab,
-                                                             int RT, int R, int dim) {
+                                                             int RT, int R, int dim, const float* __restrict__ kpos,
+                                                             const float* __restrict__ pos, const float* __restrict__ lse,
+                                                             const float* __restrict__ row_scale, float inv_T) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= R * dim) return;
   const int step = gridDim.y;
   int b = blockIdx.y;
+  float pterm = 0.f;
+  if (kpos != nullptr && b == 0) {
+    const int r = e / dim;
+    pterm = row_scale[r] * inv_T * (__expf(pos[r] * inv_T - lse[r]) - 1.f) * kpos[e];
+  }
   if (step == 1) {            // deterministic mode: ONE add per element of a sum taken in slab order, 16 loads in flight per trip
     float s = 0.f;
     for (; b + 16 <= nslab; b += 16) {
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __rest
       for (int u = 0; u < 16; ++u) s += v[u];
     }
     for (; b < nslab; ++b) s += slab[(long)b * RT * dim + e];
-    atomicAdd(&dq[e], s);
+    atomicAdd(&dq[e], s + pterm);
     return;
   }
   float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __rest
     for (int u = 0; u < 4; ++u) s4[u] += slab[(long)(b + u * step) * RT * dim + e];
   }
   for (; b < nslab; b += step) s4[0] += slab[(long)b * RT * dim + e];
-  atomicAdd(&dq[e], (s4[0] + s4[1]) + (s4[2] + s4[3]));
+  atomicAdd(&dq[e], ((s4[0] + s4[1]) + (s4[2] + s4[3])) + pterm);
 }
 
 #define NCE_DISPATCH(RV, CALL8, CALL16, CALL24, CALL32) \
@@ -381,12 +391,14 @@ extern "C" int mscl_nce_finish(const float* part, const float* pos_logit, float*
 }
 extern "C" int mscl_nce_bwd(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
                             float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T, void* stream) {
-  return mscl_nce_bwd_virt(queue, count, q, lse, row_scale, dq, ws, ws_floats, R, dim, K, inv_T, nullptr, 0, nullptr, stream);
+  return mscl_nce_bwd_virt(queue, count, q, lse, row_scale, dq, ws, ws_floats, R, dim, K, inv_T, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const float* q, const float* lse, const float* row_scale,
                                  float* dq, float* ws, int64_t ws_floats, int R, int dim, int K, float inv_T,
-                                 const float* new_keys, int n_new, const int64_t* queue_ptr, void* stream) {
+                                 const float* new_keys, int n_new, const int64_t* queue_ptr, const float* kpos, const float* pos_logit,
+                                 void* stream) {
   if (!queue || !count || !q || !lse || !row_scale || !dq || !ws || R <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
+  if ((kpos == nullptr) != (pos_logit == nullptr)) return MSCL_E_ARG;
   if (new_keys && (!queue_ptr || n_new <= 0 || n_new > K)) return MSCL_E_ARG;
   const NceVirt vt{new_keys, queue_ptr, new_keys ? n_new : 0};
   if (dim > 128 || dim % NCE_WAVES || K % 2) return MSCL_E_SHAPE;
@@ -415,7 +427,8 @@ extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const
     MSCL_LAUNCH_CHECK();
     // (deterministic mode: one block column, so every element receives ONE add of a sum taken in slab order)
     hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, mscl_det() ? 1 : 32), dim3(256), 0, st, (const float*)ws,
-                       dq + (size_t)r0 * dim, nblk, rt, Rt, dim);
+                       dq + (size_t)r0 * dim, nblk, rt, Rt, dim, kpos ? kpos + (size_t)r0 * dim : nullptr, kpos ? pos_logit + r0 : nullptr, lt, st_,
+                       inv_T);
     MSCL_LAUNCH_CHECK();
   }
   return 0;
@@ -477,10 +490,14 @@ extern "C" int mscl_step_logs(const int32_t* rankA, const float* lossA, const in
 }
 
 // ---------------------------------------------------------------- queue bookkeeping (int64, bit-exact)
+// One launch: every block reads the pointer before it counts itself done, so the block that counts LAST may move it (the second,
+// one-thread launch that did this sat on the step's serial loss phase twice).  Library-owned ticket: two enqueues must not run side
+// by side (they are ordered on one stream in the step, as the reference orders them).
+__device__ unsigned g_enq_ticket;
 __global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue, int64_t* __restrict__ count,
-                                                      const int64_t* __restrict__ ptr, const float* __restrict__ keys, int n,
+                                                      int64_t* __restrict__ ptr, const float* __restrict__ keys, int n,
                                                       int dim, int K) {
-  const int64_t p = *ptr;
+  const int64_t p = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const long total = (long)K + (long)n * dim;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     if (e < K) {
@@ -490,16 +507,20 @@ __global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue,
       queue[(long)c * K + p + j] = keys[(long)j * dim + c];
     }
   }
+  __syncthreads();                               // (every thread of the block has used p)
+  if (threadIdx.x == 0) {
+    if (atomicAdd(&g_enq_ticket, 1u) == gridDim.x - 1) {
+      __hip_atomic_store(ptr, (p + n) % K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g_enq_ticket = 0;                          // ready for the next launch (stream order)
+    }
+  }
 }
-__global__ void enqueue_advance_kernel(int64_t* ptr, int n, int K) { *ptr = (*ptr + n) % K; }
 extern "C" int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, const float* keys, int n, int dim, int K, void* stream) {
   if (!queue || !count || !ptr || !keys || n <= 0 || dim <= 0 || K <= 0) return MSCL_E_ARG;
   if (K % n) return MSCL_E_SHAPE;                 // recognizers/moco.py:432 `assert self.K % batch_size == 0`
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)K + (long)n * dim;
   hipLaunchKernelGGL(enqueue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, queue, count, ptr, keys, n, dim, K);
-  MSCL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(enqueue_advance_kernel, dim3(1), dim3(1), 0, st, ptr, n, K);
   MSCL_LAUNCH_CHECK();
   return 0;
 }
@@ -662,6 +683,7 @@ extern "C" int mscl_nce_pos_bwd(const float* kpos, const float* pos, const float
 struct LossPackArgs {
   const float *q_rgb, *q_fb, *q_fa, *k_rgb, *k_fb, *k_fa, *p_fb, *p_fa;
   float* ws;
+  float* pos;                // [(2 n + 1) B] positive logits of the passes' rows, A | B | C (NULL: not wanted)
   int B, D, t, Cf, n;        // n = 3 with the aug cross-modal terms, else 2
   float w_intra;
 };
@@ -686,12 +708,28 @@ __global__ __launch_bounds__(256) void loss_pack_kernel(const LossPackArgs a) {
     }
     a.ws[i] = v;
   }
+  // pos[r] = <query row, its key row> of every row of the three passes (l_pos = einsum('nc,nc->n'), recognizers/moco.py:481), from
+  // the inputs themselves -- a wave per row, the arithmetic of rowdot_kernel: three launches less on the serial loss phase
+  if (a.pos != nullptr) {
+    const int lane = threadIdx.x & 63, nw = gridDim.x * 4, rows = (2 * n + 1) * a.B;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+      const int grp = r / a.B, b = r - grp * a.B;
+      const float *qa, *ka;
+      if (grp < n) { qa = grp == 0 ? a.q_rgb : grp == 1 ? a.q_fb : a.q_fa; ka = a.k_rgb; }            // pass A
+      else if (grp == n) { qa = a.q_fb; ka = a.k_fb; }                                                  // pass B
+      else { const int gq = grp - n - 1; qa = gq == 0 ? a.q_fa : a.q_rgb; ka = gq == 1 ? a.k_fb : a.k_fa; }      // pass C
+      float sdot = 0.f;
+      for (int i = lane; i < a.D; i += 64) sdot += qa[(long)b * a.D + i] * ka[(long)b * a.D + i];
+      sdot = wave_sum(sdot);
+      if (lane == 0) a.pos[r] = sdot;
+    }
+  }
 }
 extern "C" int mscl_loss_pack(const float* q_rgb, const float* q_fb, const float* q_fa, const float* k_rgb, const float* k_fb,
-                              const float* k_fa, const float* p_fb, const float* p_fa, float* ws, int B, int D, int t, int Cf,
-                              int use_aug, float w_intra, void* stream) {
+                              const float* k_fa, const float* p_fb, const float* p_fa, float* ws, float* pos, int B, int D, int t,
+                              int Cf, int use_aug, float w_intra, void* stream) {
   if (!q_rgb || !q_fb || !q_fa || !k_rgb || !k_fb || !k_fa || !p_fb || !p_fa || !ws || B <= 0 || D <= 0 || t <= 0 || Cf <= 0) return MSCL_E_ARG;
-  LossPackArgs a{q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa, p_fb, p_fa, ws, B, D, t, Cf, use_aug ? 3 : 2, w_intra};
+  LossPackArgs a{q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa, p_fb, p_fa, ws, pos, B, D, t, Cf, use_aug ? 3 : 2, w_intra};
   hipLaunchKernelGGL(loss_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, a);
   MSCL_LAUNCH_CHECK();
   return 0;

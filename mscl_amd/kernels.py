@@ -456,15 +456,17 @@ def nce_forward(queue, count, q, pos, inv_T, virt=None):
     return lse, loss, rank
 
 
-def nce_backward(queue, count, q, lse, row_scale, inv_T, virt=None):
-    """dq (R, dim) = inv_T * row_scale[r] * sum_k softmax_k * W[:, k] (negatives only)."""
+def nce_backward(queue, count, q, lse, row_scale, inv_T, virt=None, pos_pair=None):
+    """dq (R, dim) = inv_T * row_scale[r] * sum_k softmax_k * W[:, k] (negatives only).
+    pos_pair = (kpos (R, dim), pos (R,)): the positive pair's term of nce_pos_bwd is added in the same launches."""
     R, dim = q.shape
     dq = ZEROS.take(R * dim, q.device).view(R, dim)          # (a slice of the step's pre-zeroed pool: no fill launch in the loss phase)
     Kq = queue.shape[1]
     ws = torch.empty(((Kq + 127) // 128) * ((min(R, 32) + 7) // 8 * 8) * dim, dtype=torch.float32, device=q.device)
     vk, vp = virt if virt is not None else (None, None)
+    kp, ps = pos_pair if pos_pair is not None else (None, None)
     call('mscl_nce_bwd_virt', ptr(queue), ptr(count), ptr(q), ptr(lse), ptr(row_scale), ptr(dq), ptr(ws), ws.numel(), R, dim, Kq,
-         inv_T, ptr(vk), vk.shape[0] if vk is not None else 0, ptr(vp), stream_ptr())
+         inv_T, ptr(vk), vk.shape[0] if vk is not None else 0, ptr(vp), ptr(kp), ptr(ps), stream_ptr())
     return dq
 
 
@@ -475,19 +477,21 @@ def rowdot(a, b):
 
 
 def loss_pack(q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa, p_fb, p_fa, t, use_aug, w_intra):
-    """one launch for the loss phase's row layout (mscl_loss_pack): returns views QA, KA, sA, QC, KC, sC, ones, flow of one buffer"""
+    """one launch for the loss phase's row layout (mscl_loss_pack): returns views QA, KA, sA, QC, KC, sC, ones, flow of one buffer,
+    that buffer, and the positive logits (posA, posB, posC) of the three passes' rows"""
     B, D = q_rgb.shape
     Cf = p_fb.shape[1]
     n = 3 if use_aug else 2
-    sizes = [n * B * D] * 4 + [n * B, n * B, B, B * 2 * t * Cf]
+    sizes = [n * B * D] * 4 + [n * B, n * B, B, B * 2 * t * Cf, n * B, B, n * B]
     ws = torch.empty((sum(sizes),), dtype=torch.float32, device=q_rgb.device)
     call('mscl_loss_pack', ptr(q_rgb), ptr(q_fb), ptr(q_fa), ptr(k_rgb), ptr(k_fb), ptr(k_fa), ptr(p_fb), ptr(p_fa), ptr(ws),
-         B, D, t, Cf, int(use_aug), float(w_intra), stream_ptr())
+         ptr(ws[sum(sizes[:8]):]), B, D, t, Cf, int(use_aug), float(w_intra), stream_ptr())
     parts, o = [], 0
     for sz in sizes:
         parts.append(ws[o:o + sz]); o += sz
-    QA, KA, QC, KC, sA, sC, ones, flow = parts
-    return (QA.view(n * B, D), KA.view(n * B, D), sA, QC.view(n * B, D), KC.view(n * B, D), sC, ones, flow.view(B, 2 * t, Cf), ws)
+    QA, KA, QC, KC, sA, sC, ones, flow, posA, posB, posC = parts
+    return (QA.view(n * B, D), KA.view(n * B, D), sA, QC.view(n * B, D), KC.view(n * B, D), sC, ones, flow.view(B, 2 * t, Cf), ws,
+            (posA, posB, posC))
 
 
 def loss_unpack(dA, dB, dC, dpr, dpf, B, D, t, C, Cf, use_aug):

@@ -82,13 +82,13 @@ _SIGS = {
     'mscl_l2norm_bwd': [P, P, P, P, c_int, c_int, P],
     'mscl_nce_fwd': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'mscl_nce_fwd_virt': [P, P, P, P, P, c_int, c_int, c_int, c_float, P, c_int, P, P],
-    'mscl_nce_bwd_virt': [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_float, P, c_int, P, P],
+    'mscl_nce_bwd_virt': [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_float, P, c_int, P, P, P, P],
     'mscl_nce_finish': [P, P, P, P, P, c_int, c_int, c_float, P],
     'mscl_step_logs': [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P],
     'mscl_nce_bwd': [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_float, P],
     'mscl_rowdot': [P, P, P, c_int, c_int, P],
     'mscl_nce_pos_bwd': [P, P, P, P, P, c_int, c_int, c_float, P],
-    'mscl_loss_pack': [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P],
+    'mscl_loss_pack': [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P],
     'mscl_loss_unpack': [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     'mscl_queue_enqueue': [P, P, P, P, c_int, c_int, c_int, P],
     'mscl_lmcl': [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P],

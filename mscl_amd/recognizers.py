@@ -324,8 +324,7 @@ class _MoCoLossFn(torch.autograd.Function):
         ones = torch.full((B,), 1.0 / B, device=q.device)
         pos = K.rowdot(q, k)
         lse, loss_rows, rank = K.nce_forward(rec.queue, rec.count, q, pos, inv_T)
-        dq = K.nce_backward(rec.queue, rec.count, q, lse, ones, inv_T)
-        K.nce_pos_bwd(k, pos, lse, ones, dq, inv_T)
+        dq = K.nce_backward(rec.queue, rec.count, q, lse, ones, inv_T, pos_pair=(k.contiguous(), pos))
         if update_queue:
             rec.dequeue_and_enqueue(k)
         ctx.save_for_backward(dq)
@@ -530,15 +529,16 @@ class _MSCLLossFn(torch.autograd.Function):
         t = p_rgb.shape[0] // B
         C, Cf = p_rgb.shape[1], p_fb.shape[1]
         # every row layout of this phase in ONE launch (was ~10 torch.cat / repeat / full kernels): kernels.loss_pack
-        QA, KA, sA, QC, KC, sC, ones, flow, pack_ws = K.loss_pack(q_rgb.contiguous(), q_fb.contiguous(), q_fa.contiguous(), k_rgb.contiguous(),
-                                                                 k_fb.contiguous(), k_fa.contiguous(), p_fb.contiguous(), p_fa.contiguous(),
-                                                                 t, use_aug_mx, w_intra)
+        # (round 5: the pack launch also takes the positive logits of every row, the pass that sums the per-block query gradients
+        # adds the positive pair's term, the enqueue moves its own pointer -- four launches per InfoNCE pass instead of six and one
+        # per enqueue instead of two on this serial stretch)
+        QA, KA, sA, QC, KC, sC, ones, flow, pack_ws, (posA, posB, posC) = K.loss_pack(
+            q_rgb.contiguous(), q_fb.contiguous(), q_fa.contiguous(), k_rgb.contiguous(), k_fb.contiguous(), k_fa.contiguous(),
+            p_fb.contiguous(), p_fa.contiguous(), t, use_aug_mx, w_intra)
 
-        def run(queue_owner, Q, Kp, scale, virt=None):
-            pos = K.rowdot(Q, Kp)
+        def run(queue_owner, Q, Kp, scale, pos, virt=None):
             lse, loss_rows, rank = K.nce_forward(queue_owner.queue, queue_owner.count, Q, pos, inv_T, virt)
-            dq = K.nce_backward(queue_owner.queue, queue_owner.count, Q, lse, scale, inv_T, virt)
-            K.nce_pos_bwd(Kp, pos, lse, scale, dq, inv_T)
+            dq = K.nce_backward(queue_owner.queue, queue_owner.count, Q, lse, scale, inv_T, virt, pos_pair=(Kp, pos))
             return loss_rows, rank, dq
 
         # pass A: RGB queue before this step's enqueue (moco.py:484-488 snapshot; fr logits moco_head_v2.py:44,47): query rows
@@ -550,7 +550,7 @@ class _MSCLLossFn(torch.autograd.Function):
             fork.wait_stream(main)
             pack_ws.record_stream(fork)
         with torch.cuda.stream(fork if fork is not None else main):
-            lossA, rankA, dA = run(rec, QA, KA, sA)
+            lossA, rankA, dA = run(rec, QA, KA, sA, posA)
         kg = model._kglobal
         # pass C reads the flow queue AFTER the base-flow enqueue (App. E-3): flow-aug intra loss, rf, rf_aug -- query rows
         # [q_fa | q_rgb | q_rgb] against keys [k_fa | k_fb | k_fa], the first group scaled by weight_aug_flow[0].  With loss_fork_c it
@@ -563,16 +563,16 @@ class _MSCLLossFn(torch.autograd.Function):
             for tns in (pack_ws, newk):
                 tns.record_stream(forkC)
             with torch.cuda.stream(forkC):
-                lossC, rankC, dC = run(recf, QC, KC, sC, virt=(newk.contiguous(), recf.queue_ptr))
+                lossC, rankC, dC = run(recf, QC, KC, sC, posC, virt=(newk.contiguous(), recf.queue_ptr))
         # pass B: flow queue before enqueue -> loss_cls_flow
-        lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb, ones)
+        lossB, rankB, dB = run(recf, q_fb.contiguous(), k_fb.contiguous(), ones, posB)
         if forkC is not None:
             main.wait_stream(forkC)                   # C has read the queue: the enqueue may overwrite it
             for tns in (lossC, rankC, dC):
                 tns.record_stream(main)
         recf.dequeue_and_enqueue(k_fb, kg.get('fb'))                     # base pass: update_queue=True (mscl.py:239)
         if forkC is None:
-            lossC, rankC, dC = run(recf, QC, KC, sC)
+            lossC, rankC, dC = run(recf, QC, KC, sC, posC)
         if model.update_aug_flow:
             recf.dequeue_and_enqueue(k_fa, kg.get('fa'))
         if fork is not None:

@@ -655,6 +655,24 @@ def test_nce(R, K, dev):
     gfull, = torch.autograd.grad(full, q)
     K_.nce_pos_bwd(kpos.to(dev), posd, lse, scale.to(dev), dq, 1.0 / T)
     close(dq, gfull, 1e-4, 'nce dq incl. positive')
+    # the same in ONE call (round 5: the slab-sum launch adds the positive pair's term)
+    dq1 = K_.nce_backward(queue.to(dev), count.to(dev), q.detach().to(dev), lse, scale.to(dev), 1.0 / T, pos_pair=(kpos.to(dev), posd))
+    close(dq1, gfull, 1e-4, 'nce dq incl. positive, one call')
+
+
+def test_loss_pack_positive_logits(dev):
+    """mscl_loss_pack's `pos` output: <query row, key row> of every row of the three passes, bit-identical to mscl_rowdot on the rows
+    the pack lays out (the pack launch replaced three rowdot launches on the loss phase)"""
+    from mscl_amd import kernels as K_
+    B, D, t, Cf = 8, 128, 4, 64
+    for use_aug in (True, False):
+        q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa = (F.normalize(rnd((B, D), 10 + i), dim=1).to(dev) for i in range(6))
+        p_fb, p_fa = rnd((B * t, Cf), 20).to(dev), rnd((B * t, Cf), 21).to(dev)
+        QA, KA, sA, QC, KC, sC, ones, flow, ws, (posA, posB, posC) = K_.loss_pack(q_rgb, q_fb, q_fa, k_rgb, k_fb, k_fa, p_fb, p_fa, t, use_aug, 0.5)
+        n = 3 if use_aug else 2
+        assert posA.shape == (n * B,) and posB.shape == (B,) and posC.shape == (n * B,)
+        assert torch.equal(posA, K_.rowdot(QA, KA)) and torch.equal(posB, K_.rowdot(q_fb, k_fb)) and torch.equal(posC, K_.rowdot(QC, KC))
+        assert torch.equal(QA[B:2 * B], q_fb) and torch.equal(KC[:B], k_fa) and torch.equal(KC[B:2 * B], k_fb)
 
 
 def test_enqueue_bit_exact(dev):
@@ -669,6 +687,17 @@ def test_enqueue_bit_exact(dev):
         assert torch.equal(cd.cpu(), count) and torch.equal(pd.cpu(), ptr) and torch.equal(qd.cpu(), queue)
     with pytest.raises(Exception):
         K_.queue_enqueue(qd, cd, pd, rnd((7, dim), 0).to(dev))      # K % n != 0 (moco.py:432 assert)
+    # the benchmark's queue (260 blocks; the one that finishes last moves the pointer): five enqueues back to back, no host sync between
+    K = 65536
+    queue = rnd((dim, K), 2); count = torch.zeros(K, dtype=torch.long); ptr = torch.tensor([K - 16])
+    qd, cd, pd = queue.to(dev), count.to(dev), ptr.to(dev)
+    keys = [rnd((n, dim), 30 + i) for i in range(5)]
+    kd = [k.to(dev) for k in keys]
+    for k in kd:
+        K_.queue_enqueue(qd, cd, pd, k)
+    for k in keys:
+        count += 1; p = int(ptr); queue[:, p:p + n] = k.T; count[p:p + n] = 1; ptr[0] = (p + n) % K
+    assert torch.equal(cd.cpu(), count) and torch.equal(pd.cpu(), ptr) and torch.equal(qd.cpu(), queue)
 
 
 @pytest.mark.parametrize('B,t', [(2, 4), (8, 8), (3, 2)])
