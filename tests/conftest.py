@@ -18,12 +18,54 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def _poison(dev, gib):
+    """MSCL_TEST_POISON=<GiB>: fill that much device memory with NaN bit patterns, in block sizes of both pools of the caching
+    allocator, and hand it back -- half to the allocator's cache (every later torch.empty is carved out of it), half to the driver
+    (graph-private pools and the library's own allocations).  A kernel that reads a workspace element nobody wrote then sees NaN
+    instead of whatever a fresh box happens to hold (a probe for reads of uninitialised memory; off by default)."""
+    import torch
+    held = []
+    big = max(1, int(gib))
+    for _ in range(big):
+        held.append(torch.full((1 << 28,), float('nan'), device=dev))                       # 1 GiB blocks (large pool)
+    for _ in range(2048):
+        held.append(torch.full((1 << 17,), float('nan'), device=dev))                       # 512 KiB blocks (small pool)
+    torch.cuda.synchronize()
+    del held[::2]
+    torch.cuda.empty_cache()
+    del held
+    torch.cuda.synchronize()
+
+
+def _jitter(cycles):
+    """MSCL_TEST_JITTER=<cycles>: every `with torch.cuda.stream(s):` region starts with a spin kernel of that many GPU cycles on s,
+    so whatever a side stream produces arrives LATE -- a consumer on another stream that lacks a wait then reads stale data every time
+    instead of once in a blue moon (a probe for missing cross-stream edges; off by default).  A negative count delays the stream
+    that opens the region instead."""
+    import torch
+    enter = torch.cuda.StreamContext.__enter__
+
+    def late(self):
+        if cycles < 0 and self.stream is not None:         # negative: the stream that forks is the late one
+            torch.cuda._sleep(-cycles)
+        r = enter(self)
+        if cycles > 0 and self.stream is not None:
+            torch.cuda._sleep(cycles)
+        return r
+    torch.cuda.StreamContext.__enter__ = late
+
+
 @pytest.fixture(scope='session')
 def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    return torch.device('cuda:0')
+    d = torch.device('cuda:0')
+    if os.environ.get('MSCL_TEST_POISON'):
+        _poison(d, float(os.environ['MSCL_TEST_POISON']))
+    if os.environ.get('MSCL_TEST_JITTER'):
+        _jitter(int(os.environ['MSCL_TEST_JITTER']))
+    return d
 
 
 @pytest.fixture(autouse=True)
