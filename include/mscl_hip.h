@@ -59,6 +59,7 @@ int64_t mscl_debug_halo_launches(void);
 int64_t mscl_debug_stem_launches(void);   /* conv_stem.hip: the window-resident RGB-stem forward */
 int64_t mscl_debug_wgrad_halo_launches(void);
 int64_t mscl_debug_thin_launches(void);
+int64_t mscl_debug_k1_launches(void);         /* thin-K 1x1x1 streaming kernel (csrc/conv_k1.hip) */
 int64_t mscl_debug_thin_wgrad_launches(void);
 int mscl_set_deterministic(int on);
 int mscl_get_deterministic(void);

@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 mkdir -p build
 pids=()
-SRCS="conv_igemm conv_pp conv_thin conv_halo conv_stem conv_wgrad conv_wgrad_halo bn_act elementwise pool3d color_aug datapath contrast optim"
+SRCS="conv_igemm conv_pp conv_thin conv_k1 conv_halo conv_stem conv_wgrad conv_wgrad_halo bn_act elementwise pool3d color_aug datapath contrast optim"
 for f in $SRCS; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ igemm.h -nt build/$f.o ] || [ ../../include/mscl_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &

@@ -635,6 +635,11 @@ static bool halo_enabled(const mscl_conv_desc* d) {
 int mscl_conv_thin(int planes, int H, int W, int C, int K, int flip, const bf16_t* x, const bf16_t* w, bf16_t* y, const float* bias,
                    const bf16_t* addend, int relu, float* ssum, float* ssq, int stat_groups, hipStream_t st);      // conv_thin.hip
 int mscl_conv_stem(const mscl_conv_desc* d, const bf16_t* x, const bf16_t* w, bf16_t* y, float* ssum, float* ssq, hipStream_t st);   // conv_stem.hip
+int mscl_conv_k1(long M, int K, int N, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const bf16_t* addend, float* ssum, float* ssq,
+                 hipStream_t st);                                                                                      // conv_k1.hip
+static bool unit_1x1x1(const mscl_conv_desc* d) {
+  return d->kT == 1 && d->kH == 1 && d->kW == 1 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 0 && d->pW == 0;
+}
 static bool thin_shape(const mscl_conv_desc* d) {
   return d->kT == 1 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 1 && d->pW == 1 &&
          (d->C == 16 || d->C == 32) && (d->K == 16 || d->K == 32);
@@ -675,6 +680,10 @@ extern "C" int mscl_conv3d_fwd_groups(const mscl_conv_desc* d, const uint16_t* x
     const int h = mscl_conv_halo64(d, 0, x, w, y, addend, ssum, ssq, stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
+  if (stat_groups == 1 && bias == nullptr && !relu && unit_1x1x1(d)) {     // thin-K, wide-N 1x1x1: persistent streaming kernel (conv_k1.hip)
+    const int h = mscl_conv_k1((long)d->N * d->T * d->H * d->W, d->C, d->K, x, w, y, addend, ssum, ssq, (hipStream_t)stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
   IGemmGeom g{};
   g.N = d->N; g.Ts = d->T; g.Hs = d->H; g.Ws = d->W; g.Cs = d->C;
   g.Tr = d->To; g.Hr = d->Ho; g.Wr = d->Wo; g.Cr = d->K;
@@ -698,6 +707,10 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
   }
   if (halo_enabled(d)) {
     const int h = mscl_conv_halo64(d, 1, dy, wT, dx, addend, nullptr, nullptr, stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
+  if (unit_1x1x1(d)) {
+    const int h = mscl_conv_k1((long)d->N * d->T * d->H * d->W, d->K, d->C, dy, wT, dx, addend, nullptr, nullptr, (hipStream_t)stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
   IGemmGeom g{};

@@ -144,6 +144,61 @@ def test_conv_real_layer_shapes(case, dev):
         assert lib.call_raw('mscl_debug_wgrad_halo_launches') == n_wh + 2, 'layer 1 did not take the window-resident weight gradient'
 
 
+# conv_k1.hip (persistent thin-K 1x1x1 streaming kernel; round 5): the forward of a widening conv K -> 4 K (64 -> 256, 128 -> 512, 256 -> 1024, the
+# `conv3` of the Bottleneck blocks, resnet3d.py:262-296) and the input gradient of a narrowing one (256 -> 64, 512 -> 128: `conv1`), with a
+# row count that is a multiple of the 128-row tile, one that leaves a tail of ONE row, one that gives some blocks one tile and others
+# two, and a map long enough for every block to walk several tiles.  Launch counters assert the kernel family.
+K1_CASES = [
+    # name, N,T,H,W, C (in), K (out)
+    ('k1_64_256', 1, 2, 56, 56, 64, 256),               # 6272 rows = 49 tiles
+    ('k1_64_256_tail', 1, 1, 65, 65, 64, 256),          # 4225 rows: 33 tiles + 1 row
+    ('k1_128_512', 1, 2, 56, 56, 128, 512),             # two channel tiles share the rows
+    ('k1_128_512_tail', 1, 3, 41, 43, 128, 512),        # 5289 rows
+    ('k1_128_256', 2, 2, 40, 40, 128, 256),             # the first block of layer 2: 256 -> 128 narrowing, gradient 128 -> 256
+    ('k1_64_256_long', 2, 8, 56, 56, 64, 256),          # 50176 rows = 392 tiles over 192 blocks
+    ('k1_256_1024', 2, 4, 28, 28, 256, 1024),           # K = 256: 64-row tiles, four channel tiles share the rows
+    ('k1_256_1024_tail', 1, 3, 37, 41, 256, 1024),      # 4551 rows: 71 tiles + 7 rows
+]
+
+
+@pytest.mark.parametrize('case', K1_CASES, ids=[c[0] for c in K1_CASES])
+def test_conv_k1(case, dev):
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, C, K = case
+    kern, one, zero = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+    x = bf(rnd((N, T, H, W, C), 21)); w = bf(rnd((K, *kern, C), 22, scale=(2.0 / C) ** 0.5))
+    d = K_.conv_desc(x.shape, K, kern, one, zero)
+    xg, wg = x.to(dev), w.to(dev)
+    n0 = lib.call_raw('mscl_debug_k1_launches')
+    st = torch.zeros((K_.STAT_SLOTS, 2, K), device=dev)
+    y = K_.conv3d_fwd(xg, wg, d, stats=(st[0, 0], st[0, 1]))
+    assert lib.call_raw('mscl_debug_k1_launches') == n0 + 1, 'the forward did not take the thin-K kernel'
+    yr = _conv_ref(x.float(), w.float(), one, zero)
+    close(y, yr, BF16_TOL, 'k1 fwd')
+    close(st[:, 0].sum(0), yr.sum(dim=(0, 1, 2, 3)), 2e-3, 'k1 bn sum')
+    close(st[:, 1].sum(0), (yr * yr).sum(dim=(0, 1, 2, 3)), 2e-3, 'k1 bn sumsq')
+    a = bf(rnd(tuple(yr.shape), 24))
+    close(K_.conv3d_fwd(xg, wg, d, addend=a.to(dev)), yr + a.float(), BF16_TOL, 'k1 fwd + addend')
+    assert lib.call_raw('mscl_debug_k1_launches') == n0 + 2
+    # the narrowing conv K -> C whose input gradient is this GEMM: dx (.., K) = dy (.., C) . w2[C][K]
+    w2 = bf(rnd((C, *kern, K), 25, scale=(2.0 / K) ** 0.5))
+    d2 = K_.conv_desc((N, T, H, W, K), C, kern, one, zero)
+    wT = torch.empty((K, *kern, C), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(w2.to(dev), wT, C, 1, K)
+    dy = bf(rnd((N, T, H, W, C), 26)); add = bf(rnd((N, T, H, W, K), 27))
+    n1 = lib.call_raw('mscl_debug_k1_launches')
+    dx = K_.conv3d_dgrad(dy.to(dev), wT, d2)
+    dx2 = K_.conv3d_dgrad(dy.to(dev), wT, d2, addend=add.to(dev))
+    assert lib.call_raw('mscl_debug_k1_launches') == n1 + 2, 'the input gradient did not take the thin-K kernel'
+    dxr = dy.float().reshape(-1, C) @ w2.float().reshape(C, K)
+    close(dx.reshape(-1, K), dxr, BF16_TOL, 'k1 dgrad')
+    close(dx2.reshape(-1, K), dxr + add.float().reshape(-1, K), BF16_TOL, 'k1 dgrad + addend')
+    # the same launch again, many times: a race between the staged tiles and the fragment reads shows as a changed output
+    y0 = K_.conv3d_fwd(xg, wg, d)
+    for _ in range(10):
+        assert torch.equal(K_.conv3d_fwd(xg, wg, d), y0)
+
+
 # conv_pp.hip (ping-pong, shared W taps) forced onto small shapes: row tails, a map smaller than one tile, split-K over the
 # (kt, kh, channel part) groups with the finalize pass, kT = 1, strides along T / H (forward only: the strided input gradient is
 # the parity-class kernel's), 256 / 512 channels (2 / 4 channel tiles, 4 / 8 channel parts per tap).
