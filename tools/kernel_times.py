@@ -1,3 +1,5 @@
+"""Per-launch durations of every kernel in a rocprofv3 --kernel-trace --output-format csv directory, in launch order (every third launch).
+usage: python tools/kernel_times.py DIR"""
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 d = collections.defaultdict(list)

@@ -1,4 +1,6 @@
-// scratch microbenchmark: read M x 64 bf16, write M x 256 bf16 with different store shapes
+// Stand-alone probe (hipcc --offload-arch=gfx950 -O3 tools/store_bw.hip -o /tmp/store_bw): read [M][64] bf16, write [M][256] bf16 -- the
+// bytes of a 64 -> 256 1x1x1 conv on the 56^2 maps -- with 1-KB contiguous wave stores and with the MFMA fragment's store shape.  The
+// yardstick csrc/conv_k1.hip is measured against (profiles/r05_ab_sweeps.md).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
