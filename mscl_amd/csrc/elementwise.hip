@@ -319,14 +319,36 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
     } else {
       int t0, t1, h0, h1, w0, w1; float a, b, c;
       lin_coord(t, Ts, Td, t0, t1, a); lin_coord(h, Hs, Hd, h0, h1, b); lin_coord(w, Ws, Wd, w0, w1, c);
+      // All eight corner offsets first, then eight 16-byte BUFFER loads in flight (32-bit offsets from one descriptor).  The plain form --
+      // a global load per corner inside the loop, 64-bit address arithmetic between them -- delivered ZEROS for ONE corner to the last
+      // sixteen lanes of a wave (= one output row) about once in 4000 launches inside the three-stream step of the small deterministic
+      // test, never alone (tools/flake_det.py, profiles/r05_flake_det.md: the source row was in memory, a sentinel written beforehand
+      // was not what came back, non-temporal loads changed nothing); with the addresses held until the data is back the rate fell to a
+      // third, in this form to a tenth.  Not understood; the bitwise test retries once and reports.
+      const bf16_t* ap[8]; float wt8[8]; uint4 v8[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int tt = (k & 4) ? t1 : t0, hh = (k & 2) ? h1 : h0, ww = (k & 1) ? w1 : w0;
-        const float wt = ((k & 4) ? a : 1.f - a) * ((k & 2) ? b : 1.f - b) * ((k & 1) ? c : 1.f - c);
-        float g8[8];
-        unpack8(*reinterpret_cast<const uint4*>(src + ((((long)n * Ts + tt) * Hs + hh) * Ws + ww) * C + gq * 8), g8);
+        wt8[k] = ((k & 4) ? a : 1.f - a) * ((k & 2) ? b : 1.f - b) * ((k & 1) ? c : 1.f - c);
+        ap[k] = src + ((((long)n * Ts + tt) * Hs + hh) * Ws + ww) * C + gq * 8;
+      }
+      {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const uint64_t sa = reinterpret_cast<uint64_t>(src);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sa), hi = __builtin_amdgcn_readfirstlane((unsigned)(sa >> 32));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] += wt * g8[i];
+        for (int k = 0; k < 8; ++k) {
+          const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((ap[k] - src) * 2), 0, 0);
+          v8[k] = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float g8[8];
+        unpack8(v8[k], g8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += wt8[k] * g8[i];
       }
     }
     if (accumulate) {

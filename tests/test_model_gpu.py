@@ -300,40 +300,59 @@ def test_graphed_step_equals_eager_bitwise_in_deterministic_mode(dev):
     """With lib.set_deterministic the captured-graph step and the eager step are the same arithmetic in the same order: three
     optimizer steps on three DIFFERENT batches give bit-identical losses, parameters and queue state (no noise yardstick needed)
     -- for the graph that reads its inputs by address (the single-GPU default: asserted, so a replay provably read each new
-    batch's address and not the capture batch's) and for the graph that copies them into static buffers."""
+    batch's address and not the capture batch's) and for the graph that copies them into static buffers.
+    One re-run per mode: on this pool ONE load of the trilinear up-sampling kernel delivers zeros to a quarter wave about once in
+    40 000 launches inside the three-stream step (profiles/r05_flake_det.md, tools/flake_det.py: diagnosed to the load, not
+    understood, never outside the step) -- one pyramid row moves, loss_pos by 1e-4, and bit-identity is gone for that run.  A run
+    that disagrees is repeated once and the event is reported as a warning; a systematic difference disagrees twice and fails."""
+    import warnings
     from mscl_amd import ClipSGD, lib
     from mscl_amd.graph import GraphedStep
     from mscl_amd.synthetic import synthetic_batch
     B, T, H, Kq = 2, 8, 32, 64
+
+    def run(mode):
+        model, cfg = build(T, Kq, dev)
+        opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
+        batches = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(3)]
+        losses = []
+        if mode != 'eager':
+            gs = GraphedStep(model, opt, batches[0], warmup=2, indirect=None if mode == 'graph' else False)
+            assert (gs.indirect is not None) == (mode == 'graph'), 'which input path the captured step took'
+            for s in range(3):
+                losses.append(float(gs.step(batches[s])[0]))
+        else:
+            for s in (0, 0, 0, 1, 2):
+                out = model.train_step(batches[s], sync_logs=False)
+                opt.zero_grad(); out['loss'].backward(); opt.step()
+                losses.append(float(out['loss'].detach()))
+            losses = losses[2:]
+        torch.cuda.synchronize()
+        return losses, model.arena.Q.clone(), model.recognizer.queue.clone(), model.recognizer_flow.queue.clone()
+
+    def same(x, y):
+        return x[0] == y[0] and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]) and torch.equal(x[3], y[3])
     lib.set_deterministic(True)
     try:
-        runs = []
-        for mode in ('eager', 'graph', 'graph_static'):
-            model, cfg = build(T, Kq, dev)
-            opt = ClipSGD.from_cfg(model, cfg.optimizer, cfg.optimizer_config)
-            batches = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(3)]
-            losses = []
-            if mode != 'eager':
-                gs = GraphedStep(model, opt, batches[0], warmup=2, indirect=None if mode == 'graph' else False)
-                assert (gs.indirect is not None) == (mode == 'graph'), 'which input path the captured step took'
-                for s in range(3):
-                    losses.append(float(gs.step(batches[s])[0]))
-            else:
-                for s in (0, 0, 0, 1, 2):
-                    out = model.train_step(batches[s], sync_logs=False)
-                    opt.zero_grad(); out['loss'].backward(); opt.step()
-                    losses.append(float(out['loss'].detach()))
-                losses = losses[2:]
-            torch.cuda.synchronize()
-            runs.append((losses, model.arena.Q.clone(), model.recognizer.queue.clone(), model.recognizer_flow.queue.clone()))
+        ref = run('eager')
+        assert len(set(ref[0])) == 3, 'the three batches must give three different losses'
+        again = run('eager')
+        if not same(ref, again):                      # which of the two eager runs carries an event: a third decides
+            third = run('eager')
+            assert same(third, ref) or same(third, again), 'three eager runs, three results'
+            warnings.warn('deterministic mode: one of three eager runs differed (profiles/r05_flake_det.md)')
+            ref = ref if same(third, ref) else again
+        for mode in ('graph', 'graph_static'):
+            got = run(mode)
+            if not same(ref, got):
+                warnings.warn(f'deterministic mode: a {mode} run differed from the eager run once (losses {ref[0]} vs {got[0]}); '
+                              'repeated (profiles/r05_flake_det.md)')
+                got = run(mode)
+            assert ref[0] == got[0], (mode, ref[0], got[0])
+            assert torch.equal(ref[1], got[1]), (mode, float((ref[1] - got[1]).abs().max()))
+            assert torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3]), mode
     finally:
         lib.set_deterministic(False)
-    (l0, q0, a0, b0) = runs[0]
-    assert len(set(l0)) == 3, 'the three batches must give three different losses'
-    for (l1, q1, a1, b1) in runs[1:]:
-        assert l0 == l1, (l0, l1)
-        assert torch.equal(q0, q1), float((q0 - q1).abs().max())
-        assert torch.equal(a0, a1) and torch.equal(b0, b1)
 
 
 # ----------------------------------------------------------------------------- 2 ranks on one GPU
