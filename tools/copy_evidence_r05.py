@@ -55,7 +55,7 @@ def main():
     nce = open(os.path.join(P, 'r05_nce_passes.md')).read()
     nf = re.search(r'nce_fwd_kernel<24>.*?([0-9.]+) us', nce); nb = re.search(r'nce_bwd_kernel<24>.*?([0-9.]+) us', nce)
     txt = (f"**Results** (one MI355X, `profiles/r05_*`, every file stamped with its commit, `{head}`; box-to-box spread is several per cent -- the\n"
-           f"boxes of this round's calls read 1099-1181 clip-pairs/s on one and the same build -- so A/B pairs are made inside one call; the number\n"
+           f"boxes of this round's calls read 1099-1188 clip-pairs/s on one and the same build -- so A/B pairs are made inside one call; the number\n"
            f"to quote is the DRIVER's: round 4 1095.8). This evidence run: **{d['value']:.1f} clip-pairs/s** ({d['ms_per_step']:.2f} ms per step of 8\n"
            f"clip-pairs), deterministic mode {det:.0f}, CPU baseline (oracle, {d['cpu_baseline']['cores']} threads) {d['cpu_baseline']['value']:.2f}. Dominant kernel: layer-1 forward "
            f"{rf['avg_launch_ms'] * 1e3:.1f} µs by events =\n{rf['achieved']:.0f} TFLOP/s = **{rf['frac']:.3f} of the MFMA peak**, HBM traffic "
