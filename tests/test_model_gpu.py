@@ -1316,9 +1316,16 @@ def test_slowonly50_trunk_32x224(dev):
     x = synthetic_batch(B, T, H, H, 0, 0)['imgs'][0]
     mean = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1, 1); std = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1, 1)
     model.zero_grad()
+    from mscl_amd import lib
+    n_k1 = lib.call_raw('mscl_debug_k1_launches')
     maps = model.recognizer.encoder_q(model.aug_gpu.pack_rgb(x.to(dev)))
+    # (round 5) the widening 1x1x1 convs of layers 1-3 -- conv3 of 3 + 4 + 6 blocks and layer 1's shortcut -- take the thin-K streaming
+    # kernel (csrc/conv_k1.hip) at this size ...
+    assert lib.call_raw('mscl_debug_k1_launches') - n_k1 == 14, lib.call_raw('mscl_debug_k1_launches') - n_k1
     loss = maps[-1].float().mean() + maps[1].float().mean()
     loss.backward()
+    # ... and so do the input gradients of the narrowing conv1 of layers 1-2 (256 -> 64 twice, 256 -> 128, 512 -> 128 three times)
+    assert lib.call_raw('mscl_debug_k1_launches') - n_k1 == 14 + 6, lib.call_raw('mscl_debug_k1_launches') - n_k1
     omaps = orc.recognizer.encoder_q((x - mean) / std)
     oloss = omaps[-1].mean() + omaps[1].mean()
     oloss.backward()
