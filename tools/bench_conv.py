@@ -41,7 +41,8 @@ SHAPES = [
 
 # ResNet3dSlowOnly-50 at 8 x 32 x 224^2 (BASELINE configs[4]; --r50): thin-K convs on 205-MB maps, HBM-bound
 SHAPES_R50 = [
-    ('r50_stem_pairw', (8, 32, 224, 113, 8), 64, (1, 7, 4), (1, 2, 1), (0, 3, 1)),       # conv1 (1,7,7) / (1,2,2) on W-paired input
+    ('r50_stem_pairw', (8, 32, 224, 113, 8), 64, (5, 7, 4), (2, 2, 1), (2, 3, 1)),       # conv1 (5,7,7) / (2,2,2) of mscl_r50_cosm_lr3e-2.py:18 on W-paired input (implicit-GEMM kernel: conv_stem.hip covers kT <= 3)
+    ('r50_stem_177_pairw', (8, 32, 224, 113, 8), 64, (1, 7, 4), (1, 2, 1), (0, 3, 1)),   # the (1,7,7) / (1,2,2) stem of the reference's default SlowOnly (conv_stem.hip)
     ('r50_l1_c1_64_64', (8, 16, 56, 56, 64), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ('r50_l1_c2_133', (8, 16, 56, 56, 64), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('r50_l1_c3_64_256', (8, 16, 56, 56, 64), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
