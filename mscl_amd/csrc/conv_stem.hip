@@ -1,5 +1,5 @@
 // Window-resident forward of the RGB stems on bf16 MFMA, gfx950: nn.Conv3d(3, 64, (kT, 7, 7), stride (sT, 2, 2), padding (pT, 3, 3))
-// of r3d.py:176-184 (torchvision r3d_18: kT = 3) and resnet3d.py conv1 (ResNet3dSlowOnly: kT = 1), executed on the W-PAIRED clip
+// of r3d.py:176-184 (torchvision r3d_18: kT = 3) and resnet3d.py conv1 (ResNet3dSlowOnly: kT = 1; mscl_r50_cosm_lr3e-2.py:18: kT = 5, sT = 2), executed on the W-PAIRED clip
 // (elementwise.hip, pair_w_kernel: a position holds two neighbouring pixels as 8 channels, the conv becomes (kT, 7, 4) / stride
 // (sT, 2, 1) / pad (pT, 3, 1) over pairs; one (kt, kh) row of the kernel = 4 pairs x 8 channels = ONE 32-deep MFMA k step).
 //
@@ -34,7 +34,7 @@ __device__ __forceinline__ auto stem_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-// KT = temporal taps (1, 3); NPS = window pieces per thread and plane (a piece = 512 threads x 16 B: NPS * 512 pairs hold the window
+// KT = temporal taps (1, 3, 5); NPS = window pieces per thread and plane (a piece = 512 threads x 16 B: NPS * 512 pairs hold the window
 // of one plane); RING = weight-ring stages.
 template <int KT, int NPS, int RING>
 __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, const bf16_t* __restrict__ src,
@@ -91,11 +91,20 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
   // ---- prologue: plane 0 and the first RING weight stages, then the other planes: the loop starts when plane 0 and stage 0 have
   // landed; the later planes are first read in stage 3 (k step 7), whose wait (at the end of stage 2) is for a weight stage issued
   // AFTER them and so covers them, while the waits of stages 0 and 1 leave their pieces in flight ----
+  // (KT = 5, the (5,7,7) / temporal-stride-2 stem of mscl_r50: four later planes are more pieces than the counted wait below can
+  // leave in flight, and five planes make ONE block per CU anyway -- every plane goes out first and has landed when the loop starts)
+  constexpr bool PLANES_FIRST = KT > 3;
   issue_plane(0);
+  if constexpr (PLANES_FIRST) {
+#pragma unroll
+    for (int kt = 1; kt < KT; ++kt) issue_plane(kt);
+  }
 #pragma unroll
   for (int u = 0; u < RING; ++u) issue_weights(u);
+  if constexpr (!PLANES_FIRST) {
 #pragma unroll
-  for (int kt = 1; kt < KT; ++kt) issue_plane(kt);
+    for (int kt = 1; kt < KT; ++kt) issue_plane(kt);
+  }
 
   const int fr = lane & 15, fq = lane >> 4;
   const int wpl16 = __builtin_amdgcn_readfirstlane(g.WPL * 16);
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(const StemGeom g, con
   };
 #define ST_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
   // plane 0 + stage 0 landed; the other planes and RING - 1 stages stay in flight
-  constexpr int LATE = (KT - 1) * NPS;                    // pieces of the later planes
+  constexpr int LATE = PLANES_FIRST ? 0 : (KT - 1) * NPS; // pieces of the later planes still in flight behind the first weight stages
   static_assert(RING - 1 + LATE <= 8 && (KT == 1 || RING <= 3), "prologue wait");
 #define ST_WAIT_N(n) do { if ((n) >= 8) ST_WAIT(8); else if ((n) == 7) ST_WAIT(7); else if ((n) == 6) ST_WAIT(6); else if ((n) == 5) ST_WAIT(5); \
     else if ((n) == 4) ST_WAIT(4); else if ((n) == 3) ST_WAIT(3); else if ((n) == 2) ST_WAIT(2); else if ((n) == 1) ST_WAIT(1); else ST_WAIT(0); } while (0)
@@ -222,7 +231,7 @@ extern "C" int64_t mscl_debug_stem_launches(void) { return g_stem_launches; }   
 
 template <int KT, int NPS>
 static void stem_go(const StemGeom& g, unsigned nblk, const bf16_t* x, const bf16_t* w, bf16_t* y, float* ssum, float* ssq, hipStream_t st) {
-  constexpr int RING = KT == 1 ? 2 : 3;
+  constexpr int RING = KT == 1 ? 2 : 3;           // (KT = 5: 120 KB of window at NPS = 3 + 24 KB of ring: one block per CU)
   constexpr size_t lds = (size_t)KT * NPS * 512 * 16 + (size_t)RING * 8192;
   static bool attr_done = false;
   if (!attr_done) {
@@ -236,7 +245,7 @@ static void stem_go(const StemGeom& g, unsigned nblk, const bf16_t* x, const bf1
 // d describes the PAIRED convolution: C = 8, K = 64, kernel (kT, 7, 4), stride (sT, 2, 1), padding (pT, 3, 1).
 int mscl_conv_stem(const mscl_conv_desc* d, const bf16_t* x, const bf16_t* w, bf16_t* y, float* ssum, float* ssq, hipStream_t st) {
   if (d->C != 8 || d->K != 64 || d->kH != 7 || d->kW != 4 || d->sH != 2 || d->sW != 1 || d->pH != 3 || d->pW != 1 ||
-      (d->kT != 1 && d->kT != 3)) return 0;
+      (d->kT != 1 && d->kT != 3 && d->kT != 5)) return 0;
   // MSCL_STEM: 0 off, 1 forced (tests: small planes too); default: planes of at least two 256-position tiles
   static MsclTune t("MSCL_STEM");
   const int sw = t.get(-1);
@@ -254,9 +263,11 @@ int mscl_conv_stem(const mscl_conv_desc* d, const bf16_t* x, const bf16_t* w, bf
   const int pairs = (2 * (span - 1) + 7) * g.WPL;
   const unsigned nblk = (unsigned)((long)d->N * d->To * g.tiles);
   if (pairs <= 2 * 512) {
-    if (d->kT == 3) stem_go<3, 2>(g, nblk, x, w, y, ssum, ssq, st); else stem_go<1, 2>(g, nblk, x, w, y, ssum, ssq, st);
+    if (d->kT == 5) stem_go<5, 2>(g, nblk, x, w, y, ssum, ssq, st);
+    else if (d->kT == 3) stem_go<3, 2>(g, nblk, x, w, y, ssum, ssq, st); else stem_go<1, 2>(g, nblk, x, w, y, ssum, ssq, st);
   } else if (pairs <= 3 * 512) {
-    if (d->kT == 3) stem_go<3, 3>(g, nblk, x, w, y, ssum, ssq, st); else stem_go<1, 3>(g, nblk, x, w, y, ssum, ssq, st);
+    if (d->kT == 5) stem_go<5, 3>(g, nblk, x, w, y, ssum, ssq, st);
+    else if (d->kT == 3) stem_go<3, 3>(g, nblk, x, w, y, ssum, ssq, st); else stem_go<1, 3>(g, nblk, x, w, y, ssum, ssq, st);
   } else return 0;
   MSCL_LAUNCH_CHECK();
   ++g_stem_launches;

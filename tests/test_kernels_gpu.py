@@ -465,6 +465,9 @@ STEM_CASES = [
     ('stride_t2', 1, 5, 64, 64, 3, 2, 1, False),
     ('small_20x24', 2, 4, 20, 24, 3, 1, 1, True),
     ('small_kt1_22x23', 2, 2, 22, 23, 1, 1, 0, True),
+    ('r50_cfg_kt5_224', 1, 6, 224, 224, 5, 2, 2, False),      # conv1 of mscl_r50_cosm_lr3e-2.py:18: (5,7,7) / (2,2,2) / pad (2,3,3): three window pieces per plane
+    ('kt5_112_tail', 2, 5, 112, 96, 5, 2, 2, False),         # two pieces per plane, an odd frame count
+    ('small_kt5_20x24', 1, 7, 20, 24, 5, 2, 2, True),
 ]
 
 
