@@ -169,6 +169,282 @@ __global__ __launch_bounds__(256, 2) void nce_fwd_kernel(const float* __restrict
   }
 }
 
+// ---- Round 6: the feature x queue product on the matrix cores (exact fp32: v_mfma_f32_16x16x4_f32 == an fmaf chain) ----------------
+// The vector form above splits the 128 channels over four waves: every lane does R x 32 multiply-adds per column, fetches the query
+// rows from LDS for each channel, and the four partial sums of every (row, column) meet through LDS -- loads, 3072 multiply-adds and
+// the exchange follow one another inside a block (17 / 25 us per pass at 24 rows = 1.9 / 1.3 TB/s of queue reads).  Here a WAVE owns
+// 64 queue columns over ALL channels, so a logit is born complete in one accumulator:
+//   D[queue column m][query row n] += A[m][c] * B[c][n],  A = the queue tile as it arrives from memory, B = the query rows.
+// * A operand = the load itself.  Load g of a lane is 16 bytes: channel 32 (lane >> 4) + g, columns k0 + 4 (lane & 15) .. + 3 -- a wave
+//   instruction reads 256 contiguous bytes of each of four queue rows -- and register j of that load is the A operand (row m =
+//   lane & 15, k = lane >> 4) of the MFMA whose row m stands for column k0 + 4 m + j: the MFMA does not care which column a row is,
+//   so no data moves between the load and the matrix core.  All 32 loads of a wave (32 KB) are issued before the first use.
+// * B operand = q[16 h + (lane & 15)][32 (lane >> 4) + g], 32 registers per 16-row half = eight 16-byte loads per wave; no LDS.
+// * The accumulator of MFMA j holds, in register v, column k0 + 16 (lane >> 4) + 4 v + j for query row lane & 15: a lane ends up
+//   with SIXTEEN CONSECUTIVE columns of ONE query row, so max / sum-exp / rank count are in-lane loops; the four lane groups of a
+//   row and the two waves of a 128-column chunk meet through 6 KB of LDS in a fixed order (the `part` layout of the ABI is kept).
+// * Ages: lane l turns count[k0 + l] into its decay once; the sixteen a lane needs come back from LDS as four 16-byte reads.
+// One block = 4 waves = 256 columns: 256 blocks at K = 65536, one per CU, 128 KB of loads in flight per CU.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define NCE_MCOLS 64                      // queue columns per wave of the MFMA kernels (two waves = one 128-column chunk of `part`)
+
+struct NceTile { int k0, kc; bool live4; };            // kc: the lane's first column (clamped), live4: its four columns exist
+// (no zero-fill here: rows >= R are clamped to row R - 1 and never stored; channels >= dim meet zeroed queue registers)
+template <int RH>
+__device__ __forceinline__ void nce_mfma_load_q(const float* __restrict__ q, float (&bq)[RH][32], int R, int dim, int lane) {
+  const int lm = lane & 15, lg = lane >> 4;
+  const int cq = dim >> 2, imax = (cq >> 2) - 1;          // lane group lg contracts channels [lg cq, (lg + 1) cq): contiguous in a query row
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    const int r = 16 * h + lm < R ? 16 * h + lm : R - 1;
+    const float* qp = q + r * dim + lg * cq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(qp + 4 * (i < imax ? i : imax));
+      bq[h][4 * i] = v[0]; bq[h][4 * i + 1] = v[1]; bq[h][4 * i + 2] = v[2]; bq[h][4 * i + 3] = v[3];
+    }
+  }
+}
+__device__ __forceinline__ void nce_mfma_load_tile(const float* __restrict__ queue, f32x4_t (&wv)[32], int dim, int K, int lane,
+                                                   const NceTile& t, const NceVirt& vt, int p) {
+  // one buffer descriptor over the queue; a lane's byte offset (its channel of the group, its first column) in a VGPR, the group's
+  // row offset 4 g K in the instruction's SGPR operand: no 64-bit address arithmetic per load (the launcher checks dim K 4 < 2^31)
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const int lg = lane >> 4;
+  const uint64_t qa = reinterpret_cast<uint64_t>(queue);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)qa), hi = __builtin_amdgcn_readfirstlane((unsigned)(qa >> 32));
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
+  const int cq = dim >> 2, gmax = cq - 1;  // MFMA step g contracts channels lg cq + g (lg = 0 .. 3): step g exists for every lane group or for none
+  const int voff = (lg * cq * K + t.kc) * 4;
+#pragma unroll
+  for (int g = 0; g < 32; ++g) {           // unconditional loads from clamped rows / columns
+    const int gs = g < gmax ? g : gmax;
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, gs * 4 * K, 0);
+    wv[g] = __builtin_bit_cast(f32x4_t, v);
+  }
+  if (vt.keys != nullptr) {                // the virtual enqueue's columns (wave-uniform test first: one tile in K / 64 has any)
+    if (p < t.k0 + NCE_MCOLS && p + vt.n_new > t.k0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int jn = t.kc + j - p;
+        if (jn >= 0 && jn < vt.n_new) {
+#pragma unroll
+          for (int g = 0; g < 32; ++g) wv[g][j] = vt.keys[(long)jn * dim + lg * cq + (g < gmax ? g : gmax)];
+        }
+      }
+    }
+  }
+  if (gmax < 31) {                         // dim < 128 (wave-uniform); dead columns need no zeros: the epilogue masks them by column
+#pragma unroll
+    for (int g = 0; g < 32; ++g)
+      if (g > gmax) wv[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+}
+// decay of a column at age `a` (recognizers/moco.py:484) in the snapshot `vt` describes, as nce_decay takes it (p = *vt.ptr)
+__device__ __forceinline__ float nce_mfma_decay(long a, int k, int p, const NceVirt& vt) {
+  const int jn = k - p;
+  const float age = vt.keys == nullptr ? (float)a : ((jn >= 0 && jn < vt.n_new) ? 1.f : (float)(a + 1));
+  return powf(0.99999f, age);
+}
+template <int RH>
+__device__ __forceinline__ void nce_mfma_logits(const f32x4_t (&wv)[32], const float (&bq)[RH][32], f32x4_t (&acc)[RH][4]) {
+#pragma unroll
+  for (int h = 0; h < RH; ++h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[h][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 32; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < RH; ++h) acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g][j], bq[h][g], acc[h][j], 0, 0, 0);
+}
+
+template <int RH>
+__global__ __launch_bounds__(256, 1) void nce_fwd_mfma_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                              const float* __restrict__ q, const float* __restrict__ pos,
+                                                              float* __restrict__ part, int R, int dim, int K, float inv_T,
+                                                              const NceVirt vt) {
+  __shared__ __attribute__((aligned(16))) float dec_s[4][NCE_MCOLS];
+  __shared__ float pm[4][4][16 * RH][3];                         // [wave][lane group][row]{max, sum, count}
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lm = lane & 15, lg = lane >> 4;
+  NceTile t; t.k0 = (blockIdx.x * 4 + wave) * NCE_MCOLS;
+  t.live4 = t.k0 + 4 * lm < K; t.kc = t.live4 ? t.k0 + 4 * lm : K - 4;
+  // the small loads first (queue pointer, the lane's age, the query rows: ~20 instructions, nothing waits for them yet), then the
+  // tile; the pointer is needed only behind the tile's loads, by the test for the virtual enqueue's columns
+  const int pq = vt.keys != nullptr ? (int)*vt.ptr : 0;
+  const int kd = t.k0 + lane < K ? t.k0 + lane : K - 1;
+  const long age = count[kd];
+  float bq[RH][32];
+  nce_mfma_load_q<RH>(q, bq, R, dim, lane);
+  __builtin_amdgcn_sched_barrier(0);        // (left alone, hipcc issues the query-row loads in the MIDDLE of the tile's: the first MFMA
+  f32x4_t wv[32];                           //  then waits for 37 of the 48 loads and the chain starts when the tile is nearly complete)
+  nce_mfma_load_tile(queue, wv, dim, K, lane, t, vt, pq);
+  dec_s[wave][lane] = nce_mfma_decay(age, kd, pq, vt);
+  f32x4_t acc[RH][4];
+  nce_mfma_logits<RH>(wv, bq, acc);
+  float dc[16];                                                  // the lane's sixteen columns: k0 + 16 lg + 4 v + j  ->  dc[4 v + j]
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(&dec_s[wave][16 * lg + 4 * v]);
+    dc[4 * v] = d4[0]; dc[4 * v + 1] = d4[1]; dc[4 * v + 2] = d4[2]; dc[4 * v + 3] = d4[3];
+  }
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    const int r = 16 * h + lm;
+    const float pr = pos[r < R ? r : 0] * inv_T;
+    float l[16], m = -INFINITY, cnt = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = t.k0 + 16 * lg + 4 * v + j < K;
+        const float x = live ? acc[h][j][v] * dc[4 * v + j] * inv_T : -INFINITY;
+        l[4 * v + j] = x; m = fmaxf(m, x); cnt += (live && x > pr) ? 1.f : 0.f;
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += (m == -INFINITY) ? 0.f : __expf(l[i] - m);
+    float* o = pm[wave][lg][r];
+    o[0] = m; o[1] = sum; o[2] = cnt;
+  }
+  __syncthreads();
+  // one partial per 128-column chunk (= two waves x four lane groups), merged in a fixed order
+  if (threadIdx.x < 2 * 16 * RH) {
+    const int ch = threadIdx.x / (16 * RH), r = threadIdx.x - ch * 16 * RH;
+    const int blk = blockIdx.x * 2 + ch;
+    if (r < R && blk * NCE_BCOLS < K) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) M = fmaxf(M, pm[2 * ch + w][g][r][0]);
+      float S = 0.f, Cn = 0.f;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float* o = pm[2 * ch + w][g][r];
+          S += (o[0] == -INFINITY) ? 0.f : o[1] * __expf(o[0] - M);
+          Cn += o[2];
+        }
+      float* o = part + ((long)blk * R + r) * 3; o[0] = M; o[1] = S; o[2] = Cn;
+    }
+  }
+}
+
+// Backward on the matrix cores.  Phase 1 = the forward's logits, turned in place into the coefficients cf[r][column] = softmax * decay *
+// scale.  Phase 2 = dq[r][c] += sum over the tile's columns of cf[r][column] * queue[c][column]: the contraction index is now the COLUMN,
+// which phase 1 had along the lanes -- the one transposition this pass needs.  The tile goes through LDS once (each load is written as
+// it arrives, under phase 1's MFMAs) in the image Wt[column group of 16][channel][16 columns], 16-byte units XOR-swizzled by
+// (channel >> 2) & 3, and comes back as the B operand of D2[r][c] += A2[r][kk] B2[kk][c] with K-step t <-> columns 16 kk + t:
+//   A2 (row r = lane & 15, kk = lane >> 4) = cf[r][16 kk + t] -- exactly the accumulator register (j, v) with 4 v + j = t the lane
+//   already holds: no movement;  B2 (kk, channel 16 cb + (lane & 15)) = one 16-byte LDS read per four K-steps, conflict-free.
+// The four waves' [rows x dim] results are added in wave order through the dead tile image and leave as ONE slab per block
+// ([block][rt][dim], summed by nce_bwd_reduce_kernel as before; half as many slabs as the vector form wrote).
+#define NCE_WT_FLOATS (4 * 128 * 16)       // one wave's tile image: [4 column groups][128 channels][16 columns] = 32 KB
+template <int RH>
+__global__ __launch_bounds__(256, 1) void nce_bwd_mfma_kernel(const float* __restrict__ queue, const int64_t* __restrict__ count,
+                                                              const float* __restrict__ q, const float* __restrict__ lse,
+                                                              const float* __restrict__ row_scale, float* __restrict__ slab,
+                                                              int R, int rt, int dim, int K, float inv_T, const NceVirt vt) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // Wt[4 waves][NCE_WT_FLOATS] | dec_s[4][64]
+  float* dec_s = sm + 4 * NCE_WT_FLOATS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lm = lane & 15, lg = lane >> 4;
+  float* Wt = sm + wave * NCE_WT_FLOATS;
+  NceTile t; t.k0 = (blockIdx.x * 4 + wave) * NCE_MCOLS;
+  t.live4 = t.k0 + 4 * lm < K; t.kc = t.live4 ? t.k0 + 4 * lm : K - 4;
+  const int pq = vt.keys != nullptr ? (int)*vt.ptr : 0;
+  const int kd = t.k0 + lane < K ? t.k0 + lane : K - 1;
+  const long age = count[kd];
+  float ls[RH], sc[RH]; bool rok[RH];
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    const int r = 16 * h + lm;
+    rok[h] = r < R;
+    ls[h] = lse[rok[h] ? r : 0]; sc[h] = inv_T * row_scale[rok[h] ? r : 0];
+  }
+  float bq[RH][32];
+  nce_mfma_load_q<RH>(q, bq, R, dim, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4_t wv[32];
+  nce_mfma_load_tile(queue, wv, dim, K, lane, t, vt, pq);
+  dec_s[wave * NCE_MCOLS + lane] = nce_mfma_decay(age, kd, pq, vt);
+  // phase 1, each load also stored into the tile image: the lane's four columns are unit (lm & 3) of column group lm >> 2
+  const int cq = dim >> 2;
+  f32x4_t acc[RH][4];
+#pragma unroll
+  for (int h = 0; h < RH; ++h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[h][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 32; ++g) {
+    const int ch = lg * cq + g;                             // (g >= cq: zeros, stored over rows that phase 2 never reads as real channels)
+    if (g < cq)
+      *reinterpret_cast<f32x4_t*>(Wt + (((lm >> 2) * 128 + (ch & 127)) * 16 + 4 * ((lm & 3) ^ ((ch >> 2) & 3)))) = wv[g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < RH; ++h) acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g][j], bq[h][g], acc[h][j], 0, 0, 0);
+  }
+  float dc[16];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(&dec_s[wave * NCE_MCOLS + 16 * lg + 4 * v]);
+    dc[4 * v] = d4[0]; dc[4 * v + 1] = d4[1]; dc[4 * v + 2] = d4[2]; dc[4 * v + 3] = d4[3];
+  }
+#pragma unroll
+  for (int h = 0; h < RH; ++h)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = t.k0 + 16 * lg + 4 * v + j < K;
+        const float d = dc[4 * v + j];
+        acc[h][j][v] = (live && rok[h]) ? __expf(acc[h][j][v] * d * inv_T - ls[h]) * d * sc[h] : 0.f;
+      }
+  // phase 2 (a wave reads only the image it wrote: LDS operations of one wave complete in order)
+  f32x4_t d2[RH][8];
+#pragma unroll
+  for (int h = 0; h < RH; ++h)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) d2[h][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const float* wr = Wt + (lg * 128 + lm) * 16;
+  const int sw = (lm >> 2) & 3;
+#pragma unroll
+  for (int cp = 0; cp < 4; ++cp) {                          // channel blocks in pairs: two independent accumulator chains per row half
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(wr + (2 * cp) * 256 + 4 * (i ^ sw));
+      const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(wr + (2 * cp + 1) * 256 + 4 * (i ^ sw));
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int h = 0; h < RH; ++h) {
+          d2[h][2 * cp] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[h][jj][i], b0[jj], d2[h][2 * cp], 0, 0, 0);
+          d2[h][2 * cp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[h][jj][i], b1[jj], d2[h][2 * cp + 1], 0, 0, 0);
+        }
+    }
+  }
+  __syncthreads();                                          // every wave is done with its image: the region changes hands
+  float* red = sm;                                          // [wave][16 RH rows][128 channels]
+#pragma unroll
+  for (int h = 0; h < RH; ++h)
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[(wave * 16 * RH + 16 * h + 4 * lg + v) * 128 + 16 * cb + lm] = d2[h][cb][v];
+  __syncthreads();
+  float* o = slab + (long)blockIdx.x * rt * dim;
+  for (int e = threadIdx.x; e < rt * 128; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c < dim && r < 16 * RH)
+      o[r * dim + c] = ((red[r * 128 + c] + red[(16 * RH + r) * 128 + c]) + red[(32 * RH + r) * 128 + c]) + red[(48 * RH + r) * 128 + c];
+  }
+}
+
 // one block per row: merge the per-block partials.  256 threads take nblk / 256 partials each with every load in flight, then
 // meet through LDS (one wave looping over 1024 partials twice was 32 dependent round trips: 8 us, three times in the loss phase)
 __global__ __launch_bounds__(256) void nce_finish_kernel(const float* __restrict__ part, const float* __restrict__ pos,
@@ -363,12 +639,22 @@ extern "C" int mscl_nce_fwd_virt(const float* queue, const int64_t* count, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+  static MsclTune t_mfma("MSCL_NCE_MFMA");               // A/B aid: 0 = the vector kernels
+  // (K % 4, dim % 16: a lane reads four columns of a queue row and four channels of a query row as 16-byte pieces; 32-bit byte offsets)
+  const bool mfma = K % 4 == 0 && dim % 16 == 0 && (long)dim * K * 4 < (1L << 31) && t_mfma.get(1) != 0;
   for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {
     const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
     const int rt = Rt <= 8 ? 8 : (Rt <= 16 ? 16 : (Rt <= 24 ? 24 : 32));
     const size_t lds = ((size_t)128 * rt + (size_t)NCE_WAVES * rt * NCE_BCOLS) * sizeof(float);        // 61 KB at 24 rows: two blocks per CU
     const float* qt = q + (size_t)r0 * dim; const float* pt = pos_logit + r0;
     float* part_t = part + (size_t)nblk * r0 * 3;
+    if (mfma) {
+      const int nb = (K + 4 * NCE_MCOLS - 1) / (4 * NCE_MCOLS);
+      if (Rt <= 16) hipLaunchKernelGGL(nce_fwd_mfma_kernel<1>, dim3(nb), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt);
+      else hipLaunchKernelGGL(nce_fwd_mfma_kernel<2>, dim3(nb), dim3(256), 0, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt);
+      MSCL_LAUNCH_CHECK();
+      continue;
+    }
     NCE_DISPATCH(Rt,
       hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(nblk), dim3(256), lds, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
       hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(nblk), dim3(256), lds, st, queue, count, qt, pt, part_t, Rt, dim, K, inv_T, vt),
@@ -412,10 +698,31 @@ extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+  static MsclTune t_mfma("MSCL_NCE_MFMA");               // A/B aid: 0 = the vector kernels
+  const bool mfma = K % 4 == 0 && dim % 16 == 0 && (long)dim * K * 4 < (1L << 31) && t_mfma.get(1) != 0;
+  static bool attr_m = false;
+  if (mfma && !attr_m) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_m = true;
+  }
   for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {      // the tiles share the slab workspace: they run one after the other on `st`
     const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
     const int rt = Rt <= 8 ? 8 : (Rt <= 16 ? 16 : (Rt <= 24 ? 24 : 32));
     if ((int64_t)nblk * rt * dim > ws_floats) return MSCL_E_ARG;
+    if (mfma) {
+      const int nb = (K + 4 * NCE_MCOLS - 1) / (4 * NCE_MCOLS);            // one slab per block of 256 columns: nb <= nblk
+      const size_t ldsm = ((size_t)4 * NCE_WT_FLOATS + 4 * NCE_MCOLS) * sizeof(float);
+      const float* qt = q + (size_t)r0 * dim; const float* lt = lse + r0; const float* st_ = row_scale + r0;
+      if (Rt <= 16) hipLaunchKernelGGL(nce_bwd_mfma_kernel<1>, dim3(nb), dim3(256), ldsm, st, queue, count, qt, lt, st_, ws, Rt, rt, dim, K, inv_T, vt);
+      else hipLaunchKernelGGL(nce_bwd_mfma_kernel<2>, dim3(nb), dim3(256), ldsm, st, queue, count, qt, lt, st_, ws, Rt, rt, dim, K, inv_T, vt);
+      MSCL_LAUNCH_CHECK();
+      hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, mscl_det() ? 1 : 32), dim3(256), 0, st, (const float*)ws,
+                         dq + (size_t)r0 * dim, nb, rt, Rt, dim, kpos ? kpos + (size_t)r0 * dim : nullptr, kpos ? pos_logit + r0 : nullptr, lt, st_,
+                         inv_T);
+      MSCL_LAUNCH_CHECK();
+      continue;
+    }
     const size_t red_f = (size_t)NCE_WAVES * rt * NCE_BCOLS, wt_f = (size_t)128 * NCE_WPAD;      // Wt lies over the dead reduction image
     const size_t lds = ((size_t)rt * NCE_BCOLS + (red_f > wt_f ? red_f : wt_f)) * sizeof(float);          // (dim <= 128 = NCE_BCOLS: gc covers qs); 79 KB at 24 rows
     const float* qt = q + (size_t)r0 * dim; const float* lt = lse + r0; const float* st_ = row_scale + r0;

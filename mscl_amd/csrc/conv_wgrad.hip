@@ -291,11 +291,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const WGroup grp)
 }
 
 // bias gradients of the same group: column sums of every item's dy in one launch (colsum_kernel's loop; blockIdx.y = item)
-struct CGroupItem { const bf16_t* dy; float* dbias; long rows; int C; int blocks; };
+// (matrices wider than 512 columns: 512-column chunks along blockIdx.z, as colsum_kernel takes them along blockIdx.y; ldc = row pitch)
+struct CGroupItem { const bf16_t* dy; float* dbias; long rows; int C; int blocks; int ldc; int chunks; };
 struct CGroup { int n; CGroupItem it[MSCL_WGRAD_GROUP_MAX]; };
 __global__ __launch_bounds__(256) void colsum_group_kernel(const CGroup grp) {
-  const CGroupItem& it = grp.it[blockIdx.y];
-  if ((int)blockIdx.x >= it.blocks) return;
+  CGroupItem it = grp.it[blockIdx.y];
+  if ((int)blockIdx.x >= it.blocks || (int)blockIdx.z >= it.chunks) return;
+  it.dy += blockIdx.z * it.C; it.dbias += blockIdx.z * it.C;
   const int C = it.C, G = C / 8;
   const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void colsum_group_kernel(const CGroup grp) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const long r = r0 + u * stride;
-      v[u] = *reinterpret_cast<const uint4*>(it.dy + (r < it.rows ? r : r0) * C + tg * 8);
+      v[u] = *reinterpret_cast<const uint4*>(it.dy + (r < it.rows ? r : r0) * it.ldc + tg * 8);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -520,6 +522,7 @@ extern "C" int mscl_conv3d_wgrad_group(int n, const mscl_conv_desc* descs, const
   CGroup cg{};
   grp.n = n;
   long total = 0, cmax = 0;
+  int zmax = 1;
   for (int i = 0; i < n; ++i) {
     if (!x[i] || !dy[i] || !dw[i]) return MSCL_E_ARG;
     if (!mscl_conv3d_wgrad_groupable(&descs[i])) return MSCL_E_SHAPE;
@@ -534,10 +537,11 @@ extern "C" int mscl_conv3d_wgrad_group(int n, const mscl_conv_desc* descs, const
     if (total >= (1L << 30)) return MSCL_E_SHAPE;
     if (dbias && dbias[i]) {
       const mscl_conv_desc* d = &descs[i];
-      if (d->K > 512) return MSCL_E_SHAPE;
+      const int Kc = d->K > 512 ? 512 : d->K;                // K / 8 is a power of two (wgeom_of): 512 divides a wider K
       CGroupItem& c = cg.it[cg.n++];
-      c.dy = dy[i]; c.dbias = dbias[i]; c.rows = it.g.M; c.C = d->K;
-      const int RPc = 256 / (d->K / 8);
+      c.dy = dy[i]; c.dbias = dbias[i]; c.rows = it.g.M; c.C = Kc; c.ldc = d->K; c.chunks = d->K / Kc;
+      if (c.chunks > zmax) zmax = c.chunks;
+      const int RPc = 256 / (Kc / 8);
       long b = (c.rows + RPc * 4 - 1) / (RPc * 4); if (b > 256) b = 256; if (b < 1) b = 1;
       c.blocks = (int)b;
       if (b > cmax) cmax = b;
@@ -554,7 +558,7 @@ extern "C" int mscl_conv3d_wgrad_group(int n, const mscl_conv_desc* descs, const
   hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3((unsigned)total), dim3(256), lds, st, grp);
   MSCL_LAUNCH_CHECK();
   if (cg.n > 0) {
-    hipLaunchKernelGGL(colsum_group_kernel, dim3((unsigned)cmax, cg.n), dim3(256), 0, st, cg);
+    hipLaunchKernelGGL(colsum_group_kernel, dim3((unsigned)cmax, cg.n, zmax), dim3(256), 0, st, cg);
     MSCL_LAUNCH_CHECK();
   }
   ++g_wgrad_group_launches;

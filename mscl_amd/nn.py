@@ -128,7 +128,11 @@ class TransposeState:
     def sync_reader(self):
         sp = lib.stream_ptr()
         if sp not in self.waited:
-            torch.cuda.current_stream().wait_event(self.event)
+            # A capturing stream may not wait for an event recorded outside the capture (stream-capture isolation), and need not:
+            # whoever began the capture on it had this stream wait for its parent first (torch.cuda.graph: capture stream <- the
+            # caller's current stream), so what the refresh wrote is ordered before the captured launches.
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().wait_event(self.event)
             self.waited.add(sp)
 
 
@@ -305,6 +309,21 @@ class WGradQueue:
         q = self.queues.get(lib.stream_ptr())
         if q is not None and q[1]:
             self._flush(q[1])
+
+    def clear(self):
+        """drop everything queued and the pending end-of-backward hook, launching nothing.  For the paths on which a backward pass
+        did NOT reach its end-of-backward callbacks (the engine skips them when backward raises: an aborted capture, an
+        out-of-memory error the caller catches): the queued (conv, x, dy) items would otherwise be launched by the NEXT backward's
+        callback, reading operands of a pass that no longer exists (under an aborted capture: the released graph pool)."""
+        n = sum(len(items) for _, items in self.queues.values())
+        for _, items in self.queues.values():
+            del items[:]
+        self.queues.clear()
+        del _BackwardEnd.hooks[:]
+        return n
+
+    def pending(self):
+        return sum(len(items) for _, items in self.queues.values())
 
     def flush_all(self):
         """every stream's queue, each on its own stream (the end of a backward pass; the step's sync_streams joins the streams)"""

@@ -480,6 +480,10 @@ class QueryGraph:
             self.capture(body, x, trigger)
         except Exception as e:      # noqa: BLE001 -- nothing has executed during a capture: the eager launch below is still exact
             self.failed, self.error = True, f'{type(e).__name__}: {e}'
+            # ... but the aborted backward capture may have QUEUED deferred weight gradients whose operands live in the graph's
+            # private pool, and the engine skipped the end-of-backward callback that would have launched them: drop them, or the
+            # next real backward launches them on released memory (nn.WGradQueue.clear)
+            nn_hip.WGRADS.clear()
             return body(x)
         q, p = _ReplayFn.apply(x, anchor, self)
         return q, p, self.map_shape
@@ -1044,6 +1048,9 @@ class MSCLWithAug(nn.Module):
         Th = T2 // 2
         aug = self.aug_gpu
         K.ZEROS.reset(im_q.device)
+        # weight gradients left queued by a backward pass that raised (its end-of-backward callback never ran) belong to no pass any
+        # more: they are dropped here rather than launched by this step's backward on operands that may be gone
+        nn_hip.WGRADS.clear()
         dp = not parallel.single()
         sc = self._scal.dev                         # this step's words: uploaded by _upload_step_words on this stream
         ids = self.sup_head.mlvl_ids

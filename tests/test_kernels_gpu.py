@@ -1131,6 +1131,7 @@ def test_conv_wgrad_group(dev):
         (2, 4, 14, 14, 256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), None),
         (2, 4, 14, 14, 128, 256, (1, 1, 1), (2, 2, 2), (0, 0, 0), None),
         (1, 2, 7, 7, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), None),
+        (2, 2, 7, 7, 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), None),    # a biased layer wider than 512: column sums in two chunks
     ]
     n = len(specs)
     descs = (lib.ConvDesc * n)()

@@ -102,6 +102,63 @@ def _tap_lmcl():
             seq[0] = 0
         return tpn0(self, feats, levels=levels)
     necks.TPNSingleHip.forward = tpn_reset
+    if os.environ.get('FLAKE_DIAG'):
+        _route_through_diag()
+
+
+DIAG = {}
+
+
+def _route_through_diag():
+    """FLAKE_DIAG=1: every TRILINEAR up-sampling launch of the step goes through the self-checking twin of the kernel
+    (tools/diag/upsample_diag.hip, built by tools/diag/build.sh): both sides of every stage compared per lane, disagreements
+    recorded on the device with the wave's hardware ids; diag_report() prints the records that arrived since the last call"""
+    import ctypes
+    from mscl_amd import kernels as K
+    from mscl_amd.kernels import ptr, stream_ptr
+    lib_ = ctypes.CDLL(os.path.join(ROOT, 'tools', 'diag', 'libups_diag.so'))
+    lib_.ups_diag_upsample_add.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 10 + [ctypes.c_void_p]
+    lib_.ups_diag_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib_.ups_diag_use_b(int(os.environ.get('FLAKE_DIAG_USE_B', '0')))
+    DIAG.update(lib=lib_, seen=0, words=lib_.ups_diag_rec_words())
+    orig = K.upsample_add
+
+    def upsample_add(src, dst, trilinear, accumulate):
+        if not trilinear:
+            return orig(src, dst, trilinear, accumulate)
+        N, Ts, Hs, Ws, C = src.shape
+        _, Td, Hd, Wd, _ = dst.shape
+        rc = lib_.ups_diag_upsample_add(ptr(src), ptr(dst), N, Ts, Hs, Ws, Td, Hd, Wd, C, 1, int(accumulate), stream_ptr())
+        if rc:
+            raise RuntimeError(f'ups_diag_upsample_add -> {rc}')
+        return dst
+    K.upsample_add = upsample_add
+
+
+def diag_report(tag=''):
+    if not DIAG:
+        return
+    import ctypes
+    lib_, W = DIAG['lib'], DIAG['words']
+    cnt = (ctypes.c_uint * 8)()
+    rec = (ctypes.c_uint * (2048 * W))()
+    n = lib_.ups_diag_read(cnt, rec, 2048)
+    print(f'[diag{tag}] records {cnt[0]} (kept {n}), diag launches {cnt[1]}', flush=True)
+    import struct
+
+    def f32(u):
+        return struct.unpack('<f', struct.pack('<I', u))[0]
+    for i in range(DIAG['seen'], max(n, 0)):
+        R = rec[i * W:(i + 1) * W]
+        hw = R[6]
+        print(f'  rec {i}: off-mismatch {R[0] & 255:08b} wt-mismatch {(R[0] >> 8) & 255:08b} load-mismatch {(R[0] >> 16) & 255:08b} '
+              f'zeroA {(R[0] >> 24) & 255:08b} zeroB {R[1] & 255:08b} result-mismatch {(R[1] >> 8) & 255:08b} | launch {R[2]} block {R[3]} '
+              f'thread {R[4]} (lane {R[4] & 63}) e {R[5]} | HW_ID {hw:#010x} (wave {hw & 15} simd {(hw >> 4) & 3} cu {(hw >> 8) & 15} sh {(hw >> 12) & 1} '
+              f'se {(hw >> 13) & 7}) XCC {R[7] & 15} t {R[8] | (R[9] << 32)} | corner {R[10]} off {R[11]}/{R[12]} wt {f32(R[13]):.6f}/{f32(R[14]):.6f} '
+              f'A {R[15]:08x} {R[16]:08x} {R[17]:08x} {R[18]:08x} B {R[19]:08x} {R[20]:08x} {R[21]:08x} {R[22]:08x} C(after pause) {R[23]:08x} '
+              f'{R[24]:08x} {R[25]:08x} {R[26]:08x} | fA0 {f32(R[27]):.6g} fB0 {f32(R[28]):.6g} | total {R[29]} dims {R[30] & 255}x{(R[30] >> 8) & 255}x{R[30] >> 16} C {R[31]} '
+              f'| wtA {[round(f32(R[32 + j]), 5) for j in range(8)]} wtB {[round(f32(R[40 + j]), 5) for j in range(8)]}', flush=True)
+    DIAG['seen'] = max(n, DIAG['seen'])
 
 
 KEYS = ('lm_rgb', 'lm_flow', 'lm_sum', 'lm_hits', 'lm_drgb', 'lm_dflow', 'loss', 'G', 'Q', 'KX', 'Qb', 'Kb', 'queue', 'queue_flow', 'count', 'count_flow', 'buffers')
@@ -233,6 +290,8 @@ def main():
                               f'max |got - that| {float((g - dst.reshape(-1, C)[r].float()).abs().max()):.3g}, max |got - right| '
                               f'{float((g - want.reshape(-1, C)[r].float()).abs().max()):.3g}', flush=True)
         print(f'rep {rep} done, {bad} differing run(s) so far', flush=True)
+        if DIAG and (rep % 20 == 19 or rep == reps - 1):
+            diag_report(f' rep {rep}')
     lib.set_deterministic(False)
 
 
