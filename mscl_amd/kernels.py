@@ -29,28 +29,32 @@ def out_shape(d):
     return (d.N, d.To, d.Ho, d.Wo, d.K)
 
 
-def _splitk_floats(rows, chans):
-    """floats of fp32 scratch for split-K when the layer has too few position tiles to fill 256 CUs (else 0)."""
+def _splitk_floats(rows, chans, cap=16):
+    """floats of fp32 scratch for split-K when the layer has too few position tiles to fill 256 CUs (else 0).
+    cap: the most slabs the launch may use -- the library splits K over as many blocks as the scratch holds copies of the output
+    (csrc/conv_pp.hip, conv_igemm.hip), so the caller's scratch size IS the split policy: 16 = latency-optimal (the RGB query
+    chain, the step's critical chain), less for the chains that run beside it and only add to the sum of kernel time
+    (nn.Conv3dHip.split_cap, recognizers.MSCLWithAug.set_side_split); 1 = no split."""
     tiles = ((rows + 127) // 128) * ((chans + 127) // 128 if chans >= 128 else 1)
-    if tiles > 256 or chans < 64:
+    if tiles > 256 or chans < 64 or cap <= 1:
         return 0
-    return min(16, (512 + tiles - 1) // tiles) * rows * chans
+    return min(cap, 16, (512 + tiles - 1) // tiles) * rows * chans
 
 
-def _splitk_ws(rows, chans, device):
-    n = _splitk_floats(rows, chans)
+def _splitk_ws(rows, chans, device, cap=16):
+    n = _splitk_floats(rows, chans, cap)
     return torch.empty((n,), dtype=torch.float32, device=device) if n else None
 
 
-def fwd_ws_floats(d, stat_groups=0):
+def fwd_ws_floats(d, stat_groups=0, cap=16):
     """floats of fp32 scratch a forward conv wants: split-K slabs, and in deterministic mode the partials of the statistics pass
     (stat_groups > 0; the two uses follow one another on the stream, the larger size serves both)"""
     rows = d.N * d.To * d.Ho * d.Wo
-    return max(_splitk_floats(rows, d.K), lib.det_parts_floats(rows, d.K, stat_groups, 2) if stat_groups else 0)
+    return max(_splitk_floats(rows, d.K, cap), lib.det_parts_floats(rows, d.K, stat_groups, 2) if stat_groups else 0)
 
 
-def fwd_ws(d, device, stat_groups=0):
-    n = fwd_ws_floats(d, stat_groups)
+def fwd_ws(d, device, stat_groups=0, cap=16):
+    n = fwd_ws_floats(d, stat_groups, cap)
     return torch.empty((n,), dtype=torch.float32, device=device) if n else None
 
 
@@ -85,11 +89,11 @@ def prof_end(e0, mode, d):
     PROFILE['events'].append((mode, tuple(getattr(d, f) for f in _DESC_FIELDS), e0, e1))
 
 
-def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
+def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None, split_cap=16):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats = (sum, sumsq) fp32 K-vectors, pre-zeroed."""
     y = torch.empty(out_shape(d), dtype=torch.bfloat16, device=x.device)
     s0, s1 = stats if stats is not None else (None, None)
-    ws = fwd_ws(d, x.device, 1 if stats is not None else 0)
+    ws = fwd_ws(d, x.device, 1 if stats is not None else 0, split_cap)
     e0 = prof_begin()
     call('mscl_conv3d_fwd', ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(bias), ptr(addend), int(relu),
          ptr(s0), ptr(s1), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
@@ -97,9 +101,9 @@ def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None):
     return y
 
 
-def conv3d_dgrad(dy, wT, d, addend=None):
+def conv3d_dgrad(dy, wT, d, addend=None, split_cap=16):
     dx = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
-    ws = _splitk_ws(d.N * d.T * d.H * d.W, d.C, dy.device)
+    ws = _splitk_ws(d.N * d.T * d.H * d.W, d.C, dy.device, split_cap)
     e0 = prof_begin()
     call('mscl_conv3d_dgrad', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dx), ptr(addend), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())
     prof_end(e0, 'dgrad', d)

@@ -52,6 +52,7 @@ class Conv3dHip(nn.Module):
         self.p_exec = (self.padding[0], self.padding[1], 1) if self.pair_w else self.padding
         self._rt = None           # runtime views, set by materialize()
         self._plans = {}          # per input shape: cached descriptor / workspace size (cba_fwd)
+        self.split_cap = 16       # most split-K slabs a launch of this conv may use (kernels._splitk_floats): lower on side chains
         self._descs = {}
 
     def extra_repr(self):
@@ -68,7 +69,7 @@ class Conv3dHip(nn.Module):
         rt = self._rt
         if rt is None:
             raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
-        return K.conv3d_fwd(x, rt['w'], self.desc(x.shape), bias=rt['bias'], addend=addend, relu=relu, stats=stats)
+        return K.conv3d_fwd(x, rt['w'], self.desc(x.shape), bias=rt['bias'], addend=addend, relu=relu, stats=stats, split_cap=self.split_cap)
 
     def wT(self):
         """the transposed bf16 kernel the input-gradient kernels read, refreshed first if an optimizer step has left it behind the
@@ -82,7 +83,7 @@ class Conv3dHip(nn.Module):
         return self._rt['wT']
 
     def dgrad(self, dy, x_shape, addend=None):
-        return K.conv3d_dgrad(dy, self.wT(), self.desc(x_shape), addend=addend)
+        return K.conv3d_dgrad(dy, self.wT(), self.desc(x_shape), addend=addend, split_cap=self.split_cap)
 
     def wgrad(self, x, dy):
         """dw += ...: plain adds where one block owns an element (include/mscl_hip.h, mscl_conv3d_wgrad INVARIANT): every
@@ -173,11 +174,11 @@ def cba_fwd(conv, bn, x, residual, relu):
     if rt is None:
         raise MsclError('model not materialized on a GPU: call model.materialize(device) first')
     shape = tuple(x.shape)
-    pkey = (shape, lib.DET_GEN)        # (the scratch size below depends on the library's deterministic mode)
+    pkey = (shape, lib.DET_GEN, conv.split_cap)        # (the scratch size below depends on the library's deterministic mode and on the split policy)
     plan = conv._plans.get(pkey)
     if plan is None:
         d = conv.desc(shape)
-        plan = conv._plans[pkey] = (d, ctypes.byref(d), K.out_shape(d), K.fwd_ws_floats(d, 2 if d.N % 2 == 0 else 1),
+        plan = conv._plans[pkey] = (d, ctypes.byref(d), K.out_shape(d), K.fwd_ws_floats(d, 2 if d.N % 2 == 0 else 1, conv.split_cap),
                                      (d.N, d.T, d.H, d.W, d.C, d.K, d.kT))
     d, dref, oshape, ws_n, sig = plan
     C = conv.out_channels

@@ -980,6 +980,19 @@ class MSCLWithAug(nn.Module):
         chosen, self.stream_probe = pick_side_streams(cand, n, spin, _Comm() if use_comm else None)
         return chosen
 
+    def set_side_split(self, cap_key=16, cap_flow=16):
+        """Split-K policy per chain (round 6).  The step follows the SUM of kernel time over its three streams, and a split-K launch
+        buys its latency with slab traffic (k fp32 copies of the output written, read again by splitk_finalize): worth it on the RGB
+        query chain, which paces the step, not on the chains that run beside it.  cap_key / cap_flow: the most slabs a conv launch
+        of the RGB key encoder / of the flow recognizer (query and key) may use; the RGB query chain keeps 16.
+        (measured: profiles/r06_ab_sweeps.md)"""
+        for mods, cap in ((self.recognizer.k_modules(), cap_key),
+                          (self.recognizer_flow.q_modules() + self.recognizer_flow.k_modules(), cap_flow)):
+            for m in mods:
+                for c in m.modules():
+                    if isinstance(c, Conv3dHip):
+                        c.split_cap = int(cap)
+
     def sync_streams(self):
         """make the current stream wait for the flow stream (parameter gradients are written by kernels, not by
         autograd's AccumulateGrad, so the optimizer orders itself explicitly)"""

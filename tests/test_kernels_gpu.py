@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 BF16_TOL = 2.0 ** -7
 F32_TOL = 3e-4
@@ -698,7 +699,12 @@ def test_nce(R, K, dev):
     lse, lr, rk = K_.nce_forward(queue.to(dev), count.to(dev), q.detach().to(dev), pos.detach().to(dev), 1.0 / T)
     close(lse, torch.logsumexp(logits, 1), 1e-5, 'lse')
     close(lr, loss_rows, 2e-5, 'nce loss rows')
-    assert torch.equal(rk.cpu().long(), rank), (rk.cpu(), rank)
+    # the rank is a count of fp32 comparisons: a negative whose logit sits within rounding of the positive's may fall on either side
+    # (the MFMA chain, the vector chain and the CPU matmul add the 128 products in different orders), every other one may not
+    l64 = torch.cat([pos.double()[:, None], q.double() @ w.double()], 1) / T
+    near = ((l64[:, 1:] - l64[:, :1]).abs() <= 4e-6 * l64[:, :1].abs().clamp_min(1.0)).sum(1)
+    assert bool(((rk.cpu().long() - rank).abs() <= near).all()), (rk.cpu(), rank, near)
+    assert int(near.sum()) <= max(4, R), near      # (the allowance stays a handful of near-ties per pass -- ~1e-4 wide windows among 65536 logits -- not a tolerance on the count)
     scale = rnd((R,), 5).abs() + 0.1
     # gradient of sum_r scale_r * loss_r wrt q through the NEGATIVE logits only
     neg_only = (torch.logsumexp(torch.cat([pos.detach()[:, None], q @ w], 1) / T, 1) * scale).sum()
@@ -1175,3 +1181,26 @@ def test_conv_wgrad_group(dev):
     ctypes.memmove(ctypes.byref(d1[0]), ctypes.byref(K_.conv_desc((8, 16, 56, 56, 64), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1))), ctypes.sizeof(lib.ConvDesc))
     one = (ctypes.c_void_p * 1)(xs[0].data_ptr())
     assert lib.call_raw('mscl_conv3d_wgrad_group', 1, d1, one, one, one, None, lib.stream_ptr()) == -2
+
+
+def test_upsample_beside_conv_streams(dev):
+    """The stand-alone reproducer of round 5's "dropped corner" (tools/diag/flake_repro.hip: conv -> trilinear up-sampling on one
+    stream, bit-compared with its first result, while the key and flow trunks' convs run on two more streams in one captured HIP
+    graph; HIP runtime + C ABI only) against the PRODUCT library: 60 000 comparisons, none may differ.  With packed fp32
+    instructions in the up-sampling kernel the same run shows ~230 differing comparisons (profiles/r06_flake.md: a `v_pk_mul_f32`
+    with a cross-half op_sel returns zero in lanes 48-63 beside MFMA kernels of another hardware queue; three boxes); the library
+    is built without those instructions (csrc/build.sh checks its code objects).
+    Informational second run: the VALU probe of the same tool in the compiled kernel's instruction form -- it shows whether THIS
+    box exhibits the hardware behaviour at all (printed, not asserted)."""
+    import subprocess
+    from mscl_amd import lib
+    exe = os.path.join(ROOT, 'tools', 'diag', 'flake_repro')
+    assert os.path.exists(exe), 'tools/diag/flake_repro is missing: __graft_entry__.build() builds it (tools/diag/build.sh)'
+    r = subprocess.run([exe, '--lib', lib.LIB_PATH, '--replays', '3000'], capture_output=True, text=True, timeout=300)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith('SUMMARY') or 'reference launch' in ln]
+    print('\n'.join(tail))
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert any('comparisons 60000 differing 0 ' in ln for ln in tail), tail
+    p = subprocess.run([exe, '--lib', lib.LIB_PATH, '--replays', '2000', '--probe', '0', '--side', 'convs', '--streams', 'B'],
+                       capture_output=True, text=True, timeout=300)
+    print('\n'.join(ln for ln in p.stdout.splitlines() if ln.startswith('PROBE')))

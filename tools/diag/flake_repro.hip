@@ -62,43 +62,89 @@ __global__ void cmp_kernel(const uint4* got, const uint4* want, int n16) {
   if (threadIdx.x == 0) { if (any) atomicAdd(&g_cmp[1], 1u); g_cmp[0] = it + 1; }
 }
 
-// --probe: stream A runs THIS kernel instead of the conv -> up-sampling pair.  No memory traffic inside the loop: every lane forms the
-// eight trilinear weights from (a, b, c) the way the up-sampling kernel does, once with the PACKED fp32 multiplies hipcc emits there
-// (v_pk_mul_f32 with op_sel, inline asm so that the form is fixed) and once with plain v_mul_f32, and compares the two bit for bit.
-// g_probe[0] += iterations run, [1] += mismatching lanes in all, [2 + q] += those in lane quarter q, [6 + k] += those in weight k.
-__device__ unsigned g_probe[16];
+// --probe M: stream A runs THIS kernel instead of the conv -> up-sampling pair.  No memory traffic inside the loop: every lane forms the
+// eight trilinear weights from (a, b, c) the way the compiled up-sampling kernel does -- four "producer" products p = {(1-b)(1-a),
+// b(1-a), (1-b)a, ba}, each in BOTH halves of a register pair, then four "consumer" products w = (1-c, c) x p -- in the instruction
+// form M selects (inline asm, so the form is fixed), and compares every half of every result with plain v_mul_f32 arithmetic.
+//   M = 0  producers v_pk_mul_f32 with op_sel (what hipcc emits), consumers v_pk_mul_f32           (the compiled kernel's form)
+//   M = 1  producers plain v_mul_f32,                              consumers v_pk_mul_f32
+//   M = 2  producers v_pk_mul_f32 with op_sel,                     consumers plain v_mul_f32
+//   M = 3  as 0 with v_pk_fma_f32 (+ 0) in place of v_pk_mul_f32
+//   M = 4  all plain v_mul_f32 (control)
+//   M = 5  as 0 with an `s_nop 7` between any two packed instructions
+//   M = 6  producers plain v_mul_f32, consumers v_pk_add_f32 (w = (1-c, c) + p)
+// g_probe[0] += iterations, [1] += mismatching halves, [2 + q] += those in lane quarter q, [6 + i] += those in half i of
+// {p00.lo, p00.hi, p10.lo, p10.hi, p01.lo, p01.hi, p11.lo, p11.hi, w0 .. w7}.
+__device__ unsigned g_probe[32];
+template <int M>
 __global__ __launch_bounds__(256) void valu_probe_kernel(float a0, float b0, float c0, int iters) {
   const int lane = threadIdx.x & 63;
-  unsigned bad_k = 0, nbad = 0;
+  unsigned bad = 0, nbad = 0;
   float a = a0, b = b0, c = c0;
   for (int it = 0; it < iters; ++it) {
-    // operands in the register pairs the compiled kernel uses: (b, a), (1 - b, 1 - a), (1 - c, c)
     float2 ba = make_float2(b, a), nba = make_float2(1.f - b, 1.f - a), cc = make_float2(1.f - c, c);
-    float2 p00, p01, p10, p11, w01, w23, w45, w67;
-    asm volatile("v_pk_mul_f32 %0, %4, %4 op_sel:[0,1] op_sel_hi:[0,1]\n\t"      // (1-b)(1-a) in both halves
-                 "v_pk_mul_f32 %1, %5, %4 op_sel:[0,1] op_sel_hi:[0,1]\n\t"      // b (1-a)
-                 "v_pk_mul_f32 %2, %4, %5 op_sel:[0,1] op_sel_hi:[0,1]\n\t"      // (1-b) a
-                 "v_pk_mul_f32 %3, %5, %5 op_sel:[0,1] op_sel_hi:[0,1]\n\t"      // b a
-                 : "=&v"(p00), "=&v"(p10), "=&v"(p01), "=&v"(p11) : "v"(nba), "v"(ba));
-    asm volatile("s_nop 1\n\tv_pk_mul_f32 %0, %4, %5\n\tv_pk_mul_f32 %1, %4, %6\n\tv_pk_mul_f32 %2, %4, %7\n\tv_pk_mul_f32 %3, %4, %8\n\ts_nop 1"
-                 : "=&v"(w01), "=&v"(w23), "=&v"(w45), "=&v"(w67) : "v"(cc), "v"(p00), "v"(p10), "v"(p01), "v"(p11));
+    asm volatile("" : "+v"(ba), "+v"(nba), "+v"(cc));
+    float2 p00, p10, p01, p11, w01, w23, w45, w67;
+    if constexpr (M == 0 || M == 2) {
+      asm volatile("v_pk_mul_f32 %0, %4, %4 op_sel:[0,1] op_sel_hi:[0,1]\n\t"
+                   "v_pk_mul_f32 %1, %5, %4 op_sel:[0,1] op_sel_hi:[0,1]\n\t"
+                   "v_pk_mul_f32 %2, %4, %5 op_sel:[0,1] op_sel_hi:[0,1]\n\t"
+                   "v_pk_mul_f32 %3, %5, %5 op_sel:[0,1] op_sel_hi:[0,1]\n\ts_nop 1"
+                   : "=&v"(p00), "=&v"(p10), "=&v"(p01), "=&v"(p11) : "v"(nba), "v"(ba));
+    } else if constexpr (M == 5) {
+      asm volatile("s_nop 7\n\tv_pk_mul_f32 %0, %4, %4 op_sel:[0,1] op_sel_hi:[0,1]\n\ts_nop 7\n\t"
+                   "v_pk_mul_f32 %1, %5, %4 op_sel:[0,1] op_sel_hi:[0,1]\n\ts_nop 7\n\t"
+                   "v_pk_mul_f32 %2, %4, %5 op_sel:[0,1] op_sel_hi:[0,1]\n\ts_nop 7\n\t"
+                   "v_pk_mul_f32 %3, %5, %5 op_sel:[0,1] op_sel_hi:[0,1]\n\ts_nop 7"
+                   : "=&v"(p00), "=&v"(p10), "=&v"(p01), "=&v"(p11) : "v"(nba), "v"(ba));
+    } else if constexpr (M == 3) {
+      asm volatile("v_pk_fma_f32 %0, %4, %4, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\t"
+                   "v_pk_fma_f32 %1, %5, %4, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\t"
+                   "v_pk_fma_f32 %2, %4, %5, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\t"
+                   "v_pk_fma_f32 %3, %5, %5, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\ts_nop 1"
+                   : "=&v"(p00), "=&v"(p10), "=&v"(p01), "=&v"(p11) : "v"(nba), "v"(ba));
+    } else {
+      asm volatile("v_mul_f32 %0, %4, %5\n\tv_mul_f32 %1, %6, %5\n\tv_mul_f32 %2, %4, %7\n\tv_mul_f32 %3, %6, %7\n\ts_nop 1"
+                   : "=&v"(p00.x), "=&v"(p10.x), "=&v"(p01.x), "=&v"(p11.x) : "v"(nba.x), "v"(nba.y), "v"(ba.x), "v"(ba.y));
+      p00.y = p00.x; p10.y = p10.x; p01.y = p01.x; p11.y = p11.x;
+      asm volatile("" : "+v"(p00), "+v"(p10), "+v"(p01), "+v"(p11));
+    }
+    if constexpr (M == 0 || M == 1) {
+      asm volatile("v_pk_mul_f32 %0, %4, %5\n\tv_pk_mul_f32 %1, %4, %6\n\tv_pk_mul_f32 %2, %4, %7\n\tv_pk_mul_f32 %3, %4, %8\n\ts_nop 1"
+                   : "=&v"(w01), "=&v"(w23), "=&v"(w45), "=&v"(w67) : "v"(cc), "v"(p00), "v"(p10), "v"(p01), "v"(p11));
+    } else if constexpr (M == 5) {
+      asm volatile("s_nop 7\n\tv_pk_mul_f32 %0, %4, %5\n\ts_nop 7\n\tv_pk_mul_f32 %1, %4, %6\n\ts_nop 7\n\tv_pk_mul_f32 %2, %4, %7\n\ts_nop 7\n\tv_pk_mul_f32 %3, %4, %8\n\ts_nop 7"
+                   : "=&v"(w01), "=&v"(w23), "=&v"(w45), "=&v"(w67) : "v"(cc), "v"(p00), "v"(p10), "v"(p01), "v"(p11));
+    } else if constexpr (M == 6) {
+      asm volatile("v_pk_add_f32 %0, %4, %5\n\tv_pk_add_f32 %1, %4, %6\n\tv_pk_add_f32 %2, %4, %7\n\tv_pk_add_f32 %3, %4, %8\n\ts_nop 1"
+                   : "=&v"(w01), "=&v"(w23), "=&v"(w45), "=&v"(w67) : "v"(cc), "v"(p00), "v"(p10), "v"(p01), "v"(p11));
+    } else if constexpr (M == 3) {
+      asm volatile("v_pk_fma_f32 %0, %4, %5, 0\n\tv_pk_fma_f32 %1, %4, %6, 0\n\tv_pk_fma_f32 %2, %4, %7, 0\n\tv_pk_fma_f32 %3, %4, %8, 0\n\ts_nop 1"
+                   : "=&v"(w01), "=&v"(w23), "=&v"(w45), "=&v"(w67) : "v"(cc), "v"(p00), "v"(p10), "v"(p01), "v"(p11));
+    } else {
+      asm volatile("v_mul_f32 %0, %8, %10\n\tv_mul_f32 %1, %9, %11\n\tv_mul_f32 %2, %8, %12\n\tv_mul_f32 %3, %9, %13\n\t"
+                   "v_mul_f32 %4, %8, %14\n\tv_mul_f32 %5, %9, %15\n\tv_mul_f32 %6, %8, %16\n\tv_mul_f32 %7, %9, %17\n\ts_nop 1"
+                   : "=&v"(w01.x), "=&v"(w01.y), "=&v"(w23.x), "=&v"(w23.y), "=&v"(w45.x), "=&v"(w45.y), "=&v"(w67.x), "=&v"(w67.y)
+                   : "v"(cc.x), "v"(cc.y), "v"(p00.x), "v"(p00.y), "v"(p10.x), "v"(p10.y), "v"(p01.x), "v"(p01.y), "v"(p11.x), "v"(p11.y));
+    }
+    // expected values: exact multiples of 1/64, so association and fusion cannot matter
     const float na = 1.f - a, nb = 1.f - b, nc = 1.f - c;
-    const float e[8] = {na * nb * nc, na * nb * c, na * b * nc, na * b * c, a * nb * nc, a * nb * c, a * b * nc, a * b * c};
-    const float g[8] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y, w67.x, w67.y};
-    // (the reference products associate as (x y) z like the packed ones: (1-a)(1-b) first, then the c factor)
-    const float r[8] = {(nb * na) * nc, (nb * na) * c, (b * na) * nc, (b * na) * c, (nb * a) * nc, (nb * a) * c, (b * a) * nc, (b * a) * c};
-    (void)e;
+    const float ep[4] = {nb * na, b * na, nb * a, b * a};
+    const float gp[8] = {p00.x, p00.y, p10.x, p10.y, p01.x, p01.y, p11.x, p11.y};
+    const float gw[8] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y, w67.x, w67.y};
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (__float_as_uint(g[k]) != __float_as_uint(r[k])) { bad_k |= 1u << k; ++nbad; }
-    // next operands: still exact quarters, varied so that nothing folds
+    for (int k = 0; k < 8; ++k) {
+      if (__float_as_uint(gp[k]) != __float_as_uint(ep[k >> 1])) { bad |= 1u << k; ++nbad; }
+      const float ew = M == 6 ? ep[k >> 1] + ((k & 1) ? c : nc) : ep[k >> 1] * ((k & 1) ? c : nc);
+      if (__float_as_uint(gw[k]) != __float_as_uint(ew)) { bad |= 1u << (8 + k); ++nbad; }
+    }
     a = a == 0.25f ? 0.75f : 0.25f; b = b == 0.75f ? 0.25f : 0.75f; c = (it & 2) ? 0.25f : 0.75f;
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
   }
-  if (lane == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_probe[0], (unsigned)iters);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_probe[0], (unsigned)iters);
   if (nbad) {
     atomicAdd(&g_probe[1], nbad); atomicAdd(&g_probe[2 + (lane >> 4)], nbad);
-    for (int k = 0; k < 8; ++k) if (bad_k >> k & 1) atomicAdd(&g_probe[6 + k], 1u);
+    for (int k = 0; k < 16; ++k) if (bad >> k & 1) atomicAdd(&g_probe[6 + k], 1u);
   }
 }
 
@@ -139,7 +185,7 @@ static std::vector<Layer> trunk(bool flow) {
 
 int main(int argc, char** argv) {
   std::string libp = "mscl_amd/csrc/libmscl_hip.so", diagp, side = "both";
-  long replays = 2000; int reps = 20; bool eager = false, one_stream = false, probe = false;
+  long replays = 2000; int reps = 20; bool eager = false, one_stream = false, probe = false; int pmode = 0;
   int lay_lo = 0, lay_hi = 1000; std::string streams = "BC";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -150,7 +196,7 @@ int main(int argc, char** argv) {
     else if (a == "--side" && i + 1 < argc) side = argv[++i];
     else if (a == "--eager") eager = true;
     else if (a == "--one-stream") one_stream = true;
-    else if (a == "--probe") probe = true;
+    else if (a == "--probe") { probe = true; if (i + 1 < argc && argv[i + 1][0] != '-') pmode = atoi(argv[++i]); }
     else if (a == "--streams" && i + 1 < argc) streams = argv[++i];                       // which side chains run: B, C or BC
     else if (a == "--layers" && i + 1 < argc) { sscanf(argv[++i], "%d:%d", &lay_lo, &lay_hi); }   // side layers [lo, hi) of each trunk list
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -190,7 +236,17 @@ int main(int argc, char** argv) {
 
   auto chainA = [&](int n, bool compare) {
     if (probe) {
-      for (int r = 0; r < n; ++r) hipLaunchKernelGGL(valu_probe_kernel, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64);
+      for (int r = 0; r < n; ++r) {
+        switch (pmode) {
+          case 0: hipLaunchKernelGGL(valu_probe_kernel<0>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+          case 1: hipLaunchKernelGGL(valu_probe_kernel<1>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+          case 2: hipLaunchKernelGGL(valu_probe_kernel<2>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+          case 3: hipLaunchKernelGGL(valu_probe_kernel<3>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+          case 4: hipLaunchKernelGGL(valu_probe_kernel<4>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+          case 6: hipLaunchKernelGGL(valu_probe_kernel<6>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+          default: hipLaunchKernelGGL(valu_probe_kernel<5>, dim3(32), dim3(256), 0, sA, 0.25f, 0.75f, 0.25f, 64); break;
+        }
+      }
       return;
     }
     for (int r = 0; r < n; ++r) {
@@ -318,9 +374,10 @@ int main(int argc, char** argv) {
     }
   }
   if (probe) {
-    unsigned pr[16]; CHECK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr)));
-    printf("PROBE iterations/lane %u, lanes x iterations compared %.3g, mismatching lane-results %u; by lane quarter %u %u %u %u; by weight %u %u %u %u %u %u %u %u\n",
-           pr[0], (double)pr[0] * 32 * 256, pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13]);
+    unsigned pr[32]; CHECK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr)));
+    printf("PROBE form %d: iterations/lane %u, lanes x iterations %.3g, mismatching halves %u; by lane quarter %u %u %u %u; producers p00.lo..p11.hi %u %u %u %u %u %u %u %u; "
+           "consumers w0..w7 %u %u %u %u %u %u %u %u\n", pmode, pr[0], (double)pr[0] * 32 * 256, pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11],
+           pr[12], pr[13], pr[14], pr[15], pr[16], pr[17], pr[18], pr[19], pr[20], pr[21]);
   }
   printf("SUMMARY comparisons %u differing %u differing_granules %u elapsed_ms %.1f us_per_rep %.2f\n", cmp[0], cmp[1], cmp[2], ms,
          1e3 * ms / ((double)replays * reps));
