@@ -637,6 +637,7 @@ int mscl_conv_thin(int planes, int H, int W, int C, int K, int flip, const bf16_
 int mscl_conv_stem(const mscl_conv_desc* d, const bf16_t* x, const bf16_t* w, bf16_t* y, float* ssum, float* ssq, hipStream_t st);   // conv_stem.hip
 int mscl_conv_k1(long M, int K, int N, const bf16_t* src, const bf16_t* wgt, bf16_t* out, const bf16_t* addend, float* ssum, float* ssq,
                  hipStream_t st);                                                                                      // conv_k1.hip
+int mscl_launch_dgrad_s2(const mscl_conv_desc* d, const bf16_t* dy, const bf16_t* wT, bf16_t* dx, const bf16_t* addend, hipStream_t st);   // conv_dgrad_s2.hip
 static bool unit_1x1x1(const mscl_conv_desc* d) {
   return d->kT == 1 && d->kH == 1 && d->kW == 1 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 && d->pH == 0 && d->pW == 0;
 }
@@ -711,6 +712,10 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
   }
   if (unit_1x1x1(d)) {
     const int h = mscl_conv_k1((long)d->N * d->T * d->H * d->W, d->K, d->C, dy, wT, dx, addend, nullptr, nullptr, (hipStream_t)stream);
+    if (h != 0) return h == 1 ? 0 : h;
+  }
+  {   // 3x3x3 / stride 2 entry conv of a stage on a large map: dy window resident in LDS, all eight parity classes from it (conv_dgrad_s2.hip)
+    const int h = mscl_launch_dgrad_s2(d, dy, wT, dx, addend, (hipStream_t)stream);
     if (h != 0) return h == 1 ? 0 : h;
   }
   IGemmGeom g{};

@@ -134,10 +134,13 @@ REAL_CASES = [
 def test_conv_real_layer_shapes(case, dev):
     from mscl_amd import lib
     n_halo, n_wh = lib.call_raw('mscl_debug_halo_launches'), lib.call_raw('mscl_debug_wgrad_halo_launches')
+    n_s2 = lib.call_raw('mscl_debug_dgrad_s2_launches')
     test_conv_fwd_dgrad_wgrad(case, dev)
     if case[0] in ('real_l2_128_128', 'real_l3_256_256'):
         # since round 4 the 128- / 256-channel 3x3x3 layers run the window-resident weight gradient as 64 x 64 channel slices
         assert lib.call_raw('mscl_debug_wgrad_halo_launches') == n_wh + 2, f'{case[0]} did not take the window-resident weight gradient'
+    if case[0] == 'real_l2_entry_64_128_s2':
+        assert lib.call_raw('mscl_debug_dgrad_s2_launches') == n_s2 + 2, 'the layer-2 entry input gradient did not take the window-resident kernel'
     if case[0] == 'real_l1_64_64':
         # the forward with statistics, 2 input gradients (plain / + addend), 2 weight gradients (the forward with bias + ReLU is the
         # implicit-GEMM family's: the window-resident kernel has no such epilogue)
@@ -1204,3 +1207,48 @@ def test_upsample_beside_conv_streams(dev):
     p = subprocess.run([exe, '--lib', lib.LIB_PATH, '--replays', '2000', '--probe', '0', '--side', 'convs', '--streams', 'B'],
                        capture_output=True, text=True, timeout=300)
     print('\n'.join(ln for ln in p.stdout.splitlines() if ln.startswith('PROBE')))
+
+
+# conv_dgrad_s2.hip (round 6): the window-resident input gradient of a 3x3x3 / stride-2 / pad-1 entry conv, forced onto small maps
+# (MSCL_DGRAD_S2=2; by default only maps that give nearly every CU a 256-cell tile take it): one tile per plane with a ragged end,
+# odd extents on every axis (the last odd output of an axis does not exist; T' + 1 runs past the clip), two output-channel tiles and
+# four dy-channel chunks, several tiles per plane; launch counter, addend, and a repeat-launch race screen on the DMA rings.
+S2_CASES = [
+    # name, N,T,H,W, C (dx), K (dy)
+    ('s2_64_128', 2, 8, 24, 24, 64, 128),
+    ('s2_odd', 1, 7, 23, 21, 64, 128),
+    ('s2_128_256', 1, 4, 20, 20, 128, 256),
+    ('s2_tiles', 1, 4, 44, 40, 64, 128),               # 22 x 21 padded cells = 462: two tiles per plane, the second ragged
+]
+
+
+@pytest.mark.parametrize('case', S2_CASES, ids=[c[0] for c in S2_CASES])
+def test_conv_dgrad_s2(case, dev):
+    from mscl_amd import kernels as K_, lib
+    name, N, T, H, W, C, K = case
+    kern, st, pad = (3, 3, 3), (2, 2, 2), (1, 1, 1)
+    x = rnd((N, T, H, W, C), 31).requires_grad_(True); w = bf(rnd((K, *kern, C), 32, scale=(2.0 / (C * 27)) ** 0.5))
+    d = K_.conv_desc((N, T, H, W, C), K, kern, st, pad)
+    yr = _conv_ref(x, w.float(), st, pad)
+    dy = bf(rnd(tuple(yr.shape), 33))
+    yr.backward(dy.float())
+    wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(w.to(dev), wT, K, 27, C)
+    os.environ['MSCL_DGRAD_S2'] = '2'
+    lib.call_raw('mscl_tuning_reload')
+    try:
+        n0 = lib.call_raw('mscl_debug_dgrad_s2_launches')
+        dx = K_.conv3d_dgrad(dy.to(dev), wT, d)
+        assert lib.call_raw('mscl_debug_dgrad_s2_launches') == n0 + 1, 'the window-resident kernel did not take the launch'
+        close(dx, x.grad, BF16_TOL, 's2 dgrad')
+        add = bf(rnd((N, T, H, W, C), 34))
+        close(K_.conv3d_dgrad(dy.to(dev), wT, d, addend=add.to(dev)), x.grad + add.float(), BF16_TOL, 's2 dgrad + addend')
+        for _ in range(10):
+            assert torch.equal(K_.conv3d_dgrad(dy.to(dev), wT, d), dx)
+        # and the same arithmetic as the implicit-GEMM parity classes up to the order of the fp32 sums
+        os.environ['MSCL_DGRAD_S2'] = '0'
+        lib.call_raw('mscl_tuning_reload')
+        close(K_.conv3d_dgrad(dy.to(dev), wT, d), dx, BF16_TOL, 's2 vs parity classes')
+    finally:
+        os.environ.pop('MSCL_DGRAD_S2', None)
+        lib.call_raw('mscl_tuning_reload')

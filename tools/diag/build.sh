@@ -15,7 +15,7 @@ if [ "$1" = "variants" ] && git -C ../.. rev-parse d4d050e^ >/dev/null 2>&1 && [
   mkdir -p build
   git -C ../.. show d4d050e^:mscl_amd/csrc/elementwise.hip > build/elementwise_orig.hip
   $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -I../../mscl_amd/csrc -c build/elementwise_orig.hip -o build/elementwise_orig.o
-  OBJS=""; for f in conv_igemm conv_pp conv_thin conv_k1 conv_halo conv_stem conv_wgrad conv_wgrad_halo bn_act pool3d color_aug datapath contrast optim; do OBJS="$OBJS ../../mscl_amd/csrc/build/$f.o"; done
+  OBJS=""; for f in conv_igemm conv_pp conv_dgrad_s2 conv_thin conv_k1 conv_halo conv_stem conv_wgrad conv_wgrad_halo bn_act pool3d color_aug datapath contrast optim; do OBJS="$OBJS ../../mscl_amd/csrc/build/$f.o"; done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o libmscl_hip_orig.so $OBJS build/elementwise_orig.o
   echo "built $(pwd)/libmscl_hip_orig.so"
   # the same kernel compiled WITHOUT packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32), two ways
