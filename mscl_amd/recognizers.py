@@ -777,6 +777,9 @@ class MSCLWithAug(nn.Module):
             if isinstance(m, Conv3dHip) or m is rgb.mlp_q:
                 m._bucket_counter = neck_counter
         self.sync_shadows()
+        # split-K policy of the chains beside the RGB query chain: 4 slabs instead of 16 measured the same step rate within noise
+        # (1197 vs 1193 clip-pairs/s, six alternating graphs in one process: profiles/r06_ab_sweeps.md) at a quarter of the slab traffic
+        self.set_side_split(4, 4)
         return self
 
     def _bind(self, m, ar, key, rec):
