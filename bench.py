@@ -55,12 +55,15 @@ def stage_table(events):
         else:
             name, cin, taps = ('flow trunk' if C <= 64 and kT == 1 else 'neck / shortcuts (1x1x1, 1x3x3, small 3x3x3)'), C, kT * kH * kW
         gf = 2.0 * N * To * Ho * Wo * K * taps * cin * 1e-9
-        a = acc.setdefault(name, {}).setdefault(mode, [0.0, 0.0, 0])
-        a[0] += gf; a[1] += e0.elapsed_time(e1) * share; a[2] += 1
+        a = acc.setdefault(name, {}).setdefault(mode, [0.0, 0.0, 0, 0])
+        a[0] += gf; a[1] += e0.elapsed_time(e1) * share; a[2] += 1; a[3] += 1 if len(ev) > 4 else 0
     out = {}
     for name, modes in acc.items():
-        out[name] = {m: {'launches': v[2], 'gflop': round(v[0], 2), 'ms': round(v[1], 4),
-                         'tflops': round(v[0] / max(v[1], 1e-9), 1), 'frac': round(v[0] / max(v[1], 1e-9) / PEAK_BF16_TFLOPS, 4)}
+        out[name] = {m: dict({'launches': v[2], 'gflop': round(v[0], 2), 'ms': round(v[1], 4),
+                              'tflops': round(v[0] / max(v[1], 1e-9), 1), 'frac': round(v[0] / max(v[1], 1e-9) / PEAK_BF16_TFLOPS, 4)},
+                             # layers that went out in a grouped launch (nn.WGradQueue): their time is a FLOP-share split of ONE event pair
+                             # around the whole group -- an approximation, not a per-layer measurement
+                             **({'flop_share_of_grouped_launch': v[3]} if v[3] else {}))
                      for m, v in modes.items()}
     return out
 
