@@ -22,8 +22,9 @@
 // the weight tile three steps ahead | fragment reads of the NEXT step | 32 MFMAs of this step]: reads and DMA of one wave run under
 // its own MFMAs (one wave per SIMD), one barrier per 512 MFMA cycles.
 // Per block 56.6 MMAC = 6912 MFMAs; LDS reads 16 ds_read_b128 per 32 MFMAs; DMA 8 KB of weights + 4 KB of window per step.
-// Measured (layer-2 entry, 22.2 GFLOP, tools/bench_conv.py): 75.8 us on the parity-class kernel -> 46.7 us = 475 TFLOP/s = 0.19 of the
-// MFMA peak.  With parts switched off (a study build): loop skeleton + prologues + epilogues 27 us, + DMA and fragment reads 36 us,
+// Measured (layer-2 entry, 22.2 GFLOP): 75.7 us on the parity-class kernel -> 55.9 us alone (tools/bench_conv.py); WITH the addend the step
+// passes (the shortcut's input gradient: 51 MB more to read) 87.9 -> 56.8 us.  (A form that fetched the addend inside the store loop ran
+// 46.7 us without an addend and 86.9 us with one: eight dependent HBM round trips per class.)  With parts switched off (a study build): loop skeleton + prologues + epilogues 27 us, + DMA and fragment reads 36 us,
 // + MFMAs 48 us -- the three add up, because ONE block per CU (256 accumulators per lane) leaves nothing to run under a block's
 // store-heavy epilogue or its prologue.  On the way: the shared implicit-GEMM epilogue inlined four times beside the accumulators
 // spilled 388 bytes per lane to scratch (64.5 -> 48.1 us when the rows went through LDS instead); weight tiles three steps ahead
@@ -231,6 +232,19 @@ __global__ __launch_bounds__(256, 1) void dgrad_s2_kernel(const S2Geom g, const 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ph = c >> 1, pw = c & 1;
+      // the eight rows this thread stores for the class, and (ahead of everything else: they come from HBM) their addend pieces
+      int orow8[8]; uint4 add8[8];          // (element offsets below 2^31: the launcher checks)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int item = it * 256 + tid, cell = item >> 3, g8 = item & 7;
+        const int q = q0 + cell;
+        const int hq = fdiv(q, g.dWq), wq = q - hq * g.Wq;
+        const int t = 2 * tp + pt, h = 2 * hq + ph, w = 2 * wq + pw;
+        const bool ok = q < g.cells && wq < g.Wp && h < g.H && w < g.W;
+        orow8[it] = ok ? (((n * g.T + t) * g.H + h) * g.W + w) * g.Ci + 64 * nt + 8 * g8 : -1;
+        add8[it] = make_uint4(0, 0, 0, 0);
+        if (addend != nullptr && ok) add8[it] = *reinterpret_cast<const uint4*>(addend + orow8[it]);
+      }
       __syncthreads();                          // the tiles (or the previous class's rows) are dead
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -238,24 +252,19 @@ __global__ __launch_bounds__(256, 1) void dgrad_s2_kernel(const S2Geom g, const 
         for (int j = 0; j < 4; ++j)
           *reinterpret_cast<f32x4_t*>(stg + (wm0 + 16 * i + fr) * SP + 16 * j + 4 * fq) = acc[c][j][i];
       __syncthreads();
-#pragma unroll 2
+#pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int item = it * 256 + tid, cell = item >> 3, g8 = item & 7;
-        const int q = q0 + cell;
-        const int hq = fdiv(q, g.dWq), wq = q - hq * g.Wq;
-        const int t = 2 * tp + pt, h = 2 * hq + ph, w = 2 * wq + pw;
-        if (q < g.cells && wq < g.Wp && h < g.H && w < g.W) {
-          const long o = ((((long)n * g.T + t) * g.H + h) * g.W + w) * g.Ci + 64 * nt + 8 * g8;
+        if (orow8[it] >= 0) {
           const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(stg + cell * SP + 8 * g8), v1 = *reinterpret_cast<const f32x4_t*>(stg + cell * SP + 8 * g8 + 4);
           float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if (addend != nullptr) {
-            float a8[8]; unpack8(*reinterpret_cast<const uint4*>(addend + o), a8);
+          float a8[8]; unpack8(add8[it], a8);              // (zeros without an addend)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] += a8[k];
-          }
-          *reinterpret_cast<uint4*>(dx + o) = pack8(f);
+          for (int k = 0; k < 8; ++k) f[k] += a8[k];
+          *reinterpret_cast<uint4*>(dx + orow8[it]) = pack8(f);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);        // (one class at a time: hoisting the next class's addresses and addend loads spills)
     }
   }
 }
@@ -270,6 +279,7 @@ int mscl_launch_dgrad_s2(const mscl_conv_desc* d, const bf16_t* dy, const bf16_t
   const int Wq = d->Wo + 1;
   if (S2_CM + Wq + 1 > S2_AROWS) return 0;                      // the window of a tile: 256 + W' + 2 rows
   if ((long)d->N * d->To * d->Ho * d->Wo * d->K * 2 >= (1L << 31) || (long)d->C * 27 * d->K * 2 >= (1L << 31)) return 0;
+  if ((long)d->N * d->T * d->H * d->W * d->C >= (1L << 31)) return 0;          // 32-bit element offsets into dx
   static MsclTune t_on("MSCL_DGRAD_S2");                        // A/B aid: 0 = the implicit-GEMM parity classes; 2 = also on small maps (tests)
   const int level = t_on.get(1);
   if (level == 0) return 0;
