@@ -639,9 +639,9 @@ extern "C" int mscl_nce_fwd_virt(const float* queue, const int64_t* count, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  static MsclTune t_mfma("MSCL_NCE_MFMA");               // A/B aid: 0 = the vector kernels
-  // (K % 4, dim % 16: a lane reads four columns of a queue row and four channels of a query row as 16-byte pieces; 32-bit byte offsets)
-  const bool mfma = K % 4 == 0 && dim % 16 == 0 && (long)dim * K * 4 < (1L << 31) && t_mfma.get(1) != 0;
+  // (K % 4, dim % 16: a lane reads four columns of a queue row and four channels of a query row as 16-byte pieces; 32-bit byte
+  // offsets; every other shape stays with the vector kernels.  The round-6 A/B of the two inside the step is profiles/r06_ab_step.txt)
+  const bool mfma = K % 4 == 0 && dim % 16 == 0 && (long)dim * K * 4 < (1L << 31);
   for (int r0 = 0; r0 < R; r0 += NCE_ROW_TILE) {
     const int Rt = R - r0 < NCE_ROW_TILE ? R - r0 : NCE_ROW_TILE;
     const int rt = Rt <= 8 ? 8 : (Rt <= 16 ? 16 : (Rt <= 24 ? 24 : 32));
@@ -698,8 +698,7 @@ extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  static MsclTune t_mfma("MSCL_NCE_MFMA");               // A/B aid: 0 = the vector kernels
-  const bool mfma = K % 4 == 0 && dim % 16 == 0 && (long)dim * K * 4 < (1L << 31) && t_mfma.get(1) != 0;
+  const bool mfma = K % 4 == 0 && dim % 16 == 0 && (long)dim * K * 4 < (1L << 31);
   static bool attr_m = false;
   if (mfma && !attr_m) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_bwd_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -717,6 +716,7 @@ extern "C" int mscl_nce_bwd_virt(const float* queue, const int64_t* count, const
       if (Rt <= 16) hipLaunchKernelGGL(nce_bwd_mfma_kernel<1>, dim3(nb), dim3(256), ldsm, st, queue, count, qt, lt, st_, ws, Rt, rt, dim, K, inv_T, vt);
       else hipLaunchKernelGGL(nce_bwd_mfma_kernel<2>, dim3(nb), dim3(256), ldsm, st, queue, count, qt, lt, st_, ws, Rt, rt, dim, K, inv_T, vt);
       MSCL_LAUNCH_CHECK();
+      // (32 slab columns: swept again for the 256 slabs of this form -- 4 / 8 / 16 / 32 / 64: 26.7 / 24.3 / 23.0 / 22.8 / 23.6 us per call pair at 24 rows)
       hipLaunchKernelGGL(nce_bwd_reduce_kernel, dim3((Rt * dim + 255) / 256, mscl_det() ? 1 : 32), dim3(256), 0, st, (const float*)ws,
                          dq + (size_t)r0 * dim, nb, rt, Rt, dim, kpos ? kpos + (size_t)r0 * dim : nullptr, kpos ? pos_logit + r0 : nullptr, lt, st_,
                          inv_T);
@@ -840,7 +840,10 @@ extern "C" int mscl_queue_enqueue(float* queue, int64_t* count, int64_t* ptr, co
 #define LMCL_MAX_B 4096
 __device__ float g_lmcl_part[LMCL_MAX_B];
 __device__ unsigned g_lmcl_ticket;
-__global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb, const float* __restrict__ flow,
+// (round 6: 1024 threads per clip instead of 256 -- the kernel is a string of short phases on ONE block per clip, eight CUs in all, on the
+// step's serial loss phase: 25 us under the tracer; sixteen waves share the 24 normalisations, the 128 frame-pair products and the
+// gradient rows four times as wide)
+__global__ __launch_bounds__(1024) void lmcl_kernel(const float* __restrict__ rgb, const float* __restrict__ flow,
                                                    float* __restrict__ loss_sum, int32_t* __restrict__ hits,
                                                    float* __restrict__ drgb, float* __restrict__ dflow, int B, int t, int C,
                                                    float inv_T, int det) {
@@ -854,9 +857,10 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
   float* gr = sim + t * t2;          // [t][C]  grad wrt normalised rgb
   float* gf = gr + t * C;            // [2t][C]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NW = (int)blockDim.x >> 6, NT = (int)blockDim.x;
   float* lrow = gf + t2 * C;          // [t] per-frame loss terms of this clip, added up in frame order by one thread
   const float* rb = rgb + (long)b * t * C; const float* fb = flow + (long)b * t2 * C;
-  for (int row = wave; row < t + t2; row += 4) {
+  for (int row = wave; row < t + t2; row += NW) {
     const float* src = row < t ? rb + row * C : fb + (row - t) * C;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += src[c] * src[c];
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
     if (lane == 0) { if (row < t) nr[row] = nrm; else nf[row - t] = nrm; }
   }
   __syncthreads();
-  for (int e = wave; e < t * t2; e += 4) {
+  for (int e = wave; e < t * t2; e += NW) {
     const int i = e / t2, j = e % t2;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += xr[i * C + c] * xf[j * C + c];
@@ -907,20 +911,20 @@ __global__ __launch_bounds__(256) void lmcl_kernel(const float* __restrict__ rgb
       }
     }
   }
-  for (int e = tid; e < t * C; e += 256) {
+  for (int e = tid; e < t * C; e += NT) {
     const int i = e / C, c = e % C;
     float s = 0.f;
     for (int j = 0; j < t2; ++j) s += sim[i * t2 + j] * xf[j * C + c];
     gr[e] = s;
   }
-  for (int e = tid; e < t2 * C; e += 256) {
+  for (int e = tid; e < t2 * C; e += NT) {
     const int j = e / C, c = e % C;
     float s = 0.f;
     for (int i = 0; i < t; ++i) s += sim[i * t2 + j] * xr[i * C + c];
     gf[e] = s;
   }
   __syncthreads();
-  for (int row = wave; row < t + t2; row += 4) {
+  for (int row = wave; row < t + t2; row += NW) {
     const bool isr = row < t;
     const float* n8 = isr ? xr + row * C : xf + (row - t) * C;
     const float* g8 = isr ? gr + row * C : gf + (row - t) * C;
@@ -942,7 +946,7 @@ extern "C" int mscl_lmcl(const float* rgb, const float* flow, float* loss_sum, i
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lmcl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   const int det = (mscl_det() && B <= LMCL_MAX_B) ? 1 : 0;
   if (mscl_det() && !det) return MSCL_E_SHAPE;
-  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, det);
+  hipLaunchKernelGGL(lmcl_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, rgb, flow, loss_sum, hits, drgb, dflow, B, t, C, inv_T, det);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

@@ -319,12 +319,12 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
     } else {
       int t0, t1, h0, h1, w0, w1; float a, b, c;
       lin_coord(t, Ts, Td, t0, t1, a); lin_coord(h, Hs, Hd, h0, h1, b); lin_coord(w, Ws, Wd, w0, w1, c);
-      // All eight corner offsets first, then eight 16-byte BUFFER loads in flight (32-bit offsets from one descriptor).  The plain form --
-      // a global load per corner inside the loop, 64-bit address arithmetic between them -- delivered ZEROS for ONE corner to the last
-      // sixteen lanes of a wave (= one output row) about once in 4000 launches inside the three-stream step of the small deterministic
-      // test, never alone (tools/flake_det.py, profiles/r05_flake_det.md: the source row was in memory, a sentinel written beforehand
-      // was not what came back, non-temporal loads changed nothing); with the addresses held until the data is back the rate fell to a
-      // third, in this form to a tenth.  Not understood; the bitwise test retries once and reports.
+      // All eight corner offsets first, then eight 16-byte BUFFER loads in flight (32-bit offsets from one descriptor: the launcher
+      // bounds the source at 2 GiB).  History: round 5 saw one output row of this kernel lose ONE corner term for lanes 48-63 about once
+      // in 4000 launches inside the three-stream step and read it as a load that returned zeros; round 6 found the corner's WEIGHT was
+      // zero -- a `v_pk_mul_f32` with a cross-half op_sel (what hipcc makes of the products below) returns 0 in the low half for the
+      // last lane quarter beside MFMA kernels of another queue (profiles/r06_flake.md).  The library is built without packed fp32
+      // instructions since (build.sh), so the products below are plain v_mul_f32.
       const bf16_t* ap[8]; float wt8[8]; uint4 v8[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -370,6 +370,7 @@ extern "C" int mscl_upsample_add(const uint16_t* src, uint16_t* dst, int N, int 
   if (C % 8) return MSCL_E_SHAPE;
   const long total = (long)N * Td * Hd * Wd * (C / 8);
   if (total >= (1L << 31) || (long)Td * Ts >= (1L << 31)) return MSCL_E_SHAPE;
+  if (trilinear && (long)N * Ts * Hs * Ws * C * 2 >= (1L << 31)) return MSCL_E_SHAPE;      // 32-bit byte offsets into the source
   long blocks = (total + 255) / 256; if (blocks > ew_cap()) blocks = ew_cap();
   hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, Ts, Hs, Ws,
                      Td, Hd, Wd, C, trilinear, accumulate, make_updiv(C / 8, Ts, Hs, Ws, Td, Hd, Wd));

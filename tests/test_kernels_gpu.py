@@ -684,10 +684,12 @@ def test_linear_l2norm(dev):
     close(K_.l2norm_bwd(yd, nr, dy.to(dev)), x.grad, 1e-5, 'l2norm bwd')
 
 
-@pytest.mark.parametrize('R,K', [(8, 1024), (24, 65536), (16, 4096), (3, 640), (32, 2048), (96, 4096), (45, 640)])
+@pytest.mark.parametrize('R,K', [(8, 1024), (24, 65536), (16, 4096), (3, 640), (32, 2048), (96, 4096), (45, 640), (24, 2050), (40, 1022)])
 def test_nce(R, K, dev):
     """R = 96 is the three stacked row groups of the shipped config's videos_per_gpu = 32 (mscl_r18_cosm_lr2e-2.py:50): rows beyond
-    32 run as further row tiles over the same snapshot; 45 = one full + one ragged tile."""
+    32 run as further row tiles over the same snapshot; 45 = one full + one ragged tile.  K = 2050 / 1022 (even, not a multiple of
+    4) are the shapes the fp32-MFMA kernels leave to the vector kernels (a lane of theirs reads two columns, not four); every other
+    K runs on the matrix cores (round 6)."""
     from mscl_amd import kernels as K_
     dim, T = 128, 0.07
     queue = F.normalize(rnd((dim, K), 1), dim=0)

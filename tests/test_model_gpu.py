@@ -64,7 +64,11 @@ def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None):
             assert abs(got[k] - v) <= loss_tol * max(1.0, abs(v)), f'{what} {k}: hip {got[k]} vs ref {v}'
         else:
             r = pos_rows if (k.endswith('_pos') and pos_rows) else rows
-            slack = 1e-6 if r is None else 1.0 / r + 1e-6
+            # the LMCL rows are at chance at step 0 (see above): the number that may change rank grows with the row count -- one per
+            # 64 rows (round 6: 2 of 128 rows flipped in one of five runs at B = 32, 76 / 128 vs 78 / 128; the default mode's float
+            # atomics move the features from run to run)
+            flips = max(1, -(-r // 64)) if (r is not None and k.endswith('_pos') and pos_rows) else 1
+            slack = 1e-6 if r is None else flips / r + 1e-6
             assert abs(got[k] - v) <= slack, f'{what} {k}: hip {got[k]} vs ref {v}'
 
 

@@ -45,9 +45,10 @@ cd $R
 { echo "# commit $H: aten device ops of one eager step by call site (tools/glue_launches.py)"; python3 tools/glue_launches.py 2>/dev/null | grep -v amdgpu; } > $O/glue_launches.txt
 { echo "# commit $H: BatchNorm passes alone (tools/bench_bn.py)"; python3 tools/bench_bn.py 2>/dev/null | grep -v amdgpu; } > $O/bn_passes.txt
 { echo "# commit $H: the grouped weight-gradient launch against per-layer launches, two captured whole-step graphs replayed alternately in one process (tools/ab_step.py, clip-pairs/s)"; python3 tools/ab_step.py "nn.GROUP_WGRADS[0]=False" "nn.GROUP_WGRADS[0]=True" 2>/dev/null | grep -v amdgpu; } > $O/ab_group_wgrad.txt
-{ echo "# commit $H: alternating whole-step graphs in one process (tools/ab_step.py, clip-pairs/s): window-resident stride-2 input gradient off / on; InfoNCE vector kernels / fp32 MFMA kernels; side-chain split-K cap 16 / 4 / 1"
+{ echo "# commit $H: alternating whole-step graphs in one process (tools/ab_step.py, clip-pairs/s): window-resident stride-2 input gradient off / on; side-chain split-K cap 16 / 4 / 1"
   python3 tools/ab_step.py "os.environ.__setitem__('MSCL_DGRAD_S2','0'); lib.call_raw('mscl_tuning_reload')" "os.environ.__setitem__('MSCL_DGRAD_S2','1'); lib.call_raw('mscl_tuning_reload')" 2>/dev/null | grep -v amdgpu
-  python3 tools/ab_step.py "os.environ.__setitem__('MSCL_NCE_MFMA','0'); lib.call_raw('mscl_tuning_reload')" "os.environ.__setitem__('MSCL_NCE_MFMA','1'); lib.call_raw('mscl_tuning_reload')" 2>/dev/null | grep -v amdgpu
+  # (the InfoNCE vector / MFMA pair was measured with the switch MSCL_NCE_MFMA that commit abbe824 still had: 1179.3 -> 1184.5; the
+  #  switch is gone, the vector kernels take the shapes the MFMA kernels do not)
   python3 tools/ab_step.py "model.set_side_split(16,16)" "model.set_side_split(4,4)" "model.set_side_split(1,1)" 2>/dev/null | grep -v amdgpu; } > $O/ab_round6.txt
 { echo "# commit $H: the stand-alone reproducer of the round-5 dropped corner against the PRODUCT library (tools/diag/flake_repro: 1 000 000 comparisons), then its VALU probe in the compiled kernel's packed-fp32 form beside the RGB key trunk's convs on this box"
   tools/diag/flake_repro --replays 50000 2>&1 | grep "device\|reference\|SUMMARY"; tools/diag/flake_repro --replays 20000 --probe 0 --side convs --streams B 2>&1 | grep "PROBE"; rocm-smi --showuniqueid 2>/dev/null | grep -i unique; } > $O/flake_repro.txt
