@@ -15,7 +15,11 @@ class GraphedStep:
     def __init__(self, model, optimizer, example_batch, warmup=2, indirect=None):
         """indirect: None = inputs by address wherever the step allows it (below), False = always through the static buffers"""
         self.model, self.opt = model, optimizer
-        model.shuffle_mode = 'gather'            # all-to-all split sizes change per step and cannot be baked into a graph
+        # The shuffle-BN exchange inside a captured step uses the all-gather formulation (W x the rows of the all-to-all).  Round 6 dealt
+        # the permutation balanced (parallel.shuffle_perm: B / W rows to every rank, always), which gives the all-to-all equal, constant
+        # split sizes -- and found that capturing `dist.all_to_all_single` segfaults in this stack (RCCL 2.26.6 under torch 2.10, one-rank
+        # group, tools/scratch/a2a_capture.py; the all-gather captures and replays fine), so the fallback stays.
+        model.shuffle_mode = 'gather'
         dev = model.arena.device
         example_batch = model.with_aug_draw(example_batch)      # stochastic augmenter: static mask / parameter buffers
         self.static = {k: [t.to(dev).clone() for t in v] for k, v in example_batch.items()}

@@ -58,10 +58,34 @@ def all_gather_cat(t):
     return out
 
 
-def shuffle_perm(n, step, slot, seed=20221):
-    """permutation of range(n) shared by all ranks: CPU generator seeded from (seed, step, slot)."""
+def balanced_world(n, world=None):
+    """the world size for which shuffle_perm deals a BALANCED permutation of n = W * B rows (0: none): W ranks, B a multiple of W"""
+    W = world if world is not None else (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1)
+    return W if (W >= 1 and n % W == 0 and (n // W) % W == 0) else 0
+
+
+def shuffle_perm(n, step, slot, seed=20221, world=None):
+    """permutation of range(n) shared by all ranks: CPU generator seeded from (seed, step, slot).
+
+    Round 6: when the per-rank batch B = n / W is a multiple of the world size W (the shipped config: 32 clips on 4 or 8 GPUs) the
+    permutation is dealt BALANCED: every rank encodes exactly B / W rows of every owner, in random order -- each owner shuffles its
+    rows and deals them round-robin to the encoders, each encoder shuffles what it received.  Still a permutation of the global
+    batch whose every encoder batch mixes all replicas (what shuffle-BN is for: recognizers/moco.py:146-172 draws an unconstrained
+    torch.randperm; the shared seed was a documented deviation already), and the all-to-all that carries it has EQUAL, CONSTANT
+    split sizes: it can be captured into the whole-step HIP graph, where the unconstrained form had to fall back to an all-gather
+    of W times the rows.  world = None: the initialised process group's size (1 without one: plain randperm, as before)."""
     g = torch.Generator().manual_seed(seed + 7919 * step + 104729 * slot)
-    return torch.randperm(n, generator=g)
+    W = balanced_world(n, world)
+    if W <= 1:
+        return torch.randperm(n, generator=g)
+    B = n // W
+    k = B // W
+    dealt = [torch.randperm(B, generator=g) + s * B for s in range(W)]              # owner s: its rows, shuffled
+    rows = []
+    for r in range(W):                                                                   # encoder r: k rows of every owner, shuffled
+        got = torch.cat([dealt[s][r * k:(r + 1) * k] for s in range(W)])
+        rows.append(got[torch.randperm(B, generator=g)])
+    return torch.cat(rows)
 
 
 @torch.no_grad()

@@ -157,6 +157,33 @@ def test_shuffle_perm_is_shared_and_invertible():
     assert bucket_plan(10, 4) == [(0, 4), (4, 8), (8, 10)]
 
 
+def test_balanced_shuffle_perm():
+    """parallel.shuffle_perm with a per-rank batch that is a multiple of the world size (round 6): a permutation of the global batch
+    in which every rank encodes exactly B / W rows of every owner -- so the all-to-all that carries it has equal, constant split
+    sizes (capturable into the whole-step graph) -- shared by all ranks (same seed -> same permutation), different from step to
+    step and slot to slot; the ShufflePlan built on it moves every row once and restores every owner's order."""
+    import torch
+    from mscl_amd import parallel
+    W, B = 4, 8
+    perm = parallel.shuffle_perm(W * B, 5, 1, world=W)
+    assert sorted(perm.tolist()) == list(range(W * B)) and torch.equal(perm, parallel.shuffle_perm(W * B, 5, 1, world=W))
+    assert not torch.equal(perm, parallel.shuffle_perm(W * B, 6, 1, world=W)) and not torch.equal(perm, parallel.shuffle_perm(W * B, 5, 2, world=W))
+    for r in range(W):
+        owners = torch.bincount(perm.view(W, B)[r] // B, minlength=W)
+        assert owners.tolist() == [B // W] * W, owners
+    assert parallel.balanced_world(W * B, W) == W and parallel.balanced_world(4 * 3, 4) == 0 and parallel.balanced_world(16) == 1
+    assert torch.equal(parallel.shuffle_perm(12, 3, 1, world=4), parallel.shuffle_perm(12, 3, 1))      # B = 3 on 4 ranks: the plain randperm
+    xs = [torch.arange(B, dtype=torch.float32).view(B, 1) + 100 * r for r in range(W)]
+    plans = [parallel.ShufflePlan(W, B, r, perm) for r in range(W)]
+    for pl in plans:
+        assert pl.send_splits == [B // W] * W and pl.recv_splits == [B // W] * W
+    sent = [list(torch.split(xs[r].index_select(0, plans[r].send_order), plans[r].send_splits)) for r in range(W)]
+    allx = torch.cat(xs)
+    for r in range(W):
+        got = torch.cat([sent[s][r] for s in range(W)]).index_select(0, plans[r].recv_order)
+        assert torch.equal(got, allx.index_select(0, perm.view(W, B)[r]))
+
+
 def test_shuffle_plan_simulated_world4():
     """ShufflePlan on 4 simulated ranks (no process group): rows land where the all-gather formulation puts them, and
     the way back restores every owner's order."""

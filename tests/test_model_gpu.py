@@ -962,6 +962,33 @@ def _rccl_forced_worker(port, q):
             res.append({k: v for k, v in out['log_vars'].items() if 'loss' in k})
         assert model._a2a and model.reducer.launched == set() and int(model.recognizer.queue_ptr) == 3 * B
         torch.cuda.synchronize()
+        # round 6: the whole step INCLUDING its collectives as one captured graph (all-gather formulation of the shuffle: capturing the
+        # all-to-all segfaults in this RCCL, graph.py) -- in deterministic mode three optimizer steps equal the eager launches, which use the
+        # all-to-all, bit for bit
+        from mscl_amd import lib
+        from mscl_amd.graph import GraphedStep
+        lib.set_deterministic(True)
+
+        def run(graph):
+            m2, c2 = build(T, Kq, dev)
+            o2 = ClipSGD.from_cfg(m2, c2.optimizer, c2.optimizer_config)
+            bs = [synthetic_batch(B, T, H, H, 0, s, device=dev) for s in range(3)]
+            losses = []
+            if graph:
+                gs = GraphedStep(m2, o2, bs[0], warmup=2)
+                for s in range(3):
+                    losses.append(float(gs.step(bs[s])[0]))
+            else:
+                for s in (0, 0, 0, 1, 2):
+                    out = m2.train_step(bs[s], sync_logs=False)
+                    o2.zero_grad(); out['loss'].backward(); o2.step()
+                    losses.append(float(out['loss'].detach()))
+                losses = losses[2:]
+            torch.cuda.synchronize()
+            return losses, m2.arena.Q.clone(), m2.recognizer.queue.clone()
+        a, b = run(False), run(True)
+        lib.set_deterministic(False)
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), ('captured step with collectives != eager', a[0], b[0])
         q.put(('ok', res))
     except Exception:      # noqa
         import traceback
@@ -980,7 +1007,15 @@ def test_rccl_backend_single_rank_forced(dev):
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_forced_worker, args=(port, q))
     p.start()
-    status, res = q.get(timeout=600)
+    import queue as _queue
+    status, res, waited = None, None, 0
+    while status is None and waited < 600:          # (a worker that dies -- a crash inside RCCL, say -- must not cost a ten-minute wait)
+        try:
+            status, res = q.get(timeout=5)
+        except _queue.Empty:
+            waited += 5
+            if not p.is_alive():
+                status, res = 'err', f'the worker exited with code {p.exitcode} without a result'
     p.join(60)
     assert status == 'ok', res
     B, T, H, Kq = 2, 8, 32, 64

@@ -6,7 +6,9 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev_r06; rm -rf $O; mkdir -p $O
 H=${GIT_HEAD:-unknown}; echo "$H" > $O/HEAD
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_line_under_rocprof.json 2> $O/stats.err
+# (--no-variants: the deterministic-mode leg would otherwise be the LAST step of the trace, and the launch counts / loss-phase timeline below
+#  would describe deterministic mode -- as rounds 5's and the first round-6 copy of these two files did)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $O/bench_line_under_rocprof.json 2> $O/stats.err
 f=$(ls $O/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
 t=$(ls $O/stats/*/*kernel_trace.csv 2>/dev/null | head -1)
 [ -n "$t" ] && python3 $R/tools/count_step_kernels.py $O/stats > $O/step_launch_counts.txt 2>&1
