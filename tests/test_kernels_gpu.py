@@ -1200,7 +1200,9 @@ def test_upsample_beside_conv_streams(dev):
     import subprocess
     from mscl_amd import lib
     exe = os.path.join(ROOT, 'tools', 'diag', 'flake_repro')
-    assert os.path.exists(exe), 'tools/diag/flake_repro is missing: __graft_entry__.build() builds it (tools/diag/build.sh)'
+    if not os.path.exists(exe):                   # __graft_entry__.build() builds it; a tree that arrived without built files builds it here
+        subprocess.run(['bash', os.path.join(ROOT, 'tools', 'diag', 'build.sh')], check=True, capture_output=True, timeout=600)
+    assert os.path.exists(exe), 'tools/diag/flake_repro is missing and tools/diag/build.sh did not produce it'
     r = subprocess.run([exe, '--lib', lib.LIB_PATH, '--replays', '3000'], capture_output=True, text=True, timeout=300)
     tail = [ln for ln in r.stdout.splitlines() if ln.startswith('SUMMARY') or 'reference launch' in ln]
     print('\n'.join(tail))
