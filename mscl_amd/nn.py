@@ -382,7 +382,7 @@ def _wgrad(conv, x, dy):
     here, and each delays the chain it leaves.  Concurrency for small launches has to come from ONE launch (a grouped kernel), not
     from more streams: WGradQueue.)"""
     if GROUP_WGRADS[0]:
-        key = ('wg', tuple(x.shape), lib.DET_GEN)
+        key = ('wg', tuple(x.shape), lib.DET_GEN, GROUP_MAX_ROWS)
         ok = conv._plans.get(key)
         d = conv.desc(x.shape)
         if ok is None:

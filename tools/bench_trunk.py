@@ -4,7 +4,8 @@ Prints one JSON line: clips/s, ms per iteration and the fraction of the dense bf
 (algorithmic 241.3 GFLOP per clip: forward 81.39 + input gradients without the stem's + weight gradients).
 --r50: BASELINE.json configs[4], the ResNet3dSlowOnly-50 trunk of mscl_r50_cosm_lr3e-2.py on one (8, 3, 32, 224, 224) batch (the
 deep / large-activation stress case); its algorithmic FLOPs are counted from the conv descriptors of the run itself.
-usage: python tools/bench_trunk.py [--iters N] [--warmup W] [--r50] [--batch B]"""
+--group-rows N: nn.GROUP_MAX_ROWS for this run (output positions up to which a weight gradient joins a grouped launch; 0 = none).
+usage: python tools/bench_trunk.py [--iters N] [--warmup W] [--r50] [--batch B] [--group-rows N]"""
 import argparse
 import json
 import os
@@ -25,10 +26,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--r50', action='store_true')
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--group-rows', type=int, default=-1)
     a = ap.parse_args()
     from mscl_amd import Config, build_model
     from mscl_amd.fill import fill_module
     from mscl_amd.nn import Conv3dHip
+    from mscl_amd import nn as nn_hip
+    if a.group_rows >= 0:
+        nn_hip.GROUP_MAX_ROWS = a.group_rows
     from mscl_amd.synthetic import synthetic_batch
     dev = torch.device('cuda:0')
     B, T, H = (a.batch, 32, 224) if a.r50 else (a.batch, 16, 112)
@@ -82,7 +87,7 @@ def main():
         extra = {}
     tf = gflop / ms
     print(json.dumps({'metric': name, 'value': B / ms * 1e3, 'unit': 'clips/s', 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
-                      'ms_per_iter': ms, 'iters': a.iters, 'dtype': 'bf16', 'launch': 'eager, one stream',
+                      'ms_per_iter': ms, 'iters': a.iters, 'group_max_rows': nn_hip.GROUP_MAX_ROWS, 'dtype': 'bf16', 'launch': 'eager, one stream',
                       'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
                                    'algorithmic_gflop_per_iter': gflop,
                                    'note': 'whole iteration incl. BatchNorm passes and launch gaps, not one kernel'}, **extra}))
