@@ -114,7 +114,9 @@ int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_t* src, con
                      const uint16_t* addend, float* stat_sum, float* stat_sq, void* stream);
 
 /* dx = conv_transpose(dy, w) [+ addend]; wT_bf16 is the kernel re-laid out [Cin][kT][kH][kW][Cout]
- * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient. */
+ * (mscl_weight_transpose).  Replaces autograd's conv3d input gradient.  For a STRIDED conv addend == dx is allowed (dx += ...: an
+ * element is read and written by the same wave, the read first) and the positions no tap reaches are then left alone -- a
+ * 1x1x1 / stride-2 shortcut touches one position in eight.  Stride-1 convs: addend and dx must not overlap. */
 int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, const uint16_t* wT_bf16, uint16_t* dx,
                       const uint16_t* addend, float* splitk_ws, int64_t splitk_ws_floats, void* stream);
 

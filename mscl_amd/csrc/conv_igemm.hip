@@ -732,6 +732,10 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
     g.lsT = ilog2_exact(d->sT); g.lsH = ilog2_exact(d->sH); g.lsW = ilog2_exact(d->sW);
     if (g.lsT < 0 || g.lsH < 0 || g.lsW < 0 || d->sT > 2 || d->sH > 2 || d->sW > 2) return MSCL_E_STRIDE;
     // stride-parity classes: input position i receives tap k only if (i + p - k) % s == 0
+    // IN PLACE (addend == dx): positions of a class without taps keep what dx holds, so such a class is not launched at all --
+    // the strided 1x1x1 shortcut of a stage entry then touches 1/8 (1/4) of the map it adds to instead of writing a map of
+    // mostly zeros that the entry conv's input gradient reads back as its addend (nn._BlockFn / _BottleneckFn)
+    const bool inplace = addend != nullptr && addend == dx;
     int nc = 0;
     for (int a = 0; a < d->sT; ++a) for (int b = 0; b < d->sH; ++b) for (int c = 0; c < d->sW; ++c) {
       ClassInfo& ci = g.cls[nc];
@@ -747,8 +751,9 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
         }
       }
       ci.ntl = (unsigned char)n;
-      if (ci.M > 0) ++nc;
+      if (ci.M > 0 && !(inplace && n == 0)) ++nc;
     }
+    if (nc == 0) return 0;                            // (in place and no position receives a tap: nothing to add)
     g.nclass = nc;
   }
   return launch_igemm(g, dy, wT, dx, nullptr, addend, nullptr, nullptr, 0, splitk_ws, (long)splitk_ws_floats, (hipStream_t)stream);

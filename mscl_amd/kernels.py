@@ -101,8 +101,14 @@ def conv3d_fwd(x, w, d, bias=None, addend=None, relu=False, stats=None, split_ca
     return y
 
 
-def conv3d_dgrad(dy, wT, d, addend=None, split_cap=16):
-    dx = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
+def conv3d_dgrad(dy, wT, d, addend=None, split_cap=16, out=None):
+    """out: an existing (N, T, H, W, C) bf16 map to ACCUMULATE into (dx = out += ...; the library's in-place form, include/mscl_hip.h)"""
+    if out is not None:
+        assert addend is None and out.is_contiguous() and tuple(out.shape) == (d.N, d.T, d.H, d.W, d.C) and out.dtype == torch.bfloat16
+        assert max(d.sT, d.sH, d.sW) > 1, 'in place is defined for strided convs only (include/mscl_hip.h)'
+        dx = addend = out
+    else:
+        dx = torch.empty((d.N, d.T, d.H, d.W, d.C), dtype=torch.bfloat16, device=dy.device)
     ws = _splitk_ws(d.N * d.T * d.H * d.W, d.C, dy.device, split_cap)
     e0 = prof_begin()
     call('mscl_conv3d_dgrad', ctypes.byref(d), ptr(dy), ptr(wT), ptr(dx), ptr(addend), ptr(ws), ws.numel() if ws is not None else 0, stream_ptr())

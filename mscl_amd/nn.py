@@ -82,8 +82,13 @@ class Conv3dHip(nn.Module):
                 st.sync_reader()
         return self._rt['wT']
 
-    def dgrad(self, dy, x_shape, addend=None):
-        return K.conv3d_dgrad(dy, self.wT(), self.desc(x_shape), addend=addend, split_cap=self.split_cap)
+    def dgrad(self, dy, x_shape, addend=None, out=None):
+        return K.conv3d_dgrad(dy, self.wT(), self.desc(x_shape), addend=addend, split_cap=self.split_cap, out=out)
+
+    def strided_pointwise(self):
+        """a 1x1x1 conv with a stride: its input gradient reaches one position in prod(stride) -- cheaper added INTO an existing
+        map (dgrad(out=...)) than written as a map of mostly zeros"""
+        return tuple(self.kernel_size) == (1, 1, 1) and max(self.stride) > 1
 
     def wgrad(self, x, dy):
         """dw += ...: plain adds where one block owns an element (include/mscl_hip.h, mscl_conv3d_wgrad INVARIANT): every
@@ -226,9 +231,9 @@ def cba_eval(conv, bn, x, residual, relu):
     return out
 
 
-def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_addend=None):
+def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_addend=None, dx_into=None):
     """backward of cba_fwd: BN(+ReLU) input gradient, conv weight gradient (into the arena), conv input
-    gradient (optionally fused with `dx_addend`).  Returns (dx|None, dres|None).
+    gradient (optionally fused with `dx_addend`, or accumulated into the existing map `dx_into`).  Returns (dx|None, dres|None).
     (Rounds 1-3 carried an opt-in fused form -- the layer-1 input-gradient kernel reducing the consuming BatchNorm's sums in its
     epilogue -- that broke even at best; removed in round 4, see conv_halo.hip.)"""
     rt = bn._rt
@@ -241,7 +246,7 @@ def cba_bwd(conv, bn, dout, out, y, save, x, relu, need_dx, want_dres=False, dx_
     rt['slot_g'].touched = True
     rt['slot_b'].touched = True
     _wgrad(conv, x, dy)
-    dx = conv.dgrad(dy, x.shape, addend=dx_addend) if need_dx else None
+    dx = conv.dgrad(dy, x.shape, addend=dx_addend, out=dx_into) if need_dx else None
     return dx, dres
 
 
@@ -361,6 +366,7 @@ class WGradQueue:
 
 WGRADS = WGradQueue()
 GROUP_MAX_ROWS = 16384              # output positions up to which a layer's weight gradient is deferred into a grouped launch
+SHORTCUT_INTO_DX = [True]          # False: a strided 1x1x1 shortcut's input gradient is a map of its own, added by the entry conv's (A/B, tools/ab_step.py)
 GROUP_WGRADS = [True]               # False: every weight gradient is launched where it arises (A/B, tools/ab_step.py)
 
 
@@ -506,12 +512,17 @@ class _BlockFn(torch.autograd.Function):
         c1, b1 = block.conv1[0], block.conv1[1]
         c2, b2 = block.conv2[0], block.conv2[1]
         da1, dz = cba_bwd(c2, b2, dout.contiguous(), out, y2, s2, a1, True, need_dx=True, want_dres=True)
-        if ctx.has_ds:
-            dxd, _ = cba_bwd(block.downsample[0], block.downsample[1], dz, None, yd, sd, x, False, need_dx=True)
-            shortcut_grad = dxd
+        if ctx.has_ds and SHORTCUT_INTO_DX[0] and block.downsample[0].strided_pointwise():
+            # the strided 1x1x1 shortcut reaches one input position in eight (four): the entry conv's gradient first, the shortcut's
+            # added into it at those positions -- not a map of mostly zeros written here and read back as the entry's addend
+            dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True)
+            cba_bwd(block.downsample[0], block.downsample[1], dz, None, yd, sd, x, False, need_dx=True, dx_into=dx)
         else:
-            shortcut_grad = dz
-        dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
+            if ctx.has_ds:
+                shortcut_grad, _ = cba_bwd(block.downsample[0], block.downsample[1], dz, None, yd, sd, x, False, need_dx=True)
+            else:
+                shortcut_grad = dz
+            dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
         _bucket_done(block)
         return dx, None
 
@@ -665,13 +676,16 @@ class _BottleneckFn(torch.autograd.Function):
         x, y1, a1, s1, y2, a2, s2, y3, out, s3 = t[:10]
         (c1, b1), (c2, b2), (c3, b3) = _cb(block.conv1), _cb(block.conv2), _cb(block.conv3)
         da2, dz = cba_bwd(c3, b3, dout.contiguous(), out, y3, s3, a2, True, need_dx=True, want_dres=True)
-        if ctx.has_ds:
-            cd, bd = _cb(block.downsample)
+        cd, bd = _cb(block.downsample) if ctx.has_ds else (None, None)
+        late = ctx.has_ds and SHORTCUT_INTO_DX[0] and cd.strided_pointwise()        # (see _BlockFn.backward: the strided shortcut's gradient goes INTO dx)
+        if ctx.has_ds and not late:
             shortcut_grad, _ = cba_bwd(cd, bd, dz, None, t[10], t[11], x, False, need_dx=True)
         else:
-            shortcut_grad = dz
+            shortcut_grad = None if late else dz
         da1, _ = cba_bwd(c2, b2, da2, a2, y2, s2, a1, True, need_dx=True)
         dx, _ = cba_bwd(c1, b1, da1, a1, y1, s1, x, True, need_dx=True, dx_addend=shortcut_grad)
+        if late:
+            cba_bwd(cd, bd, dz, None, t[10], t[11], x, False, need_dx=True, dx_into=dx)
         _bucket_done(block)
         return dx, None
 

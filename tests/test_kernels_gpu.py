@@ -1256,3 +1256,42 @@ def test_conv_dgrad_s2(case, dev):
     finally:
         os.environ.pop('MSCL_DGRAD_S2', None)
         lib.call_raw('mscl_tuning_reload')
+
+
+# In-place input gradient (round 6): dx += conv_transpose(dy, w) with addend == dx.  For a strided 1x1x1 shortcut the positions no
+# tap reaches are not touched at all (bit-identical afterwards); the positions that are reached hold base + gradient.  Also a 3x3x3
+# stride-2 conv in place (every position is reached: the plain sum).
+INPLACE_CASES = [
+    # name, N,T,H,W, C (dx), K (dy), kernel, stride, pad
+    ('sc_64_128_s222', 2, 8, 24, 24, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    ('sc_odd_s222', 1, 5, 7, 9, 64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    ('sc_256_512_s122', 1, 4, 14, 14, 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ('sc_flow_16_32_s122', 2, 4, 28, 28, 16, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ('k333_s222', 1, 4, 12, 12, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('case', INPLACE_CASES, ids=[c[0] for c in INPLACE_CASES])
+def test_conv_dgrad_in_place(case, dev):
+    from mscl_amd import kernels as K_
+    name, N, T, H, W, C, K, kern, st, pad = case
+    taps = kern[0] * kern[1] * kern[2]
+    x = rnd((N, T, H, W, C), 41).requires_grad_(True); w = bf(rnd((K, *kern, C), 42, scale=(2.0 / (C * taps)) ** 0.5))
+    d = K_.conv_desc((N, T, H, W, C), K, kern, st, pad)
+    yr = _conv_ref(x, w.float(), st, pad)
+    dy = bf(rnd(tuple(yr.shape), 43))
+    yr.backward(dy.float())
+    wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
+    K_.weight_transpose(w.to(dev), wT, K, taps, C)
+    base = bf(rnd((N, T, H, W, C), 44))
+    out = base.to(dev).clone()
+    r = K_.conv3d_dgrad(dy.to(dev), wT, d, out=out)
+    assert r.data_ptr() == out.data_ptr()
+    close(out, x.grad + base.float(), BF16_TOL, 'in-place dgrad')
+    # and the same as the two-map form
+    close(out, K_.conv3d_dgrad(dy.to(dev), wT, d, addend=base.to(dev)), BF16_TOL, 'in place vs addend')
+    if kern == (1, 1, 1):
+        reached = torch.zeros((T, H, W), dtype=torch.bool)
+        reached[::st[0], ::st[1], ::st[2]] = True
+        assert torch.equal(out.cpu()[:, ~reached], base[:, ~reached]), 'a position no tap reaches was rewritten'
+        assert not torch.equal(out.cpu()[:, reached], base[:, reached])
