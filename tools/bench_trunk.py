@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--r50', action='store_true')
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--group-rows', type=int, default=-1)
+    ap.add_argument('--shortcut-map', action='store_true', help='A/B: strided shortcut gradients as maps of their own (nn.SHORTCUT_INTO_DX off)')
     a = ap.parse_args()
     from mscl_amd import Config, build_model
     from mscl_amd.fill import fill_module
@@ -34,6 +35,7 @@ def main():
     from mscl_amd import nn as nn_hip
     if a.group_rows >= 0:
         nn_hip.GROUP_MAX_ROWS = a.group_rows
+    nn_hip.SHORTCUT_INTO_DX[0] = not a.shortcut_map
     from mscl_amd.synthetic import synthetic_batch
     dev = torch.device('cuda:0')
     B, T, H = (a.batch, 32, 224) if a.r50 else (a.batch, 16, 112)
@@ -87,7 +89,7 @@ def main():
         extra = {}
     tf = gflop / ms
     print(json.dumps({'metric': name, 'value': B / ms * 1e3, 'unit': 'clips/s', 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
-                      'ms_per_iter': ms, 'iters': a.iters, 'group_max_rows': nn_hip.GROUP_MAX_ROWS, 'dtype': 'bf16', 'launch': 'eager, one stream',
+                      'ms_per_iter': ms, 'iters': a.iters, 'group_max_rows': nn_hip.GROUP_MAX_ROWS, 'shortcut_into_dx': nn_hip.SHORTCUT_INTO_DX[0], 'dtype': 'bf16', 'launch': 'eager, one stream',
                       'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': tf / 2500.0,
                                    'algorithmic_gflop_per_iter': gflop,
                                    'note': 'whole iteration incl. BatchNorm passes and launch gaps, not one kernel'}, **extra}))
