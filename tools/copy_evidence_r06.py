@@ -36,6 +36,23 @@ def main():
     for a, b in MAP.items():
         if os.path.exists(os.path.join(E, a)):
             shutil.copy(os.path.join(E, a), os.path.join(P, b))
+    Eb = os.path.join(R, 'gpurun_out', 'ev_r06b')             # second call (tools/evidence_r06b.sh)
+    sc_txt = ''
+    if os.path.exists(os.path.join(Eb, 'ab_shortcut.txt')):
+        shutil.copy(os.path.join(Eb, 'ab_shortcut.txt'), os.path.join(P, 'r06_ab_shortcut.txt'))
+        sc = open(os.path.join(Eb, 'ab_shortcut.txt')).read()
+        ms = re.findall(r'median\s+([0-9.]+)', sc)
+        r50 = re.findall(r'SlowOnly-50.*?into_dx=(\w+)\s+([0-9.]+) clips/s', sc)
+        off = [float(v) for k, v in r50 if k == 'False']; on = [float(v) for k, v in r50 if k == 'True']
+        if len(ms) >= 2 and off and on:
+            sc_txt = (f" Strided shortcut gradient added into the entry's gradient in place (`profiles/r06_ab_shortcut.txt`): step {ms[0]} → {ms[1]},\n"
+                      f"SlowOnly-50 trunk {sum(off) / len(off):.0f} → {sum(on) / len(on):.0f} clips/s.")
+        k = open(os.path.join(Eb, 'kernels.md')).read()
+        gr = open(os.path.join(Eb, 'group_rows.txt')).read()
+        tail = open(os.path.join(P, 'r06_trunk_config5_r50_kernels.md')).read()
+        note = tail[tail.index('Against round 4'):tail.index('```')] if 'Against round 4' in tail else ''
+        rest = tail[tail.rindex('```') + 3:] if '```' in tail else ''
+        open(os.path.join(P, 'r06_trunk_config5_r50_kernels.md'), 'w').write(k + '\n' + note + '```\n' + gr + '```' + rest)
     head = open(os.path.join(E, 'HEAD')).read().strip()
     d = last_json(os.path.join(P, 'r06_bench_line.json'))
     rf = d['roofline']
@@ -71,7 +88,7 @@ def main():
            f"32 × 224² / 8 × 224². This round's step-level A/Bs (alternating graphs in one process, `profiles/r06_ab_step.txt`, medians): window-resident\n"
            f"stride-2 input gradient {med6[0] if med6 else '?'} → {med6[1] if len(med6) > 1 else '?'}; InfoNCE on fp32 MFMA {med6[2] if len(med6) > 2 else '?'} → {med6[3] if len(med6) > 3 else '?'}; side-chain split-K cap\n"
            f"16 / 4 / 1: {' / '.join(med6[4:7]) if len(med6) > 6 else '?'} clip-pairs/s. InfoNCE kernels (24 rows) {nf.group(1) if nf else '?'} / {nb.group(1) if nb else '?'} µs forward / backward\n"
-           f"(round 5: 17.2 / 25.2).\n")
+           f"(round 5: 17.2 / 25.2).{sc_txt}\n")
     dp = os.path.join(R, 'DESIGN.md')
     s = open(dp).read()
     a = s.index('**Results**')
