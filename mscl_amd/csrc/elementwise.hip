@@ -512,19 +512,20 @@ extern "C" int mscl_upsample_bwd(const uint16_t* ddst, uint16_t* dsrc, int N, in
 }
 
 // ---------------------------------------------------------------- mean over the middle axis
-// x (outer, inner, C) bf16 -> out (outer, C) fp32.  One block per (outer, 64-channel group... ) :
-// block = 256 threads = G channel-granules x (256/G) row lanes; LDS reduce.
-// Maps wider than 512 channels (the Bottleneck trunks: up to 2048) are cut into 512-channel chunks along blockIdx.y:
-// `C` is the chunk width the thread layout sees, `ldc` the row pitch of the map in elements.
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C, int ldc) {
-  __shared__ float red[4 * 512];
+// x (outer, inner, C) bf16 -> out (outer, C) fp32.  One 1024-thread block per (outer, channel chunk): G = chunk / 8 channel granules x
+// 1024 / G row lanes, eight rows in flight per thread, wave shuffles over the row lanes, then the 16 waves through LDS in wave order
+// (a fixed order: deterministic).  These launches sit on the way into the projection head of every chain and are pure latency:
+// with one row in flight the 8-block launch over the layer-4 map (98 rows x 512 channels per clip) was 25 dependent round trips =
+// 40 us for 0.8 MB (round 3); with 256 threads and 512-channel chunks it was still 4 trips (10 us), and the 6272-row pyramid level
+// 49 trips (34 us).  Round 6: chunks of 128 channels (64 on long maps) and 1024 threads: one trip on the layer-4 map, six on the
+// pyramid level, and 2-4 x the blocks.  `C` is the chunk width the thread layout sees, `ldc` the row pitch of the map in elements.
+__global__ __launch_bounds__(1024) void pool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int inner, int C, int ldc) {
+  __shared__ float red[16 * 128];
   x += blockIdx.y * C; out += blockIdx.y * C;
-  const int G = C >> 3;
-  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 256 / G;
+  const int G = C >> 3;                           // 8 or 16: a divisor of 64
+  const int tg = threadIdx.x % G, tr = threadIdx.x / G, RP = 1024 / G;
   const long base = (long)blockIdx.x * inner * ldc;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // eight rows in flight per thread: with one, the 8-block launch over the layer-4 map (98 rows x 512 channels per clip, on
-  // the way into the projection head of every chain) was 25 dependent round trips = 40 us for 0.8 MB
   constexpr int UNR = 8;
   for (int r0 = tr; r0 < inner; r0 += RP * UNR) {
     uint4 v[UNR];
@@ -541,17 +542,30 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
       for (int i = 0; i < 8; ++i) s[i] += f[i];
     }
   }
-  block_channel_sum(s, red, G, C, 1, 0);
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] += __shfl_xor(s[i], o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wave * C + tg * 8 + i] = s[i];
+  }
   __syncthreads();
   const float inv = 1.f / (float)inner;
-  for (int i = threadIdx.x; i < C; i += 256)
-    out[(long)blockIdx.x * ldc + i] = (red[i] + red[C + i] + red[2 * C + i] + red[3 * C + i]) * inv;
+  for (int i = threadIdx.x; i < C; i += 1024) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w * C + i];
+    out[(long)blockIdx.x * ldc + i] = t * inv;
+  }
 }
 extern "C" int mscl_pool_fwd(const uint16_t* x, float* out, int outer, int inner, int C, void* stream) {
   if (!x || !out || outer <= 0 || inner <= 0 || C <= 0) return MSCL_E_ARG;
   if (C % 8 || ilog2_exact(C / 8) < 0 || C > 4096) return MSCL_E_SHAPE;
-  const int Cc = C > 512 ? 512 : C;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer, C / Cc), dim3(256), 0, (hipStream_t)stream, x, out, inner, Cc, C);
+  int Cc = inner > 2048 ? 64 : 128;               // (G = 8 / 16 granules: 128 / 64 row lanes)
+  if (Cc > C) Cc = C;                             // (C / 8 is a power of two: G divides 64 whatever the width)
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(outer, C / Cc), dim3(1024), 0, (hipStream_t)stream, x, out, inner, Cc, C);
   MSCL_LAUNCH_CHECK();
   return 0;
 }

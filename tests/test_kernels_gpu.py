@@ -1295,3 +1295,14 @@ def test_conv_dgrad_in_place(case, dev):
         reached[::st[0], ::st[1], ::st[2]] = True
         assert torch.equal(out.cpu()[:, ~reached], base[:, ~reached]), 'a position no tap reaches was rewritten'
         assert not torch.equal(out.cpu()[:, reached], base[:, reached])
+
+
+@pytest.mark.parametrize('outer,inner,C', [(8, 98, 512), (8, 6272, 128), (3, 1, 2048), (2, 2049, 64), (2, 130, 16), (1, 1025, 256)])
+def test_pool_fwd_shapes(outer, inner, C, dev):
+    """mean over the middle axis on the shapes of the step (layer-4 map, the 28 x 28 pyramid level), the Bottleneck trunks' 2048
+    channels, a narrow map, and row counts one past a trip of the 1024-thread layout; twice (a fixed summation order)"""
+    from mscl_amd import kernels as K_
+    x = bf(rnd((outer, inner, C), 51))
+    p = K_.pool_fwd(x.to(dev), outer, inner)
+    close(p, x.double().mean(1).float(), 2e-6 * max(1.0, inner ** 0.5), 'pool fwd')
+    assert torch.equal(K_.pool_fwd(x.to(dev), outer, inner), p)
