@@ -58,12 +58,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int NW = 8;              // waves per block (two per SIMD)
 constexpr int RING = 2, TPS = 2;   // weight ring: RING stages of TPS taps
+// KT = temporal taps: 3 (pad 1: R3D-18 layer 1) or 1 (pad 0: the 1x3x3 conv2 of the SlowOnly-50 / r2d Bottlenecks at 64 channels -- one
+// source plane, nine taps, no plane switch; round 6)
+template <int KT>
 __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const HaloGeom g, const bf16_t* __restrict__ src,
                                                               const bf16_t* __restrict__ wgt, bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ addend, float* __restrict__ stat_sum,
                                                               float* __restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BM = 256;
+  constexpr int BM = 256, NT = 9 * KT;
   constexpr int RPP = 8 * NW;                              // window rows per DMA pass
   constexpr int NHK = (BM + 128 + RPP - 1) / RPP * RPP;    // 384 window rows (BM + 2 * (W + 2) + 2, W <= 61)
   constexpr int PLANE = NHK * 128;
@@ -93,9 +96,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
     const bool ok = q >= 0 && hp >= 1 && hp <= g.H && wp >= 1 && wp <= g.W;
     win_voff[ps] = ok ? (unsigned)((((hp - 1) * g.W + (wp - 1)) * HC + lg * 8) * 2) : HOOB;
   }
-  auto issue_plane = [&](int hp) {                         // source plane t + hp - 1 into the window slot (rows outside the clip: zeros)
-    const bool okp = (unsigned)(t + hp - 1) < (unsigned)g.T;
-    const unsigned so = __builtin_amdgcn_readfirstlane(okp ? (unsigned)((plane + hp - 1) * g.HW) * (HC * 2) : 0u);
+  auto issue_plane = [&](int hp) {                         // source plane t + hp - KT / 2 into the window slot (rows outside the clip: zeros)
+    const bool okp = (unsigned)(t + hp - KT / 2) < (unsigned)g.T;
+    const unsigned so = __builtin_amdgcn_readfirstlane(okp ? (unsigned)((plane + hp - KT / 2) * g.HW) * (HC * 2) : 0u);
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       const unsigned vo = okp ? win_voff[ps] : HOOB;
@@ -103,13 +106,13 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
     }
   };
   const int w_row = tid >> 3, w_lg = tid & 7;
-  const unsigned w_voff0 = (unsigned)((w_row * 27 * HC + (w_lg ^ (w_row & 7)) * 8) * 2);     // source-side swizzle
+  const unsigned w_voff0 = (unsigned)((w_row * NT * HC + (w_lg ^ (w_row & 7)) * 8) * 2);     // source-side swizzle
   auto issue_weights = [&](int tap) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(tap * HC * 2));
     unsigned char* dst = Ws + (((tap / TPS) % RING) * TPS + tap % TPS) * (64 * 128) + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_ptr_t)(dst), 16, w_voff0, so, 0, 0);
   };
-  auto tap_plane = [&](int kt) { return mode ? 2 - kt : kt; };
+  auto tap_plane = [&](int kt) { return mode ? KT - 1 - kt : kt; };
   auto tap_shift = [&](int kh, int kw) { return mode ? (2 - kh) * g.Wp + (2 - kw) : kh * g.Wp + kw; };
 
   // ---- prologue: first plane, the first RING weight stages ----
@@ -149,11 +152,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
     else if ((n) == 4) HB_WAIT(4); else if ((n) == 3) HB_WAIT(3); else if ((n) == 2) HB_WAIT(2); else if ((n) == 1) HB_WAIT(1); else HB_WAIT(0); } while (0)
   // ---- a ring stage = TPS taps: one barrier per STAGE (it publishes the next stage and frees the one just used) instead of one per
   // tap -- 17 barriers per block instead of 31; the DMA of a stage has a whole stage of MFMAs to land under ----
-  constexpr int NST = (27 + TPS - 1) / TPS;
-  auto taps_in = [](int st) { return st < 0 || st >= NST ? 0 : (27 - st * TPS < TPS ? 27 - st * TPS : TPS); };
+  constexpr int NST = (NT + TPS - 1) / TPS;
+  auto taps_in = [](int st) { return st < 0 || st >= NST ? 0 : (NT - st * TPS < TPS ? NT - st * TPS : TPS); };
   auto issue_stage = [&](int st) {
 #pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) if (st < NST && st * TPS + tt < 27) issue_weights(st * TPS + tt);
+    for (int tt = 0; tt < TPS; ++tt) if (st < NST && st * TPS + tt < NT) issue_weights(st * TPS + tt);
   };
   {   // plane + stage 0 landed; stages 1 .. RING - 1 stay in flight
     int infl = 0;
@@ -165,12 +168,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_halo64b_kernel(const Hal
   asm volatile("" ::: "memory");
   read_half(0, 0, 0);
 #pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
+  for (int tap = 0; tap < NT; ++tap) {
     read_half(tap, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     mma(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (tap + 1 < 27) {
+    if (tap + 1 < NT) {
       const bool edge = (tap + 1) % TPS == 0;              // tap + 1 opens a new stage
       const int st_e = tap / TPS;                          // the stage tap belongs to
       if ((tap + 1) % 9 == 0) {
@@ -310,8 +313,8 @@ extern "C" int mscl_conv_halo64(const mscl_conv_desc* d, int mode, const uint16_
 static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, const uint16_t* w, uint16_t* out,
                        const uint16_t* addend, float* ssum, float* ssq, int stat_stride, void* stream) {
   if (!d || !src || !w || !out) return MSCL_E_ARG;
-  if (d->C != HC || d->K != HC || d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 ||
-      d->pT != 1 || d->pH != 1 || d->pW != 1) return 0;
+  if (d->C != HC || d->K != HC || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pH != 1 || d->pW != 1) return 0;
+  if (!((d->kT == 3 && d->pT == 1) || (d->kT == 1 && d->pT == 0))) return 0;
   HaloGeom g{};
   g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
   if (HBM + 2 * g.Wp + 2 > NH || (long)d->N * d->T * g.HW * HC * 2 >= (1L << 31)) return 0;
@@ -321,12 +324,14 @@ static int halo_launch(const mscl_conv_desc* d, int mode, const uint16_t* src, c
   g.stat_stride = stat_stride;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64b_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const unsigned nblk = (unsigned)(d->N * d->T * g.tiles);
-  hipLaunchKernelGGL(conv_halo64b_kernel, dim3(nblk), dim3(64 * NW), (size_t)NH * 128 + (size_t)RING * TPS * 64 * 128, (hipStream_t)stream, g, src, w,
-                     out, addend, ssum, ssq);
+  const size_t lds = (size_t)NH * 128 + (size_t)RING * TPS * 64 * 128;
+  if (d->kT == 3) hipLaunchKernelGGL(conv_halo64b_kernel<3>, dim3(nblk), dim3(64 * NW), lds, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
+  else hipLaunchKernelGGL(conv_halo64b_kernel<1>, dim3(nblk), dim3(64 * NW), lds, (hipStream_t)stream, g, src, w, out, addend, ssum, ssq);
   MSCL_LAUNCH_CHECK();
   ++g_halo_launches;
   return 1;

@@ -35,7 +35,8 @@ struct WHGeom {
   int total;                        // plane tiles = N * T * tiles
   int gk;                           // slots: blocks per (kt, channel slice)
   int planes;                       // N * T
-  int C, K, ncs, nsub;              // channels of x / dy; ci slices (C / 64); blocks per slot = 3 * (K/64) * (C/64)
+  int C, K, ncs, nsub;              // channels of x / dy; ci slices (C / 64); blocks per slot = KT * (K/64) * (C/64)
+  int KT;                           // temporal taps: 3 (pad 1) or 1 (pad 0: the 1x3x3 conv2 of the Bottleneck trunks, round 6)
   FastDiv dWp, dTiles, dT, dPlanes;
 };
 
@@ -75,8 +76,9 @@ __global__ __launch_bounds__(64 * WH_NW, 1) void wgrad_halo64_kernel(const WHGeo
   const int wq = wave & 3, grp = wave >> 2;                // ci tile of the wave; k-step group
   // the three kt blocks of a slot: consecutive logical ids = one XCD (its L2 then serves two of the three reads of every tile)
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int sub = lin % g.nsub, slot = lin / g.nsub;       // sub = (co slice * ncs + ci slice) * 3 + kt
-  const int kt = sub % 3, cs = (sub / 3) % g.ncs, kslice = sub / (3 * g.ncs);
+  const int sub = lin % g.nsub, slot = lin / g.nsub;       // sub = (co slice * ncs + ci slice) * KT + kt
+  const int KT = __builtin_amdgcn_readfirstlane(g.KT), ktc = KT >> 1;      // ktc = the temporal pad
+  const int kt = sub % KT, cs = (sub / KT) % g.ncs, kslice = sub / (KT * g.ncs);
   const int c2 = g.C * 2, k2 = g.K * 2;                    // row pitch of x / dy in bytes
   const auto rs_x = wh_rsrc(x);
   const auto rs_dy = wh_rsrc(dy);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64 * WH_NW, 1) void wgrad_halo64_kernel(const WHGeo
     while (it < i_end) {
       const int plane = item_plane(it);
       const int t = plane - fdiv(plane, g.dT) * g.T;
-      if ((unsigned)(t + kt - 1) < (unsigned)g.T) break;
+      if ((unsigned)(t + kt - ktc) < (unsigned)g.T) break;
       it += i_step;
     }
     return it;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(64 * WH_NW, 1) void wgrad_halo64_kernel(const WHGeo
     const int q0 = g.Wp + tile * 256;
     x_q = q0 - g.Wp - 1 + prow;                            // >= -1
     d_q = q0 + prow;
-    xs = __builtin_amdgcn_readfirstlane((unsigned)((plane + kt - 1) * g.HW) * (unsigned)c2);
+    xs = __builtin_amdgcn_readfirstlane((unsigned)((plane + kt - ktc) * g.HW) * (unsigned)c2);
     ds = __builtin_amdgcn_readfirstlane((unsigned)(plane * g.HW) * (unsigned)k2);
   };
   auto issue_piece = [&](int k, int stage) {               // k (wave-uniform, runtime) in [0, NP), issued in order
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * WH_NW, 1) void wgrad_halo64_kernel(const WHGeo
 // dw[co][kt*9 + t9][ci] += sum over the gk slabs of (kt, channel slice), in a fixed order.  One thread per float4 of a slab (the four
 // co of one accumulator): 16-byte loads that a wave reads 1 KB at a time, four owned elements of dw updated by plain adds.
 __global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float4* __restrict__ slabs4, float* __restrict__ dw, int gk, int nsub,
-                                                                  int ncs, int C, long total4) {
+                                                                  int ncs, int C, long total4, int KT) {
   constexpr int S4 = WH_SLAB / 4;                          // float4 per slab
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= total4) return;
@@ -293,10 +295,10 @@ __global__ __launch_bounds__(256) void wgrad_halo64_reduce_kernel(const float4* 
   const float r4[4] = {(s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y),
                        (s4[0].z + s4[1].z) + (s4[2].z + s4[3].z), (s4[0].w + s4[1].w) + (s4[2].w + s4[3].w)};
   const int lane = q & 63, u36 = q >> 6, wq = u36 / 36, v36 = u36 - wq * 36, t9 = v36 >> 2, i = v36 & 3;
-  const int kt = sub % 3, cs = sub / 3, cis = cs % ncs, cos = cs / ncs;
+  const int kt = sub % KT, cs = sub / KT, cis = cs % ncs, cos = cs / ncs;
   const int co0 = cos * 64 + i * 16 + (lane >> 4) * 4, ci = cis * 64 + wq * 16 + (lane & 15);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dw[((long)(co0 + r) * 27 + kt * 9 + t9) * C + ci] += r4[r];     // one owner per element: plain adds, the same bits every run
+  for (int r = 0; r < 4; ++r) dw[((long)(co0 + r) * (9 * KT) + kt * 9 + t9) * C + ci] += r4[r];     // one owner per element: plain adds, the same bits every run
 }
 
 static long g_wgrad_halo_launches = 0;
@@ -315,14 +317,15 @@ static int wh_cus() {
 // planes of at least MSCL_WGRAD_HALO_MIN padded positions (default 200: the 14 x 16 planes of layer 3 fill 87 % of one
 // 256-position tile; the 7 x 9 planes of layer 4 would fill 25 % and stay with the general kernel)
 static bool wh_shape(const mscl_conv_desc* d) {
-  if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
+  if (d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pH != 1 || d->pW != 1) return false;
+  if (!((d->kT == 3 && d->pT == 1) || (d->kT == 1 && d->pT == 0))) return false;
   if ((d->C % 64) || (d->K % 64) || d->C > 512 || d->K > 512) return false;
   const int Wp = d->W + 2;
   if (256 + 2 * Wp + 2 > WH_XROWS) return false;
   if ((long)d->N * d->T * d->H * d->W * d->C * 2 >= (1L << 31) || (long)d->N * d->T * d->H * d->W * d->K * 2 >= (1L << 31)) return false;
   static MsclTune t_min("MSCL_WGRAD_HALO_MIN");
   if ((long)d->H * Wp < t_min.get(200)) return false;
-  const int nsub = 3 * (d->C / 64) * (d->K / 64);
+  const int nsub = d->kT * (d->C / 64) * (d->K / 64);
   if (nsub > wh_cus()) return false;
   // enough plane tiles for every block to walk a few: a block that stages one or two items pays its prologue, its pair reduction
   // and its 147-KB slab for nothing (128 -> 128 on the 4 x 14 x 14 pyramid level, 32 items over 21 x 12 blocks: 27.8 vs 23.0 us
@@ -332,7 +335,7 @@ static bool wh_shape(const mscl_conv_desc* d) {
   return items * nsub >= (long)t_items.get(4) * wh_cus();
 }
 static int wh_slots(const mscl_conv_desc* d) {
-  const int nsub = 3 * (d->C / 64) * (d->K / 64);
+  const int nsub = d->kT * (d->C / 64) * (d->K / 64);
   const int tiles = (d->H * (d->W + 2) + 255) / 256;
   int gk = wh_cus() / nsub;
   if (gk > d->N * d->T * tiles) gk = d->N * d->T * tiles;
@@ -341,7 +344,7 @@ static int wh_slots(const mscl_conv_desc* d) {
 // floats of workspace mscl_wgrad_halo64 wants (0: the layer is not covered)
 extern "C" int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d) {
   if (!d || !wh_shape(d)) return 0;
-  return (int64_t)wh_slots(d) * 3 * (d->C / 64) * (d->K / 64) * WH_SLAB;
+  return (int64_t)wh_slots(d) * d->kT * (d->C / 64) * (d->K / 64) * WH_SLAB;
 }
 
 // returns 1 if launched, 0 if the shape / workspace is not covered, <0 / >0 on error
@@ -350,7 +353,7 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   if (!wh_shape(d)) return 0;
   WHGeom g{};
   g.N = d->N; g.T = d->T; g.H = d->H; g.W = d->W; g.HW = d->H * d->W; g.Wp = d->W + 2;
-  g.C = d->C; g.K = d->K; g.ncs = d->C / 64; g.nsub = 3 * g.ncs * (d->K / 64);
+  g.C = d->C; g.K = d->K; g.ncs = d->C / 64; g.KT = d->kT; g.nsub = g.KT * g.ncs * (d->K / 64);
   g.tiles = (d->H * g.Wp + 255) / 256;
   g.total = d->N * d->T * g.tiles;
   static bool attr_done = false;
@@ -369,7 +372,7 @@ int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t
   MSCL_LAUNCH_CHECK();
   const long total4 = (long)g.nsub * (WH_SLAB / 4);
   hipLaunchKernelGGL(wgrad_halo64_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, (const float4*)ws, dw, gk, g.nsub,
-                     g.ncs, d->C, total4);
+                     g.ncs, d->C, total4, g.KT);
   MSCL_LAUNCH_CHECK();
   ++g_wgrad_halo_launches;
   return 1;

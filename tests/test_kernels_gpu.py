@@ -270,17 +270,19 @@ def test_conv_pp_forced(case, dev, monkeypatch):
 HALO2_CASES = [('h2_small', 2, 4, 12, 12), ('h2_plane56', 1, 3, 56, 56), ('h2_tail', 3, 5, 13, 11), ('h2_w61', 1, 2, 9, 61), ('h2_T1', 2, 1, 20, 20)]
 
 
+@pytest.mark.parametrize('kt', [3, 1], ids=['k333', 'k133'])
 @pytest.mark.parametrize('case', HALO2_CASES, ids=[c[0] for c in HALO2_CASES])
-def test_conv_halo_two_blocks(case, dev, monkeypatch):
+def test_conv_halo_two_blocks(case, kt, dev, monkeypatch):
     """the window-resident layer-1 conv (the A/B arms of round 4 -- one block per CU, one-tap ring stages of depth 2 / 3 / 4 -- were
-    deleted in round 5 with their switches)"""
+    deleted in round 5 with their switches); kt = 1 (round 6): the same kernel on ONE source plane, the 1x3x3 / pad (0,1,1) conv2 of
+    the 64-channel Bottlenecks"""
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W = case
     C = K = 64
-    kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    kern, stride, pad = (kt, 3, 3), (1, 1, 1), (kt // 2, 1, 1)
     monkeypatch.setenv('MSCL_HALO', '1')
     lib.tune()
-    x = bf(rnd((N, T, H, W, C), 51)); w = bf(rnd((K, *kern, C), 52, scale=(2.0 / (C * 27)) ** 0.5))
+    x = bf(rnd((N, T, H, W, C), 51)); w = bf(rnd((K, *kern, C), 52, scale=(2.0 / (C * 9 * kt)) ** 0.5))
     d = K_.conv_desc(x.shape, K, kern, stride, pad)
     xg, wg = x.to(dev), w.to(dev)
     n0 = lib.call_raw('mscl_debug_halo_launches')
@@ -297,7 +299,7 @@ def test_conv_halo_two_blocks(case, dev, monkeypatch):
     dy = bf(rnd(tuple(yr.shape), 55))
     yr.backward(dy.float())
     wT = torch.empty((C, *kern, K), dtype=torch.bfloat16, device=dev)
-    K_.weight_transpose(wg, wT, K, 27, C)
+    K_.weight_transpose(wg, wT, K, 9 * kt, C)
     n1 = lib.call_raw('mscl_debug_halo_launches')
     dx = K_.conv3d_dgrad(dy.to(dev), wT, d)
     add = bf(rnd(tuple(x.shape), 56))
@@ -328,11 +330,13 @@ WGRAD_HALO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('kt', [3, 1], ids=['k333', 'k133'])
 @pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=[c[0] for c in WGRAD_HALO_CASES])
-def test_conv_wgrad_halo_forced(case, dev, monkeypatch):
+def test_conv_wgrad_halo_forced(case, kt, dev, monkeypatch):
+    """kt = 1 (round 6): the same kernel with ONE temporal tap / pad 0 -- the 1x3x3 conv2 of the Bottleneck trunks"""
     from mscl_amd import kernels as K_, lib
     name, N, T, H, W, C, K = case
-    kern, stride, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    kern, stride, pad = (kt, 3, 3), (1, 1, 1), (kt // 2, 1, 1)
     monkeypatch.setenv('MSCL_WGRAD_HALO_MIN', '1')            # planes of any size
     monkeypatch.setenv('MSCL_WGRAD_HALO_ITEMS', '0')          # ... and any number of them
     lib.tune()

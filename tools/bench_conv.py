@@ -48,6 +48,9 @@ SHAPES_R50 = [
     ('r50_l1_c3_64_256', (8, 16, 56, 56, 64), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ('r50_l1_c1_256_64', (8, 16, 56, 56, 256), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ('r50_l2_c2_133_s2', (8, 16, 56, 56, 128), 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ('r50_l2_c2_133', (8, 16, 28, 28, 128), 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r50_l3_c2_133', (8, 16, 14, 14, 256), 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r50_l4_c2_133', (8, 16, 7, 7, 512), 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('r50_l2_c3_128_512', (8, 16, 28, 28, 128), 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ('r50_l2_c1_512_128', (8, 16, 28, 28, 512), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ('r50_l3_c1_311', (8, 16, 14, 14, 1024), 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
