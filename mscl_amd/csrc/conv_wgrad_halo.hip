@@ -313,7 +313,8 @@ static int wh_cus() {
   }
   return cus;
 }
-// which layers take this kernel: 3x3x3 / 1 / 1, channel counts multiples of 64, planes whose padded rows fit the 376-row window;
+// which layers take this kernel: 3x3x3 / 1 / 1 (and, round 6, 1x3x3 / 1 / (0,1,1): SlowOnly-50 layers 1-3 78.6 / 77.0 / 63.8 -> 62.4 / 54.0 / 53.0 us,
+// the 28 x 28 FPN level of the R3D-18 step 45.2 -> 37.5 us alone, the step unchanged), channel counts multiples of 64, planes whose padded rows fit the 376-row window;
 // planes of at least MSCL_WGRAD_HALO_MIN padded positions (default 200: the 14 x 16 planes of layer 3 fill 87 % of one
 // 256-position tile; the 7 x 9 planes of layer 4 would fill 25 % and stay with the general kernel)
 static bool wh_shape(const mscl_conv_desc* d) {
