@@ -13,6 +13,7 @@ fill.  Rank 0 prints ONE JSON line (contract in the task statement) with two ext
   cpu_baseline  the oracle/ restatement ("port") timed on this box's host cores on a bounded sample
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -358,11 +359,11 @@ def main():
         ach2 = flops2 / (avg2 * 1e-3) / 1e12 if ms2 else 0.0
         traffic = None
         tname = None
-        for tname in ('r05_traffic_layer1.json', 'r04_traffic_layer1.json', 'r03_traffic_layer1.json', 'r02_traffic_layer1.json', 'r01_traffic_layer1.json'):     # PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see the file
-            tp = os.path.join(ROOT, 'profiles', tname)
-            if os.path.exists(tp):
-                traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
-                break
+        # PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/evidence_r0N.sh), the newest committed round first; see the file
+        for tp in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic_layer1.json')), reverse=True):
+            traffic = json.load(open(tp)).get('traffic_bytes_per_launch')
+            tname = os.path.basename(tp)
+            break
         step_s = dt / args.steps
         line = {
             'metric': 'clip-pairs/sec/node (R3D-18, 16x112^2, bs8/gpu)',
