@@ -58,6 +58,7 @@ int64_t mscl_debug_pp_launches(void);
 int64_t mscl_debug_halo_launches(void);
 int64_t mscl_debug_stem_launches(void);   /* conv_stem.hip: the window-resident RGB-stem forward */
 int64_t mscl_debug_wgrad_halo_launches(void);
+int64_t mscl_debug_wgrad_stem_launches(void);   /* window-resident weight gradient of the W-paired RGB stem (conv_wgrad_stem.hip) */
 int64_t mscl_debug_thin_launches(void);
 int64_t mscl_debug_k1_launches(void);         /* thin-K 1x1x1 streaming kernel (csrc/conv_k1.hip) */
 int64_t mscl_debug_dgrad_s2_launches(void);   /* window-resident stride-2 input gradient (csrc/conv_dgrad_s2.hip) */

@@ -13,7 +13,7 @@ NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $NOPK"
 mkdir -p build
 pids=()
-SRCS="conv_igemm conv_pp conv_dgrad_s2 conv_thin conv_k1 conv_halo conv_stem conv_wgrad conv_wgrad_halo bn_act elementwise pool3d color_aug datapath contrast optim"
+SRCS="conv_igemm conv_pp conv_dgrad_s2 conv_thin conv_k1 conv_halo conv_stem conv_wgrad conv_wgrad_halo conv_wgrad_stem bn_act elementwise pool3d color_aug datapath contrast optim"
 for f in $SRCS; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ igemm.h -nt build/$f.o ] || [ ../../include/mscl_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o 2> >(grep -v "is not a recognized feature for this target" >&2) &

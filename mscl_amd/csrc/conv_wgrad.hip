@@ -473,6 +473,8 @@ extern "C" int64_t mscl_debug_wgrad_group_launches(void) { return g_wgrad_group_
 
 int mscl_wgrad_halo64(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                       hipStream_t st);           // conv_wgrad_halo.hip
+int mscl_wgrad_stem(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
+                    hipStream_t st);             // conv_wgrad_stem.hip
 int mscl_wgrad_thin(const mscl_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw, float* ws, int64_t ws_floats,
                     hipStream_t st);             // conv_thin.hip
 // 128 x 128 tile, 2 x 2 waves of 64 x 64: per 64-position step a wave makes 16 transposing reads for 16 MFMAs (the 64 x 64
@@ -598,7 +600,13 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
     tres = mscl_wgrad_thin(d, x, dy, dw, ws, ws_floats - tail, st);
     if (tres < 0 || tres > 1) return tres;
   }
-  if (hres == 1 || pres == 1 || tres == 1) e = 0;
+  int sres = 0;
+  if (hres == 0 && tres == 0 && ws != nullptr) {          // W-paired RGB stem: window-resident kernel (conv_wgrad_stem.hip)
+    const long tail = (mscl_det() && dbias) ? (long)MSCL_DET_PARTS * d->K : 0;
+    sres = mscl_wgrad_stem(d, x, dy, dw, ws, ws_floats - tail, st);
+    if (sres < 0 || sres > 1) return sres;
+  }
+  if (hres == 1 || pres == 1 || tres == 1 || sres == 1) e = 0;
   else if (big_tile(d)) e = launch_w<128, 128, 2>(g, x, dy, dw, st, dws, dfl);
   else if (d->K >= 64) e = launch_w<64, 64>(g, x, dy, dw, st, dws, dfl);
   else if (d->K == 32) e = launch_w<32, 64>(g, x, dy, dw, st, dws, dfl);
@@ -631,10 +639,12 @@ extern "C" int mscl_conv3d_wgrad(const mscl_conv_desc* d, const uint16_t* x, con
 // the bias partials); 0 outside deterministic mode for layers that do not use the window-resident kernel
 extern "C" int64_t mscl_wgrad_thin_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_wgrad_halo_ws(const mscl_conv_desc* d);
+extern "C" int64_t mscl_wgrad_stem_ws(const mscl_conv_desc* d);
 extern "C" int64_t mscl_conv3d_wgrad_ws(const mscl_conv_desc* d, int with_bias) {
   if (!d) return 0;
   int64_t pp = mscl_wgrad_halo_ws(d);
   if (pp == 0) pp = mscl_wgrad_thin_ws(d);
+  if (pp == 0) pp = mscl_wgrad_stem_ws(d);
   if (!mscl_det()) return pp;
   if (pp > 0) return pp + (with_bias ? (int64_t)MSCL_DET_PARTS * d->K : 0);
   const int64_t dwn = (int64_t)d->K * d->kT * d->kH * d->kW * d->C;

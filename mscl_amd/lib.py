@@ -39,6 +39,7 @@ _SIGS = {
     'mscl_debug_halo_launches': [],
     'mscl_debug_stem_launches': [],
     'mscl_debug_wgrad_halo_launches': [],
+    'mscl_debug_wgrad_stem_launches': [],
     'mscl_debug_thin_wgrad_launches': [],
     'mscl_get_deterministic': [],
     'mscl_tuning_reload': [],
@@ -101,7 +102,7 @@ _SIGS = {
     'mscl_sgd_step': [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P],
     'mscl_cast_bf16': [P, P, c_int64, P],
 }
-_INT64_RESULT = ('mscl_debug_dgrad_s2_launches', 'mscl_debug_wgrad_group_launches', 'mscl_wgrad_halo_ws', 'mscl_debug_halo_launches', 'mscl_debug_stem_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_k1_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
+_INT64_RESULT = ('mscl_debug_wgrad_stem_launches', 'mscl_debug_dgrad_s2_launches', 'mscl_debug_wgrad_group_launches', 'mscl_wgrad_halo_ws', 'mscl_debug_halo_launches', 'mscl_debug_stem_launches', 'mscl_debug_wgrad_halo_launches', 'mscl_det_parts_floats', 'mscl_conv3d_wgrad_ws', 'mscl_debug_pp_launches', 'mscl_debug_thin_launches', 'mscl_debug_k1_launches', 'mscl_debug_thin_wgrad_launches', 'mscl_wgrad_thin_ws')
 EXPORTS = tuple(_SIGS)
 
 _lib = None

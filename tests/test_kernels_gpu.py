@@ -1310,3 +1310,47 @@ def test_pool_fwd_shapes(outer, inner, C, dev):
     p = K_.pool_fwd(x.to(dev), outer, inner)
     close(p, x.double().mean(1).float(), 2e-6 * max(1.0, inner ** 0.5), 'pool fwd')
     assert torch.equal(K_.pool_fwd(x.to(dev), outer, inner), p)
+
+
+# conv_wgrad_stem.hip (round 6): the window-resident weight gradient of the W-paired RGB stems on the same cases as the forward kernel:
+# launch counter, CPU fp32 autograd of F.conv3d on the 3-channel clip (through the fold of the paired staging buffer), accumulation
+# into a non-zero dw, the same bits on every run (slot-ordered slab sums), and the general kernel's result.
+@pytest.mark.parametrize('case', STEM_CASES, ids=[c[0] for c in STEM_CASES])
+def test_conv_wgrad_stem_window_resident(case, dev):
+    from mscl_amd import kernels as K_
+    from mscl_amd import lib
+    name, N, T, H, W, kT, sT, pT, forced = case
+    Co = 64
+    x3 = bf(rnd((N, T, H, W, 3), 11)); w = bf(rnd((Co, kT, 7, 7, 3), 12, scale=(2.0 / (3 * 49 * kT)) ** 0.5))
+    x8 = torch.zeros((N, T, H, W, 8), dtype=torch.bfloat16); x8[..., :3] = x3
+    wr = w.float().requires_grad_(True)
+    yr = _conv_ref(x3.float(), wr, (sT, 2, 2), (pT, 3, 3))
+    dy = bf(rnd(tuple(yr.shape), 13))
+    yr.backward(dy.float())
+    xp = K_.pair_w(x8.to(dev))
+    d = K_.conv_desc(tuple(xp.shape), Co, (kT, 7, 4), (sT, 2, 1), (pT, 3, 1))
+    if forced:
+        lib.tune(MSCL_WGRAD_STEM=1)
+    try:
+        n0 = lib.call_raw('mscl_debug_wgrad_stem_launches')
+        dw8 = torch.zeros((Co, kT, 7, 4, 8), dtype=torch.float32, device=dev)
+        K_.conv3d_wgrad(xp, dy.to(dev), d, dw8, None)
+        assert lib.call_raw('mscl_debug_wgrad_stem_launches') == n0 + 1, 'the window-resident stem weight gradient did not take the launch'
+        g = torch.zeros((Co, kT, 7, 7, 3), dtype=torch.float32, device=dev)
+        K_.pair_w_grad_fold(dw8, g)
+        close(g, wr.grad, F32_TOL, f'stem wgrad {name}')
+        assert float(dw8[..., 6:].abs().max()) == 0.0          # channels 6, 7 of a pair are zero in the clip
+        first = dw8.clone()
+        K_.conv3d_wgrad(xp, dy.to(dev), d, dw8, None)            # accumulates
+        assert torch.equal(dw8, 2 * first)
+        for _ in range(3):
+            again = torch.zeros_like(dw8)
+            K_.conv3d_wgrad(xp, dy.to(dev), d, again, None)
+            assert torch.equal(again, first)
+        lib.tune(MSCL_WGRAD_STEM=0)
+        ref = torch.zeros_like(dw8)
+        K_.conv3d_wgrad(xp, dy.to(dev), d, ref, None)
+        assert lib.call_raw('mscl_debug_wgrad_stem_launches') == n0 + 5
+        close(first, ref, F32_TOL, 'window-resident stem weight gradient vs general kernel')
+    finally:
+        lib.tune(MSCL_WGRAD_STEM=None)
