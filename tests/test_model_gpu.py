@@ -52,7 +52,24 @@ def loss_close(got, ref, what, tol=2e-3):
     assert abs(got - ref) <= tol * max(1.0, abs(ref)), f'{what}: hip {got} vs ref {ref}'
 
 
-def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None):
+def lmcl_near_ties(orc, eps=0.01):
+    """{'top1_acc_pos': n1, 'top5_acc_pos': n5}: how many LMCL rows of the oracle's last step have their label's score within `eps`
+    of the top-1 / top-5 boundary -- the rows whose rank a bf16 pipeline may legitimately change.  eps = 0.01: a cosine good to 7e-4
+    (bf16 conv operands under fp32 sums) divided by the temperature 0.07; at B = 32 the scores have std 0.24 and 3 / 7 of the 128 rows
+    lie that close (tools/scratch/lmcl_margins.py), and the HIP path moved 0-3 of them from run to run."""
+    from oracle import mscl as om
+    f = orc._features
+    scores, labels = om.lmcl_scores(f['img']['q_mlvl'][0], f['base']['q_mlvl'][-1], f['aug']['q_mlvl'][-1], orc.T,
+                                    getattr(orc.sup_head, 'trans_flow', None))
+    scores = scores.detach().double()
+    n = scores.shape[0]
+    lab = scores[torch.arange(n), labels]
+    others = scores.clone(); others[torch.arange(n), labels] = -1e9
+    srt = others.sort(dim=1, descending=True).values
+    return {f'top{k}_acc_pos': int(((lab - srt[:, k - 1]).abs() < eps).sum()) for k in (1, 5)}
+
+
+def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None, pos_flips=None):
     """all log entries of a step against the reference / oracle: losses to `loss_tol` relative, accuracies exactly (they are
     k / rows for an integer k; `rows` given -> at most one row may flip, for full-size batches where a positive sits within
     bf16 noise of the 5th-largest negative).  `pos_rows`: row count of the LMCL scores (B * t); with the closed-form weights
@@ -68,6 +85,8 @@ def logs_match(got, ref, what, rows=None, loss_tol=2e-3, pos_rows=None):
             # 64 rows (round 6: 2 of 128 rows flipped in one of five runs at B = 32, 76 / 128 vs 78 / 128; the default mode's float
             # atomics move the features from run to run)
             flips = max(1, -(-r // 64)) if (r is not None and k.endswith('_pos') and pos_rows) else 1
+            if pos_flips is not None and k in pos_flips:     # counted from the oracle's own margins (lmcl_near_ties), at least one
+                flips = max(1, pos_flips[k])
             slack = 1e-6 if r is None else flips / r + 1e-6
             assert abs(got[k] - v) <= slack, f'{what} {k}: hip {got[k]} vs ref {v}'
 
@@ -1181,8 +1200,8 @@ def test_standalone_mocov2_step_vs_oracle(dev):
 def test_step_at_the_shipped_batch_of_32(dev):
     """videos_per_gpu = 32 is the batch the shipped config and the reference train with (mscl_r18_cosm_lr2e-2.py:50, clip 8 x
     112^2): 96 stacked InfoNCE rows (three 32-row tiles), 64 rows through the flow projection head in the batched flow pass, 128
-    LMCL rows.  All 23 log entries against the oracle (losses to 1e-3 relative, at most one row of an accuracy flips), integer
-    bookkeeping exact."""
+    LMCL rows.  All 23 log entries against the oracle (losses to 1e-3 relative, at most one row of an InfoNCE accuracy flips, the LMCL
+    accuracies by at most the number of rows the oracle itself has within bf16 noise of the rank boundary), integer bookkeeping exact."""
     from mscl_amd.synthetic import synthetic_batch
     from oracle import fill as ofill, mscl as om
     B, T, H, Kq = 32, 8, 112, 65536
@@ -1194,7 +1213,9 @@ def test_step_at_the_shipped_batch_of_32(dev):
     orc = om.MSCLWithAug(num_frames=T, K=Kq); ofill.fill_module(orc); orc.train()
     torch.manual_seed(100)
     oo = orc.train_step(batch)
-    logs_match(out['log_vars'], oo['log_vars'], 'B=32', rows=B, loss_tol=1e-3, pos_rows=B * (T // 2))
+    near = lmcl_near_ties(orc)
+    assert near['top5_acc_pos'] <= 16, near                   # (the bound stays a bound: an eighth of the rows at most)
+    logs_match(out['log_vars'], oo['log_vars'], 'B=32', rows=B, loss_tol=1e-3, pos_rows=B * (T // 2), pos_flips=near)
     for rec in (model.recognizer, model.recognizer_flow):
         assert int(rec.queue_ptr) == B and rec.batch_size == B
         assert int(rec.count.min()) == 1 and int(rec.count.max()) == 1        # moco.py:434-437: every age +1, the new slots reset to 1
