@@ -55,7 +55,7 @@ cd $R
 { echo "# commit $H: the stand-alone reproducer of the round-5 dropped corner against the PRODUCT library (tools/diag/flake_repro: 1 000 000 comparisons), then its VALU probe in the compiled kernel's packed-fp32 form beside the RGB key trunk's convs on this box"
   tools/diag/flake_repro --replays 50000 2>&1 | grep "device\|reference\|SUMMARY"; tools/diag/flake_repro --replays 20000 --probe 0 --side convs --streams B 2>&1 | grep "PROBE"; rocm-smi --showuniqueid 2>/dev/null | grep -i unique; } > $O/flake_repro.txt
 { echo "# commit $H: the GPU suite under the two hazard probes of tests/conftest.py"
-  for v in "MSCL_TEST_POISON=2" "MSCL_TEST_JITTER=200000"; do echo "\$ $v python -m pytest tests -q -m gpu"; env $v python3 -m pytest tests -q -m gpu 2>&1 | tail -2; done; } > $O/probe_runs.txt
+  for v in "MSCL_TEST_POISON=2" "MSCL_TEST_JITTER=200000"; do echo "\$ $v python -m pytest tests -q -m gpu"; env $v python3 -m pytest tests -q -m gpu > $O/probe_$v.log 2>&1; grep -E "^(FAILED|E  )" $O/probe_$v.log | head -20; tail -1 $O/probe_$v.log; done; } > $O/probe_runs.txt
 F=$R/tests/golden/oracle_curve_b8_t16_112_k65536.json
 if [ -f $F ]; then
   n=$(python3 -c "import json;print(len(json.load(open('$F'))['steps']))")
