@@ -737,6 +737,7 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
     // mostly zeros that the entry conv's input gradient reads back as its addend (nn._BlockFn / _BottleneckFn)
     const bool inplace = addend != nullptr && addend == dx;
     int nc = 0;
+    bool dropped = false;
     for (int a = 0; a < d->sT; ++a) for (int b = 0; b < d->sH; ++b) for (int c = 0; c < d->sW; ++c) {
       ClassInfo& ci = g.cls[nc];
       ci.ro[0] = (unsigned char)a; ci.ro[1] = (unsigned char)b; ci.ro[2] = (unsigned char)c;
@@ -751,9 +752,13 @@ extern "C" int mscl_conv3d_dgrad(const mscl_conv_desc* d, const uint16_t* dy, co
         }
       }
       ci.ntl = (unsigned char)n;
+      if (ci.M > 0 && inplace && n == 0) dropped = true;
       if (ci.M > 0 && !(inplace && n == 0)) ++nc;
     }
     if (nc == 0) return 0;                            // (in place and no position receives a tap: nothing to add)
+    // classes were dropped: no split-K -- its finalize pass walks EVERY position of dx and would add slab rows nobody wrote
+    // (reachable from 1024 dy channels up: K steps >= 32 and few tiles, i.e. the small-map Bottleneck shortcuts)
+    if (dropped) { splitk_ws = nullptr; splitk_ws_floats = 0; }
     g.nclass = nc;
   }
   return launch_igemm(g, dy, wT, dx, nullptr, addend, nullptr, nullptr, 0, splitk_ws, (long)splitk_ws_floats, (hipStream_t)stream);

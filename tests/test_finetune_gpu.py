@@ -128,7 +128,11 @@ def test_ssl_pretrain_loading_feature_extraction_and_finetuning(dev):
         out['loss'].backward()
         opt.step()
         losses.append(out['log_vars']['loss_cls'])
-    assert losses[-1] < 0.5 * losses[0], losses
+    # the loss of a step is taken WITH that step's dropout mask (p = 0.5 on 512 features of 4 clips): once the batch is fitted most
+    # steps read ~0.001 and one in ten spikes (0.1 ... 1.4 seen: a mask that removes the features the fit leans on), so the claim
+    # "fine-tuning reduces the loss" is read off the median of the last five steps, not off the last one (round 6: the last-step form
+    # failed once in 16 fresh processes, profiles/r06_probe_runs.txt)
+    assert sorted(losses[-5:])[2] < 0.5 * losses[0], losses
     with pytest.raises(NotImplementedError):
         build_model(dict(type='Recognizer3D', backbone=dict(type='ResNet3dSlowOnly'), cls_head=None))
 
