@@ -1272,6 +1272,10 @@ INPLACE_CASES = [
     ('sc_256_512_s122', 1, 4, 14, 14, 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     ('sc_flow_16_32_s122', 2, 4, 28, 28, 16, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     ('k333_s222', 1, 4, 12, 12, 64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    # 1024 dy channels on a small map: 32 K steps and few tiles, the shape on which split-K would engage -- it must not once classes are
+    # dropped (its finalize pass walks every position of dx)
+    ('sc_512_1024_s122_small', 1, 2, 8, 8, 512, 1024, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ('sc_512_2048_s222_small', 1, 2, 6, 6, 512, 2048, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
 ]
 
 
